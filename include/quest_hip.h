@@ -1,0 +1,152 @@
+/*
+ * quest_hip.h -- C ABI of libquest_hip.so, the MI355X (gfx950) implementation of Quest's
+ * query-aware sparse decode path.
+ *
+ * This is the drop-in boundary: every entry point takes plain device pointers, sizes and a
+ * HIP stream -- no torch types -- and corresponds one-to-one to an operator the reference
+ * exposes through its PyBind module `quest._kernels` (quest/ops/csrc/bsk_ops.cu:4-20,
+ * declarations bsk_ops.h:23-117).  INTEGRATION.md shows the binding a maintainer adds on
+ * the reference side.
+ *
+ * Conventions
+ *   - All tensors are fp16 (the reference dispatches only Half: pytorch_extension_utils.h:25-36),
+ *     contiguous, resident in device memory.  Index tensors are int32.
+ *   - Return value: 0 on success; a positive value is a hipError_t from a launch; a negative
+ *     value is one of the QUEST_E* argument errors below.  quest_error_string() names both.
+ *     Nothing throws; nothing allocates except quest_decode_begin_forward (workspace, like
+ *     BatchDecodeHandler::BeginForward, decode_handler.cuh:73-121).
+ *   - Every launch is asynchronous on `stream` (the reference launches on the NULL stream,
+ *     page.cu:89 / approx_attn.cu:141; here the caller passes torch's current stream).
+ *   - layout: 0 = NHD pool [pages][2][page_size][heads][dim], 1 = HND [pages][2][heads][page_size][dim]
+ *     (quest/utils/utils.py:1-5, kernels/include/decode/decode_page.cuh:196-239).
+ */
+#ifndef QUEST_HIP_H_
+#define QUEST_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* quest_stream_t; /* hipStream_t */
+
+#define QUEST_LAYOUT_NHD 0u
+#define QUEST_LAYOUT_HND 1u
+
+#define QUEST_EINVAL (-1)      /* malformed argument (null pointer, zero size, bad layout) */
+#define QUEST_EUNSUPPORTED (-2) /* head_dim / page_size / group size outside the built set */
+#define QUEST_ESTATE (-3)      /* forward without begin_forward (decode_handler.cuh:226-231) */
+#define QUEST_ETOOLARGE (-4)   /* top-k row longer than QUEST_TOPK_MAX_ROW */
+
+#define QUEST_TOPK_MAX_ROW 16384u
+
+/*
+ * View of one layer of a paged pool plus one sequence's page table.  Replaces
+ * paged_kv_t<kIndices, layout, half, int32_t> (decode_page.cuh:79-110), which the reference
+ * passes to its kernels by value; so is this.
+ */
+typedef struct quest_paged_kv {
+    void* data;             /* fp16 pool base of this layer (kv_cache.py:111-113 buf_layer) */
+    const int32_t* indices; /* page table; for quest_decode_forward: [num_qo_heads][page_budget] */
+    const int32_t* indptr;  /* device int32[2] = {0, n_pages} */
+    uint32_t num_heads;     /* heads stored in the pool (kv heads) */
+    uint32_t page_size;
+    uint32_t head_dim;
+    uint32_t page_budget;   /* row stride of `indices` in quest_decode_forward, else 0 */
+    uint32_t last_page_len; /* 1..page_size */
+    int32_t last_page_idx;  /* physical id of the sequence's last page */
+    uint32_t layout;
+    uint32_t reserved;
+} quest_paged_kv_t;
+
+const char* quest_error_string(int code);
+
+/* Build identification: "gfx950" and the kernel generation, for logs. */
+const char* quest_build_info(void);
+
+/*
+ * append_kv_cache_decode (bsk_ops.h:70-82, page.cu:6-99 -> AppendPagedKVCacheDecode,
+ * decode_page.cuh:577-597, kernel :398-449).
+ * k, v: [1][num_heads][head_dim].  Writes the token into the last page and folds k into the
+ * page's (max -> K slot, min -> V slot) metadata entry, re-initialising it to -/+65504 when the
+ * token opens a new page.
+ */
+int quest_append_kv_cache_decode(const void* k, const void* v, quest_paged_kv_t kv,
+                                 quest_paged_kv_t metadata, quest_stream_t stream);
+
+/*
+ * append_kv_cache_prefill (bsk_ops.h:56-68, page.cu:101-210 -> AppendPagedKVCachePrefill,
+ * decode_page.cuh:613-642, kernel :471-562).  k, v: [append_len][num_heads][head_dim];
+ * n_pages_host = number of pages of the sequence (the host knows it: len(kv_indices)).
+ */
+int quest_append_kv_cache_prefill(const void* k, const void* v, uint32_t append_len,
+                                  uint32_t n_pages_host, quest_paged_kv_t kv,
+                                  quest_paged_kv_t metadata, quest_stream_t stream);
+
+/*
+ * estimate_attn_score (bsk_ops.h:45-52, estimate.cu:6-84 -> MaxPossibleSampleWithPagedKVCache,
+ * decode_attn.cuh:1092-1149, kernel :245-401).
+ * q: [1][num_qo_heads][head_dim]; o: [num_qo_heads][n_out] fp16 with n_out = (number of KV
+ * pages) - 1; o[h][p] = fp16( sum_d max(q*Kmax, q*Kmin) ).
+ */
+int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo_heads, uint32_t n_out,
+                              quest_paged_kv_t metadata, quest_stream_t stream);
+
+/*
+ * topk_filtering (bsk_ops.h:38-43, topk.cu:7-46 -> decode_select_k, decode_select_k.cuh:25-62,
+ * which calls RAFT's radix_topk_one_block_kernel; re-implemented here).
+ * estimated_value/indices: [num_heads][num_pages]; d_out/indices_out: [num_heads][page_budget].
+ * Deterministic: ties at the k-th value go to the lowest column; output in ascending column order.
+ * `buf` is the reference's scratch argument; unused (may be NULL).
+ */
+int quest_topk_filtering(const void* estimated_value, const int32_t* estimated_indices, void* d_out,
+                         int32_t* indices_out, void* buf, uint32_t num_heads, uint32_t num_pages,
+                         uint32_t page_budget, quest_stream_t stream);
+
+/*
+ * BatchDecodeWithPagedKVCachePyTorchWrapper (bsk_ops.h:84-116, approx_attn.cu:27-150 ->
+ * BatchDecodeHandler, decode_handler.cuh:39-244).
+ */
+typedef struct quest_decode_handler quest_decode_handler_t;
+
+int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout);
+void quest_decode_handler_destroy(quest_decode_handler_t* h);
+
+/* begin_forward: n_selected_pages = indptr[1] - indptr[0] = page budget - 1 (the caller has it on
+ * the host; the reference copies it back from the device, decode_attn.cuh:866-873).  Plans the
+ * split of each head's page list over workgroups and sizes the partial-state workspace. */
+int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_selected_pages,
+                               uint32_t num_qo_heads, uint32_t num_kv_heads, uint32_t head_dim,
+                               uint32_t page_size, quest_stream_t stream);
+int quest_decode_end_forward(quest_decode_handler_t* h);
+
+/* forward: q, o: [1][num_qo_heads][head_dim]; paged_kv.indices = [num_qo_heads][page_budget]
+ * selected physical pages (row stride paged_kv.page_budget), to which the sequence's last page
+ * (last_page_idx, last_page_len tokens) is always added (decode_page.cuh:325-351).
+ * lse: optional float[num_qo_heads] (natural log), may be NULL. */
+int quest_decode_forward(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                         uint32_t num_qo_heads, float* lse, quest_stream_t stream);
+
+/* Introspection of the current plan (for benches/tests): pages per workgroup, workgroups per head. */
+int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_chunk,
+                           uint32_t* chunks_per_head);
+/* Override the planner (0 = automatic).  Used by tuning sweeps. */
+int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);
+
+/*
+ * apply_rope_in_place (bsk_ops.h:25-29, page.cu:212-252 -> QKApplyRotaryInPlace,
+ * decode_page.cuh:695-728).  q: [n][num_qo_heads][dim], k: [n][num_kv_heads][dim], in place.
+ */
+int quest_apply_rope_in_place(void* q, void* k, uint32_t n, uint32_t past_kv_len,
+                              uint32_t num_qo_heads, uint32_t num_kv_heads, uint32_t head_dim,
+                              float rope_scale, float rope_theta, quest_stream_t stream);
+
+/* rms_norm_forward (bsk_ops.h:31-34, rms_norm.cu:160-212). input/output: [rows][cols], weight [cols]. */
+int quest_rms_norm_forward(const void* input, const void* weight, void* output, uint32_t rows,
+                           uint32_t cols, float epsilon, quest_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUEST_HIP_H_ */

@@ -1,0 +1,286 @@
+"""Drop-in for the reference's PyBind module ``quest._kernels`` (quest/ops/csrc/bsk_ops.cu:4-20).
+
+Same 7 free functions + 1 class, same argument order and meaning (bsk_ops.h:23-117); each one
+validates its tensors the way the reference's CHECK_* macros do (pytorch_extension_utils.h:52-66)
+and then calls the matching C-ABI entry point of libquest_hip.so on torch's current stream.
+PyTorch is only the owner of device memory here; all arithmetic is in the HIP library.
+
+``prefill_with_paged_kv_cache`` is outside the sparse-decode hot path: the
+symbol exists so ``quest.utils`` imports unchanged, and is served by torch SDPA on the gathered pages.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import PagedKV, check, lib
+
+_NHD, _HND = 0, 1
+
+
+# ---------------------------------------------------------------- validation (CHECK_* macros)
+
+def _check_input(x: torch.Tensor, name: str) -> None:
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _check_dim(d: int, x: torch.Tensor, name: str) -> None:
+    if x.dim() != d:
+        raise RuntimeError(f"{name} must be a {d}D tensor")
+
+
+def _check_eq(a, b, what: str) -> None:
+    if a != b:
+        raise RuntimeError(f"CHECK_EQ({what}) failed. {a} vs {b}")
+
+
+def _check_ge(a, b, what: str) -> None:
+    if not a >= b:
+        raise RuntimeError(f"CHECK_GE({what}) failed. {a} vs {b}")
+
+
+def _check_half(x: torch.Tensor, op: str) -> None:
+    if x.dtype != torch.float16:  # DISPATCH_PYTORCH_DTYPE_TO_CTYPE has only Half
+        raise RuntimeError(f"{op} failed to dispatch with dtype {x.dtype}")
+
+
+def _stream(x: torch.Tensor) -> int:
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+def _pool_dims(data: torch.Tensor, layout: int):
+    """(page_size, num_heads, head_dim) of a 5-D pool layer view."""
+    if layout == _HND:
+        return data.size(3), data.size(2), data.size(4)
+    return data.size(2), data.size(3), data.size(4)
+
+
+def _paged(data, indices, indptr, last_page_len, last_page_idx, layout, page_budget=0) -> PagedKV:
+    page_size, num_heads, head_dim = _pool_dims(data, layout)
+    return PagedKV(
+        data.data_ptr(),
+        indices.data_ptr() if indices is not None else None,
+        indptr.data_ptr() if indptr is not None else None,
+        num_heads, page_size, head_dim, page_budget, int(last_page_len), int(last_page_idx), int(layout), 0)
+
+
+# ---------------------------------------------------------------- free functions
+
+def apply_rope_in_place(q, k, past_kv_len: int, rope_scale: float, rope_theta: float) -> None:
+    """page.cu:212-252.  q ``[N, Hq, D]``, k ``[N, Hkv, D]`` rotated in place."""
+    _check_input(q, "q")
+    _check_input(k, "k")
+    _check_dim(3, q, "q")
+    _check_dim(3, k, "k")
+    _check_eq(q.size(0), k.size(0), "q.size(0), k.size(0)")
+    _check_eq(q.size(2), k.size(2), "q.size(2), k.size(2)")
+    _check_half(q, "apply_rope_in_place")
+    check(lib.quest_apply_rope_in_place(q.data_ptr(), k.data_ptr(), q.size(0), int(past_kv_len), q.size(1),
+                                        k.size(1), q.size(2), float(rope_scale), float(rope_theta), _stream(q)),
+          "apply_rope_in_place")
+
+
+def rms_norm_forward(input, weight, output, epsilon: float) -> None:
+    """rms_norm.cu:183-212.  input/output ``[1, N, C]``, weight ``[C]``."""
+    _check_input(input, "input")
+    _check_input(weight, "weight")
+    _check_input(output, "output")
+    _check_eq(input.dim(), 3, "input.dim(), 3")
+    _check_half(input, "rms_norm_forward")
+    check(lib.quest_rms_norm_forward(input.data_ptr(), weight.data_ptr(), output.data_ptr(),
+                                     input.size(0) * input.size(1), input.size(2), float(epsilon), _stream(input)),
+          "rms_norm")
+
+
+def topk_filtering(estimated_value, estimated_indices, d_out, indices_out, buf, page_budget: int) -> None:
+    """topk.cu:7-46.  Rows = heads; selects ``page_budget`` largest of each row."""
+    _check_input(estimated_value, "estimated_value")
+    _check_input(estimated_indices, "estimated_indices")
+    _check_input(d_out, "d_out")
+    _check_input(indices_out, "indices_out")
+    _check_dim(2, estimated_value, "estimated_value")
+    _check_dim(2, estimated_indices, "estimated_indices")
+    num_heads, num_pages = estimated_value.size(0), estimated_value.size(1)
+    _check_eq(num_pages, estimated_indices.size(1), "num_pages, estimated_indices.size(1)")
+    _check_eq(num_heads, estimated_indices.size(0), "num_heads, estimated_indices.size(0)")
+    _check_ge(num_pages, page_budget, "num_pages, page_budget")
+    _check_eq(estimated_indices.dtype, torch.int32, "estimated_indices.scalar_type(), torch::kInt32")
+    _check_eq(indices_out.dtype, torch.int32, "indices_out.scalar_type(), torch::kInt32")
+    _check_eq(page_budget, d_out.size(1), "page_budget, d_out.size(1)")
+    _check_eq(page_budget, indices_out.size(1), "page_budget, indices_out.size(1)")
+    _check_half(estimated_value, "Top-k filtering")
+    check(lib.quest_topk_filtering(estimated_value.data_ptr(), estimated_indices.data_ptr(), d_out.data_ptr(),
+                                   indices_out.data_ptr(), buf.data_ptr() if buf is not None else None,
+                                   num_heads, num_pages, int(page_budget), _stream(estimated_value)),
+          "Top-k filtering")
+
+
+def estimate_attn_score(q, o, metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len: int,
+                        metadata_last_page_idx: int, layout: int) -> None:
+    """estimate.cu:6-84.  q ``[1, Hq, D]``; o ``[Hq, n_pages-1]`` written in place."""
+    _check_input(q, "q")
+    _check_input(o, "o")
+    _check_input(metadata_data, "metadata_data")
+    _check_input(metadata_indices, "metadata_indices")
+    _check_dim(3, q, "q")
+    _check_dim(2, o, "o")
+    _check_dim(5, metadata_data, "metadata_data")
+    _check_dim(1, metadata_indices, "metadata_indices")
+    _check_eq(q.size(0), 1, "q.size(0), 1")
+    _check_eq(metadata_indices.dtype, torch.int32, "metadata_indices.scalar_type(), torch::kInt32")
+    _check_half(q, "Estimate_attn_score")
+    page_size, num_kv_heads, head_dim = _pool_dims(metadata_data, layout)
+    _check_eq(metadata_data.size(4), q.size(2), "metadata_data.size(4), head_dim")
+    _check_eq(o.size(0), q.size(1), "o.size(0), num_heads")
+    meta = _paged(metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len, metadata_last_page_idx,
+                  layout)
+    check(lib.quest_estimate_attn_score(q.data_ptr(), o.data_ptr(), q.size(1), o.size(1), meta, _stream(q)),
+          "Estimate_attn_score")
+
+
+def _check_append(k, v, kv_data, kv_indices, kv_indptr, metadata_data, metadata_indices, metadata_indptr, layout):
+    for t, n in ((k, "k"), (v, "v"), (kv_data, "kv_data"), (kv_indices, "kv_indices"),
+                 (metadata_data, "metadata_data"), (metadata_indices, "metadata_indices")):
+        _check_input(t, n)
+    _check_dim(1, kv_indices, "kv_indices")
+    _check_dim(1, metadata_indices, "metadata_indices")
+    _check_dim(3, k, "k")
+    _check_dim(3, v, "v")
+    _check_dim(5, kv_data, "kv_data")
+    _check_dim(5, metadata_data, "metadata_data")
+    for t, n in ((kv_indices, "kv_indices"), (metadata_indices, "metadata_indices"), (kv_indptr, "kv_indptr"),
+                 (metadata_indptr, "metadata_indptr")):
+        _check_eq(t.dtype, torch.int32, f"{n}.scalar_type(), torch::kInt32")
+    page_size, num_heads, head_dim = _pool_dims(kv_data, layout)
+    _check_eq(num_heads, k.size(1), "kv_data heads, num_heads")
+    _check_eq(head_dim, k.size(2), "kv_data.size(4), head_dim")
+    _check_eq(v.size(0), k.size(0), "seq_len, v.size(0)")
+
+
+def append_kv_cache_prefill(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_len: int, kv_last_page_idx: int,
+                            metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len: int,
+                            metadata_last_page_idx: int, layout: int) -> None:
+    """page.cu:101-210.  k, v ``[N>=2, H, D]`` appended; per-page min/max metadata rebuilt."""
+    _check_append(k, v, kv_data, kv_indices, kv_indptr, metadata_data, metadata_indices, metadata_indptr, layout)
+    _check_ge(k.size(0), 2, "k.size(0), 2")
+    _check_half(k, "Append_kv_cache_prefill")
+    kv = _paged(kv_data, kv_indices, kv_indptr, kv_last_page_len, kv_last_page_idx, layout)
+    meta = _paged(metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len, metadata_last_page_idx,
+                  layout)
+    check(lib.quest_append_kv_cache_prefill(k.data_ptr(), v.data_ptr(), k.size(0), kv_indices.size(0), kv, meta,
+                                            _stream(k)), "Append_kv_cache_prefill")
+
+
+def append_kv_cache_decode(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_len: int, kv_last_page_idx: int,
+                           metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len: int,
+                           metadata_last_page_idx: int, layout: int) -> None:
+    """page.cu:6-99.  k, v ``[1, H, D]``."""
+    _check_append(k, v, kv_data, kv_indices, kv_indptr, metadata_data, metadata_indices, metadata_indptr, layout)
+    _check_eq(k.size(0), 1, "k.size(0), 1")
+    _check_half(k, "Append_kv_cache_decode")
+    kv = _paged(kv_data, kv_indices, kv_indptr, kv_last_page_len, kv_last_page_idx, layout)
+    meta = _paged(metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len, metadata_last_page_idx,
+                  layout)
+    check(lib.quest_append_kv_cache_decode(k.data_ptr(), v.data_ptr(), kv, meta, _stream(k)),
+          "Append_kv_cache_decode")
+
+
+def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, causal: bool, layout: int,
+                                allow_fp16_qk_reduction: bool, rope_scale: float, rope_theta: float):
+    """batch_prefill.cu:27-117 -- NOT on the sparse-decode path; torch SDPA over the gathered pages."""
+    _check_input(q, "q")
+    _check_input(kv_data, "kv_data")
+    _check_input(kv_indices, "kv_indices")
+    _check_dim(3, q, "q")
+    _check_dim(5, kv_data, "kv_data")
+    page_size, num_kv_heads, head_dim = _pool_dims(kv_data, layout)
+    pages = kv_data.index_select(0, kv_indices.long())  # [n, 2, ...]
+    if layout == _NHD:
+        k = pages[:, 0].reshape(-1, num_kv_heads, head_dim)
+        v = pages[:, 1].reshape(-1, num_kv_heads, head_dim)
+    else:
+        k = pages[:, 0].transpose(1, 2).reshape(-1, num_kv_heads, head_dim)
+        v = pages[:, 1].transpose(1, 2).reshape(-1, num_kv_heads, head_dim)
+    kv_len = (kv_indices.size(0) - 1) * page_size + int(kv_last_page_len)
+    k, v = k[:kv_len], v[:kv_len]
+    n, hq = q.size(0), q.size(1)
+    if hq != num_kv_heads:
+        k = k.repeat_interleave(hq // num_kv_heads, dim=1)
+        v = v.repeat_interleave(hq // num_kv_heads, dim=1)
+    mask = None
+    if causal:
+        mask = torch.ones(n, kv_len, dtype=torch.bool, device=q.device).tril(diagonal=kv_len - n)
+    o = torch.nn.functional.scaled_dot_product_attention(
+        q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), attn_mask=mask, scale=1.0 / math.sqrt(head_dim))
+    return o.transpose(0, 1).contiguous()
+
+
+# ---------------------------------------------------------------- handler class
+
+class BatchDecodeWithPagedKVCachePyTorchWrapper:
+    """bsk_ops.h:84-116 / approx_attn.cu:27-150: begin_forward plans, forward launches."""
+
+    def __init__(self, layout: int):
+        self._layout = int(layout)
+        h = ctypes.c_void_p()
+        check(lib.quest_decode_handler_create(ctypes.byref(h), self._layout), "BatchDecodeWithPagedKVCache")
+        self._h = h
+        self._destroy = lib.quest_decode_handler_destroy  # keep alive for __del__ at interpreter exit
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._destroy(h)
+
+    def begin_forward(self, indptr, num_qo_heads: int, num_kv_heads: int, head_dim: int, page_size: int,
+                      empty_data) -> None:
+        _check_dim(1, indptr, "indptr")
+        _check_eq(indptr.dtype, torch.int32, "indptr.scalar_type(), torch::kInt32")
+        if empty_data.dtype != torch.float16:
+            raise RuntimeError(f"BatchDecodeWithPagedKVCache failed to dispatch with dtype {empty_data.dtype}")
+        # the planner needs the selected-page count on the host; the reference copies indptr back
+        # too (decode_attn.cuh:866-873).  A CPU indptr skips the device sync.
+        host = indptr if not indptr.is_cuda else indptr.cpu()
+        n_sel = int(host[-1]) - int(host[0])
+        stream = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        check(lib.quest_decode_begin_forward(self._h, n_sel, int(num_qo_heads), int(num_kv_heads), int(head_dim),
+                                             int(page_size), stream), "BatchDecodeWithPagedKVCache")
+
+    def end_forward(self) -> None:
+        check(lib.quest_decode_end_forward(self._h), "BatchDecodeWithPagedKVCache")
+
+    def forward(self, q, o, paged_kv_data, paged_kv_indices, paged_kv_indptr, paged_kv_last_page_len: int,
+                paged_kv_last_page_idx: int, rope_scale: float, rope_theta: float) -> None:
+        _check_input(q, "q")
+        _check_input(o, "o")
+        _check_input(paged_kv_data, "paged_kv_data")
+        _check_input(paged_kv_indices, "paged_kv_indices")
+        _check_dim(3, q, "q")
+        _check_dim(2, paged_kv_indices, "paged_kv_indices")
+        _check_dim(5, paged_kv_data, "paged_kv_data")
+        _check_eq(paged_kv_indices.size(0), q.size(1), "paged_kv_indices.size(0), num_qo_heads")
+        _check_eq(paged_kv_data.size(1), 2, "paged_kv_data.size(1), 2")
+        _check_eq(paged_kv_data.size(4), q.size(2), "paged_kv_data.size(4), head_dim")
+        _check_eq(paged_kv_indices.dtype, torch.int32, "paged_kv_indices.scalar_type(), torch::kInt32")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, paged_kv_indices, paged_kv_indptr, paged_kv_last_page_len,
+                    paged_kv_last_page_idx, self._layout, page_budget=paged_kv_indices.size(1))
+        check(lib.quest_decode_forward(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), None, _stream(q)),
+              "BatchDecodeWithPagedKVCache")
+
+    # introspection used by the bench / tuning sweeps (not part of the reference surface)
+    def plan_info(self):
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        check(lib.quest_decode_plan_info(self._h, ctypes.byref(a), ctypes.byref(b)), "plan_info")
+        return a.value, b.value
+
+    def set_pages_per_chunk(self, ppc: int) -> None:
+        check(lib.quest_decode_set_pages_per_chunk(self._h, int(ppc)), "set_pages_per_chunk")

@@ -1,0 +1,79 @@
+"""ctypes loader for libquest_hip.so (the C ABI declared in include/quest_hip.h).
+
+There is no fallback: if the library is missing or fails to load, importing raises.  Build it
+with ``python -m quest_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libquest_hip.so")
+
+c_u32, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
+
+
+class PagedKV(ctypes.Structure):
+    """quest_paged_kv_t (include/quest_hip.h)."""
+
+    _fields_ = [
+        ("data", c_vp),
+        ("indices", c_vp),
+        ("indptr", c_vp),
+        ("num_heads", c_u32),
+        ("page_size", c_u32),
+        ("head_dim", c_u32),
+        ("page_budget", c_u32),
+        ("last_page_len", c_u32),
+        ("last_page_idx", c_i32),
+        ("layout", c_u32),
+        ("reserved", c_u32),
+    ]
+
+
+# name -> (restype, argtypes); must list every function include/quest_hip.h declares
+SIGNATURES = {
+    "quest_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "quest_build_info": (ctypes.c_char_p, []),
+    "quest_append_kv_cache_decode": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp]),
+    "quest_append_kv_cache_prefill": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, PagedKV, c_vp]),
+    "quest_estimate_attn_score": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp]),
+    "quest_topk_filtering": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
+    "quest_decode_handler_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_u32]),
+    "quest_decode_handler_destroy": (None, [c_vp]),
+    "quest_decode_begin_forward": (ctypes.c_int, [c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp]),
+    "quest_decode_end_forward": (ctypes.c_int, [c_vp]),
+    "quest_decode_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp]),
+    "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
+    "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),
+    "quest_apply_rope_in_place": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp]),
+    "quest_rms_norm_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp]),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m quest_amd.build` "
+            "(there is no CPU fallback for the quest_amd operators).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str) -> None:
+    """Translate a C-ABI status into the exception type the reference's ops raise
+    (TORCH_CHECK -> RuntimeError; std::invalid_argument -> ValueError)."""
+    if code == 0:
+        return
+    msg = lib.quest_error_string(code).decode()
+    if code == -1:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what} failed with error code {code}: {msg}")

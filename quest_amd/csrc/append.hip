@@ -1,0 +1,196 @@
+// KV append with fused per-page Key min/max metadata maintenance.
+//
+// Reference behaviour restated (not translated):
+//   decode : AppendPagedKVCacheDecodeKernel   kernels/include/decode/decode_page.cuh:398-449
+//   prefill: AppendPagedKVCachePrefillKernel  kernels/include/decode/decode_page.cuh:471-562
+// The metadata pool has the same paged struct as the KV pool; its "entries" are KV pages, the
+// K slot holds the element-wise max of the page's keys and the V slot the min (:443-446).
+//
+// gfx950 mapping: one row of D/8 lanes owns one (page, head) vector, 16 B per lane, so a wave
+// moves 4 heads x 256 B = 1 KiB contiguous (NHD) per instruction.  Bound: HBM (pure copy + RMW).
+#include "quest_common.cuh"
+
+namespace quest {
+
+// fp16 max/min on bit patterns: NaN-suppressing, -0 < +0 -- the exact rule the oracle states
+// (oracle/quest_oracle.c qo_hmax/qo_hmin) so metadata is bit-identical.
+__device__ __forceinline__ uint16_t hmax_bits(uint16_t a, uint16_t b) {
+    const bool an = (a & 0x7fffu) > 0x7c00u, bn = (b & 0x7fffu) > 0x7c00u;
+    uint16_t r = half_key(a) >= half_key(b) ? a : b;
+    if (an) r = bn ? (uint16_t)0x7fffu : b;
+    else if (bn) r = a;
+    return r;
+}
+__device__ __forceinline__ uint16_t hmin_bits(uint16_t a, uint16_t b) {
+    const bool an = (a & 0x7fffu) > 0x7c00u, bn = (b & 0x7fffu) > 0x7c00u;
+    uint16_t r = half_key(a) <= half_key(b) ? a : b;
+    if (an) r = bn ? (uint16_t)0x7fffu : b;
+    else if (bn) r = a;
+    return r;
+}
+
+typedef uint16_t ushort8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ ushort8 fold_max(ushort8 m, ushort8 k) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = hmax_bits(m[i], k[i]);
+    return m;
+}
+__device__ __forceinline__ ushort8 fold_min(ushort8 m, ushort8 k) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = hmin_bits(m[i], k[i]);
+    return m;
+}
+
+constexpr uint16_t kHalfMax = 0x7bffu;     // +65504 (CUDART_MAX_NORMAL_FP16, decode_page.cuh:430-431)
+constexpr uint16_t kHalfNegMax = 0xfbffu;  // -65504
+
+__global__ __launch_bounds__(256) void append_decode_kernel(quest_paged_kv_t kv, quest_paged_kv_t meta,
+                                                            const uint16_t* __restrict__ key,
+                                                            const uint16_t* __restrict__ value) {
+    const uint32_t D = kv.head_dim, H = kv.num_heads, S = kv.page_size;
+    const uint32_t lpr = D / kVec;  // lanes per row
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= H * lpr) return;
+    const uint32_t h = tid / lpr, f = (tid % lpr) * kVec;
+
+    const PoolStrides ks = pool_strides(kv), ms = pool_strides(meta);
+    const int32_t kv_begin = kv.indptr[0], kv_end = kv.indptr[1];
+    const uint32_t seq_len = (uint32_t)(kv_end - kv_begin - 1) * S + kv.last_page_len;
+    const uint32_t page_iter = kv_begin + (seq_len - 1) / S;
+    const uint32_t entry = (seq_len - 1) % S;
+    const size_t page = (size_t)kv.indices[page_iter];
+    const size_t mpage = (size_t)meta.indices[meta.indptr[1] - 1];
+    const uint32_t mentry = meta.last_page_len - 1;
+
+    uint16_t* kv_data = reinterpret_cast<uint16_t*>(kv.data);
+    uint16_t* m_data = reinterpret_cast<uint16_t*>(meta.data);
+    uint16_t* kdst = kv_data + page * ks.page + (size_t)h * ks.head + (size_t)entry * ks.entry + f;
+    uint16_t* mmax = m_data + mpage * ms.page + (size_t)h * ms.head + (size_t)mentry * ms.entry + f;
+    uint16_t* mmin = mmax + ms.v_off;
+
+    const ushort8 k8 = *reinterpret_cast<const ushort8*>(key + (size_t)h * D + f);
+    const ushort8 v8 = *reinterpret_cast<const ushort8*>(value + (size_t)h * D + f);
+    ushort8 mx, mn;
+    if (entry > 0) {
+        mx = *reinterpret_cast<const ushort8*>(mmax);
+        mn = *reinterpret_cast<const ushort8*>(mmin);
+    } else {  // the token opens a new page: start from the sentinels, not from stale pool bytes
+        mx = (ushort8)(kHalfNegMax);
+        mn = (ushort8)(kHalfMax);
+    }
+    mx = fold_max(mx, k8);
+    mn = fold_min(mn, k8);
+    *reinterpret_cast<ushort8*>(kdst) = k8;
+    *reinterpret_cast<ushort8*>(kdst + ks.v_off) = v8;
+    *reinterpret_cast<ushort8*>(mmax) = mx;
+    *reinterpret_cast<ushort8*>(mmin) = mn;
+}
+
+// One row of lanes per (page, head); rows of a wave are consecutive heads of one page so source
+// and (NHD) destination accesses are 1 KiB contiguous per wave instruction.
+__global__ __launch_bounds__(256) void append_prefill_kernel(quest_paged_kv_t kv, quest_paged_kv_t meta,
+                                                             const uint16_t* __restrict__ key,
+                                                             const uint16_t* __restrict__ value,
+                                                             uint32_t append_len) {
+    const uint32_t D = kv.head_dim, H = kv.num_heads, S = kv.page_size, MS = meta.page_size;
+    const uint32_t lpr = D / kVec;
+    const uint32_t rows_per_block = blockDim.x / lpr;
+    const uint32_t row = blockIdx.x * rows_per_block + threadIdx.x / lpr;
+    const uint32_t f = (threadIdx.x % lpr) * kVec;
+
+    const int32_t kv_begin = kv.indptr[0];
+    const int32_t page_nums = kv.indptr[1] - kv_begin;
+    const int32_t seq_len = (page_nums - 1) * (int32_t)S + (int32_t)kv.last_page_len;
+    const int32_t start_seq = seq_len - (int32_t)append_len;
+    const int32_t first_page = start_seq / (int32_t)S;
+    const int32_t po = first_page + (int32_t)(row / H);
+    const uint32_t h = row % H;
+    if (po >= page_nums) return;
+
+    const PoolStrides ks = pool_strides(kv), ms = pool_strides(meta);
+    const size_t page = (size_t)kv.indices[kv_begin + po];
+    const size_t mpage = (size_t)meta.indices[meta.indptr[0] + po / (int32_t)MS];
+    const uint32_t mentry = (uint32_t)po % MS;
+    int32_t e0 = start_seq - po * (int32_t)S;
+    if (e0 < 0) e0 = 0;
+    int32_t e1 = seq_len - po * (int32_t)S;
+    if (e1 > (int32_t)S) e1 = (int32_t)S;
+
+    uint16_t* kv_data = reinterpret_cast<uint16_t*>(kv.data);
+    uint16_t* m_data = reinterpret_cast<uint16_t*>(meta.data);
+    uint16_t* kdst = kv_data + page * ks.page + (size_t)h * ks.head + f;
+    uint16_t* mmax = m_data + mpage * ms.page + (size_t)h * ms.head + (size_t)mentry * ms.entry + f;
+    uint16_t* mmin = mmax + ms.v_off;
+
+    ushort8 mx, mn;
+    if (e0 > 0) {
+        mx = *reinterpret_cast<const ushort8*>(mmax);
+        mn = *reinterpret_cast<const ushort8*>(mmin);
+    } else {
+        mx = (ushort8)(kHalfNegMax);
+        mn = (ushort8)(kHalfMax);
+    }
+    const size_t src0 = ((size_t)(po * (int32_t)S - start_seq) * H + h) * D + f;
+#pragma unroll 4
+    for (int32_t e = e0; e < e1; ++e) {
+        const size_t src = src0 + (size_t)e * H * D;
+        const ushort8 k8 = *reinterpret_cast<const ushort8*>(key + src);
+        const ushort8 v8 = *reinterpret_cast<const ushort8*>(value + src);
+        mx = fold_max(mx, k8);
+        mn = fold_min(mn, k8);
+        *reinterpret_cast<ushort8*>(kdst + (size_t)e * ks.entry) = k8;
+        *reinterpret_cast<ushort8*>(kdst + (size_t)e * ks.entry + ks.v_off) = v8;
+    }
+    *reinterpret_cast<ushort8*>(mmax) = mx;
+    *reinterpret_cast<ushort8*>(mmin) = mn;
+}
+
+static int check_pool(const quest_paged_kv_t& p) {
+    if (!p.data || !p.indices || !p.indptr) return QUEST_EINVAL;
+    if (p.layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
+    if (p.num_heads == 0 || p.page_size == 0) return QUEST_EINVAL;
+    if (p.head_dim != 64 && p.head_dim != 128 && p.head_dim != 256) return QUEST_EUNSUPPORTED;
+    if (p.last_page_len == 0 || p.last_page_len > p.page_size) return QUEST_EINVAL;
+    return 0;
+}
+
+}  // namespace quest
+
+using namespace quest;
+
+extern "C" int quest_append_kv_cache_decode(const void* k, const void* v, quest_paged_kv_t kv,
+                                            quest_paged_kv_t metadata, quest_stream_t stream) {
+    if (!k || !v) return QUEST_EINVAL;
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
+    const uint32_t threads = kv.num_heads * (kv.head_dim / kVec);
+    const uint32_t block = 256, grid = (threads + block - 1) / block;
+    hipLaunchKernelGGL(append_decode_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, kv, metadata,
+                       (const uint16_t*)k, (const uint16_t*)v);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int quest_append_kv_cache_prefill(const void* k, const void* v, uint32_t append_len,
+                                             uint32_t n_pages_host, quest_paged_kv_t kv,
+                                             quest_paged_kv_t metadata, quest_stream_t stream) {
+    if (!k || !v || append_len == 0 || n_pages_host == 0) return QUEST_EINVAL;
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
+    // pages touched: from the page holding the first appended token to the last page
+    const uint64_t seq_len = (uint64_t)(n_pages_host - 1) * kv.page_size + kv.last_page_len;
+    if (append_len > seq_len) return QUEST_EINVAL;
+    const uint64_t first_page = (seq_len - append_len) / kv.page_size;
+    const uint64_t pages = n_pages_host - first_page;
+    const uint32_t block = 256;
+    const uint32_t rows_per_block = block / (kv.head_dim / kVec);
+    const uint64_t rows = pages * kv.num_heads;
+    const uint32_t grid = (uint32_t)((rows + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(append_prefill_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, kv, metadata,
+                       (const uint16_t*)k, (const uint16_t*)v, append_len);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,99 @@
+"""Operator wrappers with the reference's names and argument meaning (quest/utils/__init__.py:11-276).
+
+Each wrapper turns ``InferenceController`` state into the argument list of one ``_kernels`` op.
+All tensors are NHD/HND per ``iController.layout``; q/k/v projections are ``[tokens, heads, dim]``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _kernels
+from .controller import InferenceController
+from .decode_wrapper import BatchDecodeWithPagedKVCacheWrapper
+from .kv_cache import KvCache
+from .utils import TensorLayout
+
+__all__ = [
+    "TensorLayout",
+    "KvCache",
+    "InferenceController",
+    "BatchDecodeWithPagedKVCacheWrapper",
+    "append_kv",
+    "prefill_forward",
+    "decode_estimate",
+    "decode_topk",
+    "decode_sparse_attn",
+    "rms_norm_forward",
+    "apply_rope_in_place",
+]
+
+
+def _rope_defaults(rope_scale, rope_theta):
+    return (1.0 if rope_scale is None else rope_scale), (1e4 if rope_theta is None else rope_theta)
+
+
+def apply_rope_in_place(q: torch.Tensor, k: torch.Tensor, past_kv_len: int, rope_scale: Optional[float] = None,
+                        rope_theta: Optional[float] = None) -> None:
+    """Rotate q ``[N, Hq, D]`` and k ``[N, Hkv, D]`` in place; row i sits at position ``past_kv_len + i``."""
+    scale, theta = _rope_defaults(rope_scale, rope_theta)
+    _kernels.apply_rope_in_place(q, k, past_kv_len, scale, theta)
+
+
+def rms_norm_forward(input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> torch.Tensor:
+    out = torch.empty_like(input)
+    _kernels.rms_norm_forward(input, weight, out, epsilon)
+    return out
+
+
+def _append_args(ctl: InferenceController, layer_idx: int):
+    kv, meta = ctl.kv_cache, ctl.metadata_cache
+    return (kv.buf_layer(layer_idx), ctl.kv_indices_with_last, ctl.kv_indptr_for_append, kv.last_page_len,
+            ctl.kv_last_page_idx, meta.buf_layer(layer_idx), ctl.metadata_indices, ctl.metadata_indptr_for_append,
+            meta.last_page_len, ctl.metadata_last_page_idx, ctl.layout)
+
+
+def append_kv(k: torch.Tensor, v: torch.Tensor, iController: InferenceController, layer_idx: int) -> None:
+    """Write new keys/values ``[N, Hkv, D]`` into the paged cache of ``layer_idx`` and fold the keys into
+    the per-page (max, min) metadata.  N > 1 takes the prefill kernel, N == 1 the decode kernel."""
+    op = _kernels.append_kv_cache_prefill if k.size(0) > 1 else _kernels.append_kv_cache_decode
+    op(k, v, *_append_args(iController, layer_idx))
+
+
+def prefill_forward(q: torch.Tensor, iController: InferenceController, layer_idx: int,
+                    rope_scale: Optional[float] = None, rope_theta: Optional[float] = None) -> torch.Tensor:
+    """Causal attention of q ``[N, Hq, D]`` over the (already appended) cache.  Not on the sparse path."""
+    scale, theta = _rope_defaults(rope_scale, rope_theta)
+    return _kernels.prefill_with_paged_kv_cache(
+        q, iController.kv_cache.buf_layer(layer_idx), iController.kv_indices_with_last,
+        iController.kv_cache.last_page_len, True, iController.layout, False, scale, theta)
+
+
+def decode_estimate(q: torch.Tensor, iController: InferenceController, layer_idx: int) -> torch.Tensor:
+    """Upper-bound criticality score of every page but the current one: ``[Hq, n_pages - 1]`` fp16."""
+    meta = iController.metadata_cache
+    # metadata seqlen == number of KV pages; the last entry belongs to the current page
+    o = torch.empty((iController.num_heads, meta.seqlen - 1), dtype=q.dtype, device=q.device)
+    _kernels.estimate_attn_score(q, o, meta.buf_layer(layer_idx), iController.metadata_indices,
+                                 iController.metadata_indptr_for_append, meta.last_page_len,
+                                 iController.metadata_last_page_idx, iController.layout)
+    return o
+
+
+def decode_topk(estimated_attn_score: torch.Tensor, iController: InferenceController) -> None:
+    """Pick the ``budget - 1`` best pages per head into ``iController.topk_dindices_buffer``."""
+    _kernels.topk_filtering(estimated_attn_score, iController.kv_indices_without_last, iController.topk_dout_buffer,
+                            iController.topk_dindices_buffer, iController.topk_buf,
+                            iController.inference_page_budget - 1)
+
+
+def decode_sparse_attn(q: torch.Tensor, iController: InferenceController, layer_idx: int, topk_indices: torch.Tensor,
+                       rope_scale: Optional[float] = None, rope_theta: Optional[float] = None) -> torch.Tensor:
+    """Attention of q ``[1, Hq, D]`` over the pages in ``topk_indices`` ``[Hq, budget - 1]`` plus the
+    current page."""
+    o = torch.empty_like(q)
+    iController._decode_handler.forward(q, o, iController.kv_cache.buf_layer(layer_idx), topk_indices,
+                                        iController.kv_indptr_for_approx_decode, iController.kv_cache.last_page_len,
+                                        iController.kv_last_page_idx, rope_scale, rope_theta)
+    return o

@@ -1,0 +1,141 @@
+"""Per-sequence decode state: page tables, budgets, top-k buffers, handler lifecycle.
+
+Mirrors the reference's ``InferenceController`` (quest/utils/controller.py:7-146) attribute for
+attribute, because ``quest.utils``' wrappers and ``QuestAttention`` read these fields directly.
+Behavioural contract kept: ``prepare_metadata`` -> ``begin_forward`` -> ops -> ``end_forward``;
+``page_budget`` is in PAGES and includes the current page (controller.py:14); the first call of a
+decode step may pass ``updateTensor=False`` to re-plan with another budget without touching the
+index tensors (llama.py:434-439 layer-skip).
+
+What differs is cost, not meaning: index tensors are views/expansions of a device-resident page
+table (no Python-list -> tensor rebuild per token), small indptr tensors are cached by value, and
+top-k output buffers are reused while the budget is unchanged.  Extension: ``num_kv_heads`` for
+GQA pools (per-query-head selection).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .decode_wrapper import BatchDecodeWithPagedKVCacheWrapper
+from .kv_cache import KvCache
+from .utils import TensorLayout
+
+
+class InferenceController:
+    def __init__(self, num_layers, num_heads, head_dim, page_size,
+                 page_budget,  # pages, including the last (current) page
+                 max_seq_len,  # capacity of the KV / metadata pools, in tokens
+                 dtype, device, num_kv_heads: Optional[int] = None, layout: int = TensorLayout.NHD,
+                 shuffle_seed: Optional[int] = None):
+        self.num_heads = num_heads
+        self.num_kv_heads = num_heads if num_kv_heads is None else num_kv_heads
+        if self.num_heads % self.num_kv_heads != 0:
+            raise ValueError(f"num_heads {num_heads} is not a multiple of num_kv_heads {num_kv_heads}")
+        self.head_dim = head_dim
+        self.page_size = page_size
+        self.layout = TensorLayout.parse(layout)
+        self.device = device
+        self.dtype = dtype
+
+        max_kv_pages = (max_seq_len + page_size - 1) // page_size
+        self.kv_cache = KvCache(num_layers, self.num_kv_heads, head_dim, max_seq_len, page_size, dtype, device,
+                                self.layout, shuffle_seed)
+        # one metadata entry (max in the K slot, min in the V slot) per KV page: controller.py:29-37
+        self.metadata_cache = KvCache(num_layers, self.num_kv_heads, head_dim, max_kv_pages, page_size, dtype, device,
+                                      self.layout, None if shuffle_seed is None else shuffle_seed + 1)
+
+        self._page_budget = page_budget
+        self._decode_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout=TensorLayout.FORMAT2STR[self.layout])
+
+        self.kv_indices_with_last = None
+        self.kv_indices_without_last = None
+        self.metadata_indices = None
+        self.kv_last_page_idx = None
+        self.metadata_last_page_idx = None
+        self.kv_indptr_for_append = None
+        self.metadata_indptr_for_append = None
+        self.kv_indptr_for_approx_decode = None
+        self.inference_page_budget = None
+        self.topk_dout_buffer = None
+        self.topk_dindices_buffer = None
+        self.topk_buf = None
+
+        self._indptr_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._without_last_pages = -1
+
+    # ------------------------------------------------------------------ budgets
+    @property
+    def page_budget_pages(self) -> int:
+        return self._page_budget
+
+    @property
+    def token_budget(self) -> int:
+        return self._page_budget * self.page_size
+
+    def set_page_budget(self, page_budget: int) -> None:
+        self._page_budget = page_budget
+
+    # ------------------------------------------------------------------ step lifecycle
+    def prepare_metadata(self, seq_len: int) -> None:
+        """Reserve pages for ``seq_len`` new tokens and metadata entries for the pages they open."""
+        new_pages = self.kv_cache.append_seq(seq_len)
+        self.metadata_cache.append_seq(new_pages)
+
+    def _indptr(self, n: int) -> torch.Tensor:
+        t = self._indptr_cache.get((0, n))
+        if t is None:
+            if len(self._indptr_cache) > 64:
+                self._indptr_cache.clear()
+            t = torch.tensor([0, n], dtype=torch.int32, device=self.device)
+            self._indptr_cache[(0, n)] = t
+        return t
+
+    def begin_forward(self, seq_len: int, updateTensor: bool = True) -> None:
+        n_pages = len(self.kv_cache.indicies)
+        n_meta = len(self.metadata_cache.indicies)
+        if updateTensor:
+            self.kv_indptr_for_append = self._indptr(n_pages)
+            self.metadata_indptr_for_append = self._indptr(n_meta)
+            self.kv_last_page_idx = self.kv_cache.indicies[-1]
+            self.metadata_last_page_idx = self.metadata_cache.indicies[-1]
+            self.kv_indices_with_last = self.kv_cache.device_table()
+            self.metadata_indices = self.metadata_cache.device_table()
+
+        if seq_len > 1:
+            return  # prefill: append_kv_cache_prefill + prefill_with_paged_kv_cache need nothing else
+
+        assert n_pages > 1, "decode needs at least two pages (the current page is excluded from selection)"
+        if updateTensor and self._without_last_pages != n_pages:
+            # input ids of the top-k ([H, n_pages-1], controller.py:106), rebuilt only when a page was added
+            self.kv_indices_without_last = self.kv_indices_with_last[:-1].unsqueeze(0).expand(
+                self.num_heads, n_pages - 1).contiguous()
+            self._without_last_pages = n_pages
+
+        budget = min(self._page_budget, n_pages)
+        if budget != self.inference_page_budget or self.topk_dout_buffer is None:
+            self.topk_dout_buffer = torch.zeros((self.num_heads, budget - 1), dtype=self.dtype, device=self.device)
+            self.topk_dindices_buffer = torch.zeros((self.num_heads, budget - 1), dtype=torch.int32,
+                                                    device=self.device)
+            if self.topk_buf is None:  # scratch argument of the reference's RAFT call; unused here
+                self.topk_buf = torch.zeros((self.num_heads, 8), dtype=self.dtype, device=self.device)
+        self.inference_page_budget = budget
+        self.kv_indptr_for_approx_decode = self._indptr(budget - 1)
+        # the planner wants the count on the host: hand it a CPU indptr (no device round trip)
+        self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
+                                           self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
+
+    def end_forward(self) -> None:
+        self._decode_handler.end_forward()
+
+    def need_estimate(self) -> bool:
+        if self.inference_page_budget is None:
+            return False
+        return len(self.kv_cache.indicies) > self.inference_page_budget
+
+    def clean_states(self) -> None:
+        self.kv_cache.release()
+        self.metadata_cache.release()
+        self._without_last_pages = -1
+        self.inference_page_budget = None

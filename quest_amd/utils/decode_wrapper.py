@@ -1,0 +1,40 @@
+"""Python face of the decode handler (reference: quest/utils/decode_wrapper.py:11-81)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _kernels
+from .utils import TensorLayout
+
+
+class BatchDecodeWithPagedKVCacheWrapper:
+    """Owns the plan (pages per workgroup, partial-state workspace) that ``begin_forward`` makes
+    once per decode step and every layer's ``forward`` reuses."""
+
+    def __init__(self, kv_layout: str = "NHD"):
+        self.kv_layout = kv_layout
+        self._wrapper = _kernels.BatchDecodeWithPagedKVCachePyTorchWrapper(TensorLayout.parse(kv_layout))
+
+    def begin_forward(self, indptr: torch.Tensor, num_qo_heads: int, num_kv_heads: int, head_dim: int,
+                      page_size: int, data_type) -> None:
+        # dtype travels as an empty tensor, as in the reference's PyBind signature
+        self._wrapper.begin_forward(indptr, num_qo_heads, num_kv_heads, head_dim, page_size,
+                                    torch.empty(0, dtype=data_type))
+
+    def end_forward(self) -> None:
+        self._wrapper.end_forward()
+
+    def forward(self, q: torch.Tensor, o: torch.Tensor, paged_kv_data: torch.Tensor, paged_kv_indices: torch.Tensor,
+                paged_kv_indptr: torch.Tensor, paged_kv_last_page_len: int, paged_kv_last_page_idx: int,
+                rope_scale: Optional[float] = None, rope_theta: Optional[float] = None) -> None:
+        self._wrapper.forward(q, o, paged_kv_data, paged_kv_indices, paged_kv_indptr, paged_kv_last_page_len,
+                              paged_kv_last_page_idx, 1.0 if rope_scale is None else rope_scale,
+                              1e4 if rope_theta is None else rope_theta)
+
+    def plan_info(self):
+        return self._wrapper.plan_info()
+
+    def set_pages_per_chunk(self, ppc: int) -> None:
+        self._wrapper.set_pages_per_chunk(ppc)

@@ -1,0 +1,368 @@
+"""GPU parity: quest_amd (HIP, through the C ABI) vs the CPU oracle and the committed golden
+fixtures.  Run on the MI355X box with ``pytest -m gpu``.
+
+Bars (north_star): metadata, estimate and top-k are integer/bit-pattern work -> bit-exact vs the
+oracle; attention output fp16 within rtol = atol = 5e-3 (the reference's own tolerance,
+quest/tests/test_approx_attention.py:10-15), and we also assert the tighter 2e-3 against the
+double-precision oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import synth
+from _harness import cuda, fill, inputs, make_controller, oracle_pools, pools_match
+
+pytestmark = pytest.mark.gpu
+
+PAGE = 16
+U16 = lambda a: np.ascontiguousarray(a).view(np.uint16)
+
+
+def _qu():
+    import quest_amd.utils as qu
+
+    return qu
+
+
+def _close(a, b, tol=5e-3):
+    torch.testing.assert_close(torch.from_numpy(np.asarray(a, np.float32)), torch.from_numpy(np.asarray(b, np.float32)),
+                               rtol=tol, atol=tol)
+
+
+# ---------------------------------------------------------------------------- append / metadata
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("L,split", [(27, None), (61, 17), (113, 100), (482, None), (1011, 1000), (33, 32), (17, 16)])
+def test_append_bit_exact(layout, L, split):
+    Hq = Hkv = 8
+    q, k, v = inputs(7 + L, L, Hq)
+    ctl = make_controller(L, Hq, Hkv, 128, PAGE, 64, layout=layout, shuffle_seed=L)
+    fill(ctl, k, v, split=split)
+    kv_o, meta_o = oracle_pools(ctl, k, v)
+    assert pools_match(ctl, kv_o, meta_o, L)
+    ctl.end_forward()
+
+
+def test_append_chunked_prefill_bit_exact():
+    """Two prefill appends (second one starts mid-page) == one (decode_page.cuh:487-504 start_entry_idx)."""
+    qu = _qu()
+    L, H = 200, 4
+    q, k, v = inputs(3, L, H)
+    ctl = make_controller(L, H, H, 128, PAGE, 64, shuffle_seed=5)
+    kc, vc = cuda(k), cuda(v)
+    for a, b in [(0, 75), (75, 200)]:
+        ctl.prepare_metadata(b - a)
+        ctl.begin_forward(b - a)
+        qu.append_kv(kc[a:b], vc[a:b], ctl, 0)
+        ctl.end_forward()
+    kv_o, meta_o = oracle_pools(ctl, k, v)
+    assert pools_match(ctl, kv_o, meta_o, L)
+
+
+# ---------------------------------------------------------------------------- estimate
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_estimate_bit_exact_and_golden(golden, layout):
+    qu = _qu()
+    for seed, L, H in golden["est_cases"]:
+        seed, L, H = int(seed), int(L), int(H)
+        q, k, v = inputs(seed, L, H)
+        ctl = make_controller(L, H, H, 128, PAGE, 1024, layout=layout, shuffle_seed=seed)
+        fill(ctl, k, v)
+        got = qu.decode_estimate(cuda(q), ctl, 0).cpu().numpy()
+        ctl.end_forward()
+        kv_o, meta_o = oracle_pools(ctl, k, v)
+        exp = oracle.estimate(q, meta_o)
+        assert got.shape == exp.shape == golden[f"est_{L}"].shape
+        assert np.array_equal(U16(got), U16(exp)), f"estimate not bit-exact at L={L}"
+        _close(got, golden[f"est_{L}"])
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,page", [(32, 8, 128, 16), (8, 2, 64, 16), (8, 8, 256, 16), (8, 4, 128, 8),
+                                            (6, 3, 128, 32), (16, 2, 128, 16)])
+def test_estimate_gqa_dims_pages(Hq, Hkv, D, page):
+    qu = _qu()
+    L = 777
+    q, k, v = inputs(50 + Hq + D, L, Hq, Hkv, D)
+    for layout in (0, 1):
+        ctl = make_controller(L, Hq, Hkv, D, page, 1024, layout=layout, shuffle_seed=1)
+        fill(ctl, k, v)
+        got = qu.decode_estimate(cuda(q), ctl, 0).cpu().numpy()
+        ctl.end_forward()
+        _, meta_o = oracle_pools(ctl, k, v)
+        assert np.array_equal(U16(got), U16(oracle.estimate(q, meta_o)))
+
+
+def test_estimate_is_upper_bound():
+    """Domain property: the page score bounds every token's q.k in that page from above."""
+    qu = _qu()
+    L, H = 2000, 8
+    q, k, v = inputs(99, L, H)
+    ctl = make_controller(L, H, H, 128, PAGE, 1024)
+    fill(ctl, k, v)
+    est = qu.decode_estimate(cuda(q), ctl, 0).float().cpu().numpy()
+    ctl.end_forward()
+    qk = np.einsum("hd,lhd->hl", q[0].astype(np.float64), k.astype(np.float64))
+    n = est.shape[1]
+    per_page = qk[:, : n * PAGE].reshape(H, n, PAGE).max(-1)
+    assert np.all(est + 0.07 * np.maximum(1, np.abs(est) / 64) >= per_page)  # fp16 rounding slack
+
+
+# ---------------------------------------------------------------------------- top-k
+
+def _topk_dev(vals, in_idx, kk):
+    from quest_amd import _kernels
+
+    rows = vals.shape[0]
+    ov = torch.zeros(rows, kk, dtype=torch.float16, device="cuda:0")
+    oi = torch.zeros(rows, kk, dtype=torch.int32, device="cuda:0")
+    buf = torch.zeros(rows, 8, dtype=torch.float16, device="cuda:0")
+    _kernels.topk_filtering(cuda(vals), cuda(in_idx), ov, oi, buf, kk)
+    return ov.cpu().numpy(), oi.cpu().numpy()
+
+
+def test_topk_golden_values_and_oracle_indices(golden):
+    for seed, n, kk, rows in golden["topk_cases"]:
+        n, kk, rows = int(n), int(kk), int(rows)
+        vals = golden[f"topk_in_{n}_{kk}"]
+        in_idx = np.tile(np.arange(n, dtype=np.int32)[::-1].copy(), (rows, 1))
+        ov, oi = _topk_dev(vals, in_idx, kk)
+        ev, ei = oracle.topk(vals, in_idx, kk)
+        assert np.array_equal(oi, ei) and np.array_equal(U16(ov), U16(ev))
+        ref = golden[f"topk_vals_{n}_{kk}"]
+        assert np.array_equal(np.sort(ov.astype(np.float32), axis=1)[:, ::-1], ref.astype(np.float32))
+
+
+@pytest.mark.parametrize("n,kk", [(2047, 127), (8191, 255), (255, 63), (1024, 1024), (1025, 1), (16384, 511),
+                                  (4000, 3999), (64, 64), (1, 1), (3, 2)])
+def test_topk_ties_bit_exact(n, kk):
+    rng = np.random.default_rng(n + kk)
+    rows = 5
+    vals = np.empty((rows, n), np.float16)
+    vals[0] = (rng.integers(-8, 8, n) * 0.25).astype(np.float16)           # massive ties
+    vals[1] = rng.standard_normal(n).astype(np.float16) * 64                 # cfg-like scores
+    vals[2] = 1.0                                                            # all equal
+    vals[3] = np.where(rng.random(n) < 0.5, 0.0, -0.0).astype(np.float16)   # signed zeros
+    vals[4] = rng.standard_normal(n).astype(np.float16)
+    vals[4, rng.integers(0, n, max(1, n // 50))] = np.float16(np.inf)
+    vals[4, rng.integers(0, n, max(1, n // 50))] = np.float16(-np.inf)
+    in_idx = rng.permutation(n).astype(np.int32)[None].repeat(rows, 0)
+    ov, oi = _topk_dev(vals, in_idx, kk)
+    ev, ei = oracle.topk(vals, in_idx, kk)
+    assert np.array_equal(oi, ei)
+    assert np.array_equal(U16(ov), U16(ev))
+
+
+def test_topk_32_heads_cfg3_shape():
+    rng = np.random.default_rng(0)
+    vals = (rng.standard_normal((32, 2047)) * 40).astype(np.float16)
+    in_idx = np.tile(rng.permutation(2048)[:2047].astype(np.int32), (32, 1))
+    ov, oi = _topk_dev(vals, in_idx, 127)
+    ev, ei = oracle.topk(vals, in_idx, 127)
+    assert np.array_equal(oi, ei) and np.array_equal(U16(ov), U16(ev))
+
+
+# ---------------------------------------------------------------------------- sparse attention
+
+def test_sparse_attention_golden_indices(golden):
+    """The reference's decoupled test: feed the ORACLE's top-k pages (test_approx_attention.py:178-196)."""
+    qu = _qu()
+    for seed, L, H, B, has_idx in golden["approx_cases"]:
+        seed, L, H, B = int(seed), int(L), int(H), int(B)
+        q, k, v = inputs(seed, L, H)
+        for layout in (0, 1):
+            ctl = make_controller(L, H, H, 128, PAGE, B, layout=layout, shuffle_seed=seed)
+            fill(ctl, k, v)
+            table = np.array(ctl.kv_cache.indicies, np.int32)
+            if has_idx:
+                assert ctl.need_estimate()
+                phys = table[golden[f"approx_idx_{L}_{B}"]]
+                o = qu.decode_sparse_attn(cuda(q), ctl, 0, cuda(phys))
+            else:
+                assert not ctl.need_estimate()
+                o = qu.decode_sparse_attn(cuda(q), ctl, 0, ctl.kv_indices_without_last)
+                phys = np.tile(table[:-1], (H, 1))
+            ctl.end_forward()
+            _close(o.cpu().numpy(), golden[f"approx_o_{L}_{B}"])
+            kv_o, _ = oracle_pools(ctl, k, v)
+            eo, _ = oracle.sparse_attn(q, kv_o, phys if phys.shape[1] else np.zeros((H, 1), np.int32), phys.shape[1],
+                                       int(table[-1]), kv_o.last_page_len)
+            _close(o.cpu().numpy(), eo, tol=2e-3)
+
+
+def test_dense_decode_golden(golden):
+    qu = _qu()
+    for seed, L, H in golden["dense_cases"]:
+        seed, L, H = int(seed), int(L), int(H)
+        q, k, v = inputs(seed, L, H)
+        ctl = make_controller(L, H, H, 128, PAGE, 1024, shuffle_seed=seed)
+        fill(ctl, k, v)
+        assert not ctl.need_estimate()
+        o = qu.decode_sparse_attn(cuda(q), ctl, 0, ctl.kv_indices_without_last)
+        ctl.end_forward()
+        _close(o.cpu().numpy(), golden[f"dense_o_{L}"])
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,page,B", [(32, 8, 128, 16, 12), (8, 2, 64, 16, 9), (8, 8, 256, 16, 5),
+                                              (8, 4, 128, 8, 17), (6, 3, 128, 32, 4), (4, 4, 128, 3, 40)])
+def test_chain_gqa_dims_pages(Hq, Hkv, D, page, B):
+    """Full chain estimate -> top-k -> sparse attention vs the oracle chain (bit-exact up to the
+    page selection, then 2e-3)."""
+    qu = _qu()
+    L = 613
+    q, k, v = inputs(70 + Hq + D + page, L, Hq, Hkv, D)
+    for layout in (0, 1):
+        ctl = make_controller(L, Hq, Hkv, D, page, B, layout=layout, shuffle_seed=2)
+        fill(ctl, k, v)
+        assert ctl.need_estimate()
+        est = qu.decode_estimate(cuda(q), ctl, 0)
+        qu.decode_topk(est, ctl)
+        o = qu.decode_sparse_attn(cuda(q), ctl, 0, ctl.topk_dindices_buffer)
+        ctl.end_forward()
+        kv_o, meta_o = oracle_pools(ctl, k, v)
+        e_est = oracle.estimate(q, meta_o)
+        assert np.array_equal(U16(est.cpu().numpy()), U16(e_est))
+        table = np.array(ctl.kv_cache.indicies, np.int32)
+        ev, ei = oracle.topk(e_est, np.tile(table[:-1], (Hq, 1)), B - 1)
+        assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
+        assert np.array_equal(U16(ctl.topk_dout_buffer.cpu().numpy()), U16(ev))
+        eo, _ = oracle.sparse_attn(q, kv_o, ei, B - 1, int(table[-1]), kv_o.last_page_len)
+        _close(o.cpu().numpy(), eo, tol=2e-3)
+
+
+def test_sparse_attention_spiked_softmax():
+    """Force the online-softmax rescale branch: one key row aligned with q dominates late in a chunk."""
+    qu = _qu()
+    L, H = 1000, 4
+    q, k, v = inputs(123, L, H)
+    k = k.copy()
+    for h in range(H):
+        k[777, h] = (q[0, h].astype(np.float32) * 3).astype(np.float16)
+        k[13, h] = (q[0, h].astype(np.float32) * 2).astype(np.float16)
+    ctl = make_controller(L, H, H, 128, PAGE, 1024)
+    fill(ctl, k, v)
+    o = qu.decode_sparse_attn(cuda(q), ctl, 0, ctl.kv_indices_without_last)
+    ctl.end_forward()
+    kv_o, _ = oracle_pools(ctl, k, v)
+    table = np.array(ctl.kv_cache.indicies, np.int32)
+    eo, _ = oracle.sparse_attn(q, kv_o, np.tile(table[:-1], (H, 1)), len(table) - 1, int(table[-1]), kv_o.last_page_len)
+    _close(o.cpu().numpy(), eo, tol=2e-3)
+
+
+@pytest.mark.parametrize("ppc", [1, 2, 3, 5, 8, 64, 1000])
+def test_sparse_attention_any_split(ppc):
+    """The result must not depend on how the planner cuts the page list into workgroups."""
+    qu = _qu()
+    L, H, B = 1541, 8, 55
+    q, k, v = inputs(31, L, H)
+    ctl = make_controller(L, H, H, 128, PAGE, B, shuffle_seed=4)
+    ctl._decode_handler.set_pages_per_chunk(ppc)
+    fill(ctl, k, v)
+    est = qu.decode_estimate(cuda(q), ctl, 0)
+    qu.decode_topk(est, ctl)
+    o = qu.decode_sparse_attn(cuda(q), ctl, 0, ctl.topk_dindices_buffer)
+    assert ctl._decode_handler.plan_info()[0] == ppc
+    ctl.end_forward()
+    kv_o, _ = oracle_pools(ctl, k, v)
+    table = np.array(ctl.kv_cache.indicies, np.int32)
+    eo, _ = oracle.sparse_attn(q, kv_o, ctl.topk_dindices_buffer.cpu().numpy(), B - 1, int(table[-1]),
+                               kv_o.last_page_len)
+    _close(o.cpu().numpy(), eo, tol=2e-3)
+
+
+# ---------------------------------------------------------------------------- rope / rmsnorm
+
+@pytest.mark.parametrize("past,n,Hq,Hkv,D", [(13, 2, 4, 4, 128), (502, 69, 8, 2, 128), (32767, 1, 32, 32, 128),
+                                             (77, 5, 4, 4, 64), (1110, 3, 2, 2, 256)])
+def test_rope_vs_oracle(past, n, Hq, Hkv, D):
+    qu = _qu()
+    q = synth.normal_f16(past, (n, Hq, D))
+    k = synth.normal_f16(past + 1, (n, Hkv, D))
+    qd, kd = cuda(q), cuda(k)
+    qu.apply_rope_in_place(qd, kd, past)
+    qe, ke = q.copy(), k.copy()
+    oracle.rope_in_place(qe, past)
+    oracle.rope_in_place(ke, past)
+    _close(qd.cpu().numpy(), qe, tol=3e-3)
+    _close(kd.cpu().numpy(), ke, tol=3e-3)
+    # linear scaling (LongChat, QuestAttention.py:44-48)
+    qd2 = cuda(q)
+    kd2 = cuda(k)
+    qu.apply_rope_in_place(qd2, kd2, past, rope_scale=8.0)
+    qe2 = q.copy()
+    oracle.rope_in_place(qe2, past, 8.0)
+    _close(qd2.cpu().numpy(), qe2, tol=3e-3)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 4096), (7, 4096), (3, 256), (2, 11008)])
+def test_rms_norm_vs_oracle(rows, cols):
+    qu = _qu()
+    x = synth.normal_f16(cols, (1, rows, cols))
+    w = synth.normal_f16(cols + 1, (cols,))
+    got = qu.rms_norm_forward(cuda(x), cuda(w), 1e-5).cpu().numpy()
+    _close(got, oracle.rms_norm(x, w, 1e-5), tol=2e-3)
+
+
+# ---------------------------------------------------------------------------- full-size properties (cfg 3)
+
+def test_cfg3_full_size_properties():
+    """L=32768, budget 128 pages, H=32, D=128 (BASELINE cfg 3): size-independent properties."""
+    qu = _qu()
+    L, H, B = 32768, 32, 128
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    dev = torch.device("cuda:0")
+    k = torch.randn(L, H, 128, generator=g, device=dev, dtype=torch.float16)
+    v = torch.randn(L, H, 128, generator=g, device=dev, dtype=torch.float16)
+    q = torch.randn(1, H, 128, generator=g, device=dev, dtype=torch.float16)
+    ctl = make_controller(L, H, H, 128, PAGE, B, shuffle_seed=9, max_seq_len=L)
+    ctl.prepare_metadata(L - 1)
+    ctl.begin_forward(L - 1)
+    qu.append_kv(k[:-1], v[:-1], ctl, 0)
+    ctl.end_forward()
+    ctl.prepare_metadata(1)
+    ctl.begin_forward(1)
+    qu.append_kv(k[-1:], v[-1:], ctl, 0)
+    n_pages = L // PAGE
+    # (1) metadata == per-page extrema computed by torch on the device (exact: max/min of fp16)
+    table = ctl.kv_indices_with_last.long()
+    kp = k.view(n_pages, PAGE, H, 128)
+    meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]  # [n_meta, 2, S, H, D]
+    assert torch.equal(meta[:, 0].reshape(-1, H, 128)[:n_pages], kp.amax(1))
+    assert torch.equal(meta[:, 1].reshape(-1, H, 128)[:n_pages], kp.amin(1))
+    # (2) estimate is an upper bound of the true per-page max logit and close to the fp32 formula
+    est = qu.decode_estimate(q, ctl, 0)
+    ref = torch.maximum(q[0][None].float() * kp.amax(1).float(), q[0][None].float() * kp.amin(1).float()).sum(-1).t()
+    torch.testing.assert_close(est.float(), ref[:, :-1].contiguous(), rtol=5e-3, atol=5e-3)
+    # (3) top-k: ascending columns, threshold property, matches a stable sort of the same fp16 scores
+    qu.decode_topk(est, ctl)
+    idx = ctl.topk_dindices_buffer
+    order = torch.sort(est.float(), dim=1, descending=True, stable=True).indices[:, : B - 1]
+    exp_cols = torch.sort(order, dim=1).values
+    assert torch.equal(idx.long(), table[:-1][exp_cols])
+    assert torch.equal(ctl.topk_dout_buffer, torch.gather(est, 1, exp_cols))
+    # (4) sparse attention == torch fp32 attention over exactly the selected tokens
+    o = qu.decode_sparse_attn(q, ctl, 0, idx)
+    pages = torch.cat([exp_cols, torch.full((H, 1), n_pages - 1, device=dev)], 1)  # logical
+    tok = (pages[:, :, None] * PAGE + torch.arange(PAGE, device=dev)).reshape(H, -1)
+    kh = k.transpose(0, 1).float()
+    vh = v.transpose(0, 1).float()
+    ks = torch.gather(kh, 1, tok[:, :, None].expand(-1, -1, 128))
+    vs = torch.gather(vh, 1, tok[:, :, None].expand(-1, -1, 128))
+    p = torch.softmax((ks @ q[0].float()[:, :, None]).squeeze(-1) / 128 ** 0.5, dim=-1)
+    o_ref = (p[:, None] @ vs).squeeze(1)
+    torch.testing.assert_close(o[0].float(), o_ref, rtol=5e-3, atol=5e-3)
+    # (5) order invariance: permuting the selected pages changes nothing beyond fp32 rounding
+    perm = torch.randperm(B - 1, device=dev)
+    o2 = qu.decode_sparse_attn(q, ctl, 0, idx[:, perm].contiguous())
+    torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
+    ctl.end_forward()
+    # (6) dense path (budget >= pages) == torch fp32 full attention
+    ctl.set_page_budget(1 << 20)
+    ctl.begin_forward(1, updateTensor=False)
+    assert not ctl.need_estimate()
+    od = qu.decode_sparse_attn(q, ctl, 0, ctl.kv_indices_without_last)
+    pd = torch.softmax((kh @ q[0].float()[:, :, None]).squeeze(-1) / 128 ** 0.5, dim=-1)
+    torch.testing.assert_close(od[0].float(), (pd[:, None] @ vh).squeeze(1), rtol=5e-3, atol=5e-3)
+    ctl.end_forward()
