@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Headline bench: Quest self-attention decode (append -> estimate -> top-k -> sparse attention)
+at BASELINE.json's metric point -- Yarn-Llama-2-7B shapes (32 layers, 32 heads, D=128, fp16),
+seqlen 32768, token budget 2048 = 128 pages of 16 -- on N GPUs of one node.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+A "step" is one decode token of one sequence per GPU: the four-operator chain run for every
+layer of the model against that layer's own KV / metadata pools (so consecutive kernels touch
+different memory and the 256 MiB Infinity Cache cannot hold the working set).  Everything goes
+through the C ABI of libquest_hip.so; tokens/s is attention-only (no weights offline).
+Sequences are independent, so GPUs never exchange data inside a step; with N > 1 each step ends
+with one RCCL all_gather of the sampled token ids (weak scaling: one sequence per GPU).
+
+One JSON line on stdout (rank 0).  Extra objects: "roofline" (dominant kernel: sparse paged decode
+attention, algorithmic bytes / HIP-event launch time) and "cpu_baseline" (oracle/torch_ref eager
+port timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=32)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--seqlen", type=int, default=32768)
+    ap.add_argument("--token-budget", type=int, default=2048)
+    ap.add_argument("--page-size", type=int, default=16)
+    ap.add_argument("--layout", choices=["NHD", "HND"], default="NHD")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: the whole step captured in one hipGraph and replayed; eager: Python op by op")
+    ap.add_argument("--skip-layers", type=int, default=0,
+                    help="run the first n layers with full KV like quest/models/llama.py:428-439 (default 0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--cpu-sample-s", type=float, default=12.0)
+    return ap.parse_args()
+
+
+class Workload:
+    """One sequence: controller + filled pools + per-layer decode inputs."""
+
+    def __init__(self, a, dev):
+        import quest_amd.utils as qu
+
+        self.qu = qu
+        self.a = a
+        self.dev = dev
+        self.page_budget = a.token_budget // a.page_size
+        L = a.seqlen
+        self.ctl = qu.InferenceController(a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
+                                          L + 2 * a.page_size, torch.float16, dev, num_kv_heads=a.kv_heads,
+                                          layout=a.layout, shuffle_seed=1234)
+        g = torch.Generator(device=dev).manual_seed(1000 + dev.index)
+        ctl = self.ctl
+        # prefill L-1 tokens (device-side append with fused min/max metadata), then one decode token
+        ctl.prepare_metadata(L - 1)
+        ctl.begin_forward(L - 1)
+        kbuf = torch.empty(L - 1, a.kv_heads, a.head_dim, dtype=torch.float16, device=dev)
+        vbuf = torch.empty_like(kbuf)
+        for layer in range(a.layers):
+            kbuf.normal_(generator=g)
+            vbuf.normal_(generator=g)
+            qu.append_kv(kbuf, vbuf, ctl, layer)
+        ctl.end_forward()
+        del kbuf, vbuf
+        self.q = torch.randn(a.layers, 1, a.heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
+        self.k1 = torch.randn(a.layers, 1, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
+        self.v1 = torch.randn(a.layers, 1, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
+        ctl.prepare_metadata(1)
+        self.outs = [None] * a.layers
+
+    def step(self):
+        """One decode token: llama.py:424-439 controller sequence + QuestAttention.py:99-157 per layer."""
+        qu, ctl, a = self.qu, self.ctl, self.a
+        skip = a.skip_layers
+        if skip > 0:
+            ctl.set_page_budget(1 << 20)
+            ctl.begin_forward(1)
+        else:
+            ctl.set_page_budget(self.page_budget)
+            ctl.begin_forward(1)
+        for layer in range(a.layers):
+            if skip > 0 and layer == skip:
+                ctl.end_forward()
+                ctl.set_page_budget(self.page_budget)
+                ctl.begin_forward(1, updateTensor=False)
+            q = self.q[layer]
+            qu.append_kv(self.k1[layer], self.v1[layer], ctl, layer)
+            if not ctl.need_estimate():
+                o = qu.decode_sparse_attn(q, ctl, layer, ctl.kv_indices_without_last)
+            else:
+                est = qu.decode_estimate(q, ctl, layer)
+                qu.decode_topk(est, ctl)
+                o = qu.decode_sparse_attn(q, ctl, layer, ctl.topk_dindices_buffer)
+            self.outs[layer] = o
+        ctl.end_forward()
+        return o
+
+
+def bytes_per_layer(a):
+    """Algorithmic bytes of one layer-step, SURVEY.md 8(d) accounting (= the reference benches')."""
+    S, D, Hq, Hkv = a.page_size, a.head_dim, a.heads, a.kv_heads
+    N = (a.seqlen + S - 1) // S
+    B = min(a.token_budget // S, N)
+    app = 4 * Hkv * D * 2 * 2 + 2 * 2 * Hkv * D * 2
+    est = N * Hkv * 2 * D * 2 + Hq * D * 2 + 4 * ((N + S - 1) // S) + Hq * (N - 1) * 2
+    topk = Hq * (N - 1) * (2 + 4) + Hq * (B - 1) * (2 + 4)
+    att = B * S * 2 * Hq * D * 2 + Hq * D * 2 + Hq * (B - 1) * 4 + Hq * D * 2
+    dense = N * S * 2 * Hq * D * 2 + Hq * D * 2 + Hq * (N - 1) * 4 + Hq * D * 2
+    return {"append": app, "estimate": est, "topk": topk, "attn": att, "chain": app + est + topk + att, "dense": dense}
+
+
+def time_kernel_loop(fn, layers, reps):
+    """Average duration of `fn(layer)` launched back to back on torch's current stream (the stream
+    the kernels are launched on), bracketed by two HIP events."""
+    for layer in range(min(4, layers)):
+        fn(layer)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 0
+    for _ in range(reps):
+        for layer in range(layers):
+            fn(layer)
+            n += 1
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n  # us
+
+
+def cpu_baseline(a, budget_s):
+    """The eager-PyTorch port of the reference's CPU-runnable oracle, on the host cores."""
+    from oracle import torch_ref
+
+    torch.manual_seed(0)
+    L, H, D = a.seqlen, a.heads, a.head_dim
+    q = torch.randn(1, H, D).half()
+    k = torch.randn(L, H, D).half()
+    v = torch.randn(L, H, D).half()
+    B = a.token_budget // a.page_size
+    with torch.inference_mode():
+        torch_ref.sparse_decode(q, k, v, a.page_size, B)  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            torch_ref.sparse_decode(q, k, v, a.page_size, B)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 64:
+                break
+    per_layer = el / n
+    return {"value": 1.0 / (per_layer * a.layers), "unit": "tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n} layer-steps of oracle.torch_ref.sparse_decode (eager fp16 CPU, L={L}, budget {B} pages, "
+                      f"H={H}); {per_layer * 1e3:.0f} ms per layer-step, scaled to {a.layers} layers"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the quest_amd operators have no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from quest_amd.parallel import gather_tokens
+
+    w = Workload(a, dev)
+    torch.cuda.synchronize()
+
+    # ---- the step, eager or captured
+    if a.mode == "graph":
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            w.step()  # warm the allocator / plan before capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            w.step()
+        run = graph.replay
+    else:
+        run = w.step
+
+    tok = torch.zeros(1, dtype=torch.int64, device=dev)  # stand-in for the sampled token id of this rank's sequence
+
+    def one_step():
+        run()
+        if dist is not None:
+            gather_tokens(tok, dist)
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / a.steps
+    value = world * a.steps / elapsed  # one sequence per GPU, one token per step
+
+    out = None
+    if rank == 0:
+        qu, ctl = w.qu, w.ctl
+        bpl = bytes_per_layer(a)
+        # ---- per-operator launch time with HIP events on the launch stream (steady state of this very step)
+        ctl.set_page_budget(w.page_budget)
+        ctl.begin_forward(1)
+        ppc, chunks = ctl._decode_handler.plan_info()
+        est0 = [qu.decode_estimate(w.q[l], ctl, l) for l in range(a.layers)]
+        for l in range(a.layers):
+            qu.decode_topk(est0[l], ctl)
+        idx = ctl.topk_dindices_buffer
+        reps = 6
+        t_att = time_kernel_loop(lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, idx), a.layers, reps)
+        t_est = time_kernel_loop(lambda l: qu.decode_estimate(w.q[l], ctl, l), a.layers, reps)
+        t_topk = time_kernel_loop(lambda l: qu.decode_topk(est0[l], ctl), a.layers, reps)
+        t_app = time_kernel_loop(lambda l: qu.append_kv(w.k1[l], w.v1[l], ctl, l), a.layers, reps)
+        ctl.end_forward()
+        ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_us": t_att,
+               "chain_us_in_step": ms_per_step * 1e3 / a.layers}
+        dense_us = None
+        if not a.no_dense:
+            ctl.set_page_budget(1 << 20)
+            ctl.begin_forward(1, updateTensor=False)
+            dense_us = time_kernel_loop(
+                lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, ctl.kv_indices_without_last), a.layers, 2)
+            ctl.end_forward()
+        achieved = bpl["attn"] / (t_att * 1e-6) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")  # PMC bytes/launch, filled from rocprofv3 --pmc runs
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("sparse_decode_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "self-attn decode tokens/s (attention-only), seqlen=32768 token_budget=2048, 1/2/4/8 GPU",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Yarn-Llama-2-7B-128K shapes, 1 sequence per GPU, "
+                                   "self-attention chain (append+estimate+top-k+sparse attn) x all layers per token",
+                       "layers": a.layers, "num_qo_heads": a.heads, "num_kv_heads": a.kv_heads,
+                       "head_dim": a.head_dim, "seqlen": a.seqlen, "page_size": a.page_size,
+                       "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
+                       "kv_layout": a.layout, "mode": a.mode, "skip_layers": a.skip_layers,
+                       "sequences_per_gpu": 1, "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
+            "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel (+merge_states_kernel)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att,
+                         "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}},
+            "ops_us": ops,
+            "selfattn_us_per_layer": ms_per_step * 1e3 / a.layers,
+            "chain_bytes_per_layer": bpl["chain"],
+            "chain_frac_of_hbm_peak": bpl["chain"] / (ms_per_step * 1e-3 / a.layers) / 1e9 / HBM_PEAK_GBS,
+        }
+        if dense_us is not None:
+            out["dense_full_kv_us"] = dense_us
+            out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
+            out["speedup_vs_dense"] = dense_us / (ms_per_step * 1e3 / a.layers)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, a.cpu_sample_s)
+        else:
+            out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
