@@ -94,6 +94,17 @@ int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo_heads, uin
                               quest_paged_kv_t metadata, quest_stream_t stream);
 
 /*
+ * Fused form of the two calls QuestAttention.forward makes back to back for a decode token
+ * (QuestAttention.py:106 append_kv, :136 decode_estimate): ONE launch writes the new token (k, v) into
+ * the cache + folds it into its page's metadata, and scores all pages but the current one.  The two
+ * halves touch disjoint bytes (the estimate excludes the current page's entry), so the result is
+ * identical to calling quest_append_kv_cache_decode then quest_estimate_attn_score.
+ */
+int quest_append_estimate(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                          uint32_t num_qo_heads, uint32_t n_out, quest_paged_kv_t metadata,
+                          quest_stream_t stream);
+
+/*
  * topk_filtering (bsk_ops.h:38-43, topk.cu:7-46 -> decode_select_k, decode_select_k.cuh:25-62,
  * which calls RAFT's radix_topk_one_block_kernel; re-implemented here).
  * estimated_value/indices: [num_heads][num_pages]; d_out/indices_out: [num_heads][page_budget].
@@ -127,6 +138,20 @@ int quest_decode_end_forward(quest_decode_handler_t* h);
  * lse: optional float[num_qo_heads] (natural log), may be NULL. */
 int quest_decode_forward(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
                          uint32_t num_qo_heads, float* lse, quest_stream_t stream);
+
+/*
+ * Fused form of decode_topk + decode_sparse_attn (QuestAttention.py:144-157): the top-k selection of
+ * quest_topk_filtering runs at the head of the attention kernel (every workgroup of a head recomputes
+ * it from the head's score row -- a 4 KiB L2-resident read -- so no second launch and no cross-workgroup
+ * hand-off), then the selected pages are gathered exactly as in quest_decode_forward.
+ *   scores      [num_qo_heads][n_scores] fp16, the estimate output (n_scores = pages - 1)
+ *   page_table  paged_kv.indices = the sequence's page table [n_scores + 1] (kv_indices_with_last)
+ *   topk_val_out / topk_idx_out  optional [num_qo_heads][n_selected_pages]: the selection, bit-identical
+ *                to quest_topk_filtering's outputs (same routine), for callers that inspect it.
+ */
+int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                    uint32_t num_qo_heads, const void* scores, uint32_t n_scores,
+                                    void* topk_val_out, int32_t* topk_idx_out, float* lse, quest_stream_t stream);
 
 /* Introspection of the current plan (for benches/tests): pages per workgroup, workgroups per head. */
 int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_chunk,

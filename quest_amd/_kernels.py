@@ -193,6 +193,28 @@ def append_kv_cache_decode(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_le
           "Append_kv_cache_decode")
 
 
+def append_estimate(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_len: int, kv_last_page_idx: int, q, o,
+                    metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len: int,
+                    metadata_last_page_idx: int, layout: int) -> None:
+    """EXTENSION (not in the reference surface): append_kv_cache_decode + estimate_attn_score in one
+    launch; results identical to the two separate ops."""
+    _check_append(k, v, kv_data, kv_indices, kv_indptr, metadata_data, metadata_indices, metadata_indptr, layout)
+    _check_eq(k.size(0), 1, "k.size(0), 1")
+    _check_input(q, "q")
+    _check_input(o, "o")
+    _check_dim(3, q, "q")
+    _check_dim(2, o, "o")
+    _check_eq(q.size(0), 1, "q.size(0), 1")
+    _check_eq(o.size(0), q.size(1), "o.size(0), num_heads")
+    _check_half(k, "Append_kv_cache_decode")
+    _check_half(q, "Estimate_attn_score")
+    kv = _paged(kv_data, kv_indices, kv_indptr, kv_last_page_len, kv_last_page_idx, layout)
+    meta = _paged(metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len, metadata_last_page_idx,
+                  layout)
+    check(lib.quest_append_estimate(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1), o.size(1),
+                                    meta, _stream(k)), "append_estimate")
+
+
 def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, causal: bool, layout: int,
                                 allow_fp16_qk_reduction: bool, rope_scale: float, rope_theta: float):
     """batch_prefill.cu:27-117 -- NOT on the sparse-decode path; torch SDPA over the gathered pages."""
@@ -275,6 +297,35 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
                     paged_kv_last_page_idx, self._layout, page_budget=paged_kv_indices.size(1))
         check(lib.quest_decode_forward(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), None, _stream(q)),
               "BatchDecodeWithPagedKVCache")
+
+    def forward_fused_topk(self, q, o, paged_kv_data, page_table, scores, topk_val_out, topk_idx_out,
+                           paged_kv_last_page_len: int, paged_kv_last_page_idx: int) -> bool:
+        """EXTENSION: topk_filtering + forward in one launch.  ``page_table`` is the sequence's page table
+        ``[n_pages]`` (kv_indices_with_last), ``scores`` the estimate output ``[Hq, n_pages-1]``.  Returns
+        False (nothing launched) when the current plan's chunks are too large for the fused front end."""
+        _check_input(q, "q")
+        _check_input(o, "o")
+        _check_input(paged_kv_data, "paged_kv_data")
+        _check_input(page_table, "page_table")
+        _check_input(scores, "scores")
+        _check_dim(3, q, "q")
+        _check_dim(1, page_table, "page_table")
+        _check_dim(2, scores, "scores")
+        _check_dim(5, paged_kv_data, "paged_kv_data")
+        _check_eq(scores.size(0), q.size(1), "scores.size(0), num_qo_heads")
+        _check_eq(page_table.size(0), scores.size(1) + 1, "page_table.size(0), n_scores + 1")
+        _check_eq(page_table.dtype, torch.int32, "page_table.scalar_type(), torch::kInt32")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        _check_half(scores, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, page_table, None, paged_kv_last_page_len, paged_kv_last_page_idx, self._layout)
+        code = lib.quest_decode_forward_fused_topk(
+            self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), scores.data_ptr(), scores.size(1),
+            topk_val_out.data_ptr() if topk_val_out is not None else None,
+            topk_idx_out.data_ptr() if topk_idx_out is not None else None, None, _stream(q))
+        if code == -2:  # QUEST_EUNSUPPORTED: chunk larger than the fused front end stages
+            return False
+        check(code, "BatchDecodeWithPagedKVCache")
+        return True
 
     # introspection used by the bench / tuning sweeps (not part of the reference surface)
     def plan_info(self):

@@ -39,12 +39,15 @@ SIGNATURES = {
     "quest_append_kv_cache_decode": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp]),
     "quest_append_kv_cache_prefill": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, PagedKV, c_vp]),
     "quest_estimate_attn_score": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp]),
+    "quest_append_estimate": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp]),
     "quest_topk_filtering": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
     "quest_decode_handler_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_u32]),
     "quest_decode_handler_destroy": (None, [c_vp]),
     "quest_decode_begin_forward": (ctypes.c_int, [c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp]),
     "quest_decode_end_forward": (ctypes.c_int, [c_vp]),
     "quest_decode_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp]),
+    "quest_decode_forward_fused_topk": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_vp, c_vp,
+                                                        c_vp, c_vp]),
     "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),
     "quest_apply_rope_in_place": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp]),

@@ -4,45 +4,73 @@
 // Reference behaviour restated (not translated): MaxPossibleSampleWithPagedKVCacheKernel,
 // kernels/include/decode/decode_attn.cuh:245-401, arithmetic compute_max_possible :137-168.
 // The reference launches one block per kv head (grid (1, H), :1131) which starves a 256-CU
-// part; here the page axis is tiled too: one workgroup = 16 metadata entries x HPB heads, so
-// cfg 3 (2047 entries, 32 heads) is 1024 workgroups, each streaming 32 KiB with all of its
-// loads in flight at once (8 x 16 B per lane), no LDS.
+// part; here the (entry, head) rows are tiled in memory order: one workgroup = 64 rows
+// (2 entries x 32 heads at cfg 3 -> 1024 workgroups), each streaming 2 x 16 KiB contiguous
+// with all of its loads in flight at once (8 x 16 B per lane), no LDS.
 //
 // Bit-exactness: per lane 8 consecutive features are accumulated left to right in fp32, rows
 // are reduced with the xor butterfly (offsets LPR/2..1), one fp32->fp16 RNE cast -- the
 // reference kernel's order, which the oracle (qo_estimate) restates.  Bound: HBM.
-#include "quest_common.cuh"
+#include "append_device.cuh"
 
 namespace quest {
 
-constexpr int kEstTile = 16;  // metadata entries per workgroup
+constexpr int kEstIter = 4;  // load instructions per tensor per wave, all in flight together
+
+// Work is the flat list of (entry, kv head) rows in MEMORY order, so consecutive rows are
+// consecutive 256 B vectors: NHD -> entry-major (all heads of an entry are 8 KiB contiguous for
+// H=32), HND -> (page, head, slot).  A wave takes kEstIter*R consecutive rows, a workgroup 4 waves.
+struct AppendTail {  // optional decode-append riding in the same launch (blocks >= est_blocks)
+    quest_paged_kv_t kv;
+    const uint16_t* key;
+    const uint16_t* value;
+    uint32_t est_blocks;
+    uint32_t enabled;
+};
 
 template <int D, int G, bool HND>
 __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict__ q, half_t* __restrict__ o,
-                                                       quest_paged_kv_t meta, uint32_t n_out) {
-    constexpr int LPR = D / kVec;      // lanes per row
-    constexpr int R = kWave / LPR;     // rows per wave instruction
-    constexpr int ITER = HND ? kEstTile / R : kEstTile / 4;
-    constexpr int HPB = HND ? 4 : R;   // heads per block
+                                                       quest_paged_kv_t meta, uint32_t n_out, AppendTail tail) {
+    if (tail.enabled && blockIdx.x >= tail.est_blocks) {
+        // The appended token only touches the CURRENT page's KV entry and metadata entry (index n_out),
+        // which the estimate excludes (e < n_out), so the two halves of the launch share no byte.
+        append_decode_body(tail.kv, meta, tail.key, tail.value, (blockIdx.x - tail.est_blocks) * 256 + threadIdx.x);
+        return;
+    }
+    constexpr int LPR = D / kVec;   // lanes per row
+    constexpr int R = kWave / LPR;  // rows per load instruction
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
-    const uint32_t e0 = blockIdx.x * kEstTile;
-    const uint32_t hk = blockIdx.y * HPB + (HND ? wave : row);
     const uint32_t Hkv = meta.num_heads, S = meta.page_size;
-    const bool head_ok = hk < Hkv;
     const PoolStrides ms = pool_strides(meta);
     const half_t* data = reinterpret_cast<const half_t*>(meta.data);
-    const int32_t* idx = meta.indices + meta.indptr[0];
+    const int32_t* idx = meta.indices;  // batch_size == 1: indptr[0] == 0 (estimate.cu:14)
+    const uint32_t row0 = (blockIdx.x * 4 + wave) * (kEstIter * R) + row;
 
-    half8 mx[ITER], mn[ITER];
-    uint32_t ent[ITER];
-    bool ok[ITER];
+    half8 mx[kEstIter], mn[kEstIter];
+    // MHA: q is requested together with the metadata (one extra 16 B load per row).  GQA: G vectors per
+    // row would cost 8*G VGPRs per row, so they are read (L1/L2-resident, 8 KiB total) when consumed.
+    constexpr int QPRE = (G == 1) ? 1 : 0;
+    float8 qv[kEstIter][QPRE ? 1 : 1];
+    uint32_t ent[kEstIter], head[kEstIter];
+    bool ok[kEstIter];
 #pragma unroll
-    for (int j = 0; j < ITER; ++j) {
-        const uint32_t e = HND ? e0 + j * R + row : e0 + wave * ITER + j;
+    for (int j = 0; j < kEstIter; ++j) {
+        const uint32_t r = row0 + j * R;
+        uint32_t e, hk;
+        if (HND) {
+            const uint32_t per_page = Hkv * S;
+            const uint32_t pg = r / per_page, rem = r % per_page;
+            hk = rem / S;
+            e = pg * S + rem % S;
+        } else {
+            e = r / Hkv;
+            hk = r % Hkv;
+        }
         ent[j] = e;
-        ok[j] = head_ok && e < n_out;
+        head[j] = hk;
+        ok[j] = e < n_out;
         mx[j] = (half8)(0);
         mn[j] = (half8)(0);
         if (ok[j]) {
@@ -50,49 +78,58 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
             const half_t* p = data + page * ms.page + (size_t)hk * ms.head + (size_t)(e % S) * ms.entry + col * kVec;
             mx[j] = ld8(p);
             mn[j] = ld8(p + ms.v_off);
+            if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)hk * D + col * kVec));
+        } else if (QPRE) {
+            qv[j][0] = (float8)(0.f);
         }
     }
 
-    float8 qv[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-        qv[g] = head_ok ? to_f32(ld8(q + ((size_t)hk * G + g) * D + col * kVec)) : (float8)(0.f);
-
-#pragma unroll
-    for (int j = 0; j < ITER; ++j) {
+    for (int j = 0; j < kEstIter; ++j) {
         const float8 a = to_f32(mx[j]), b = to_f32(mn[j]);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            float8 qg;
+            if (QPRE) qg = qv[j][0];
+            else qg = ok[j] ? to_f32(ld8(q + ((size_t)head[j] * G + g) * D + col * kVec)) : (float8)(0.f);
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < kVec; ++i) acc += __builtin_fmaxf(qv[g][i] * a[i], qv[g][i] * b[i]);
+            for (int i = 0; i < kVec; ++i) acc += __builtin_fmaxf(qg[i] * a[i], qg[i] * b[i]);
             acc = row_allreduce_sum<LPR>(acc);
-            if (ok[j] && col == 0) o[((size_t)hk * G + g) * n_out + ent[j]] = (half_t)acc;
+            if (ok[j] && col == 0) o[((size_t)head[j] * G + g) * n_out + ent[j]] = (half_t)acc;
         }
     }
 }
 
 template <int D, int G>
-static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, hipStream_t s) {
+static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, AppendTail tail,
+                           hipStream_t s) {
     constexpr int R = kWave / (D / kVec);
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
-    const uint32_t hpb = hnd ? 4 : R;
-    dim3 grid((n_out + kEstTile - 1) / kEstTile, (meta.num_heads + hpb - 1) / hpb);
+    const uint64_t entries = hnd ? (uint64_t)((n_out + meta.page_size - 1) / meta.page_size) * meta.page_size : n_out;
+    const uint64_t rows = entries * meta.num_heads;
+    const uint32_t rows_per_block = 4 * kEstIter * R;
+    tail.est_blocks = (uint32_t)((rows + rows_per_block - 1) / rows_per_block);
+    uint32_t blocks = tail.est_blocks;
+    if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + 255) / 256;
+    if (blocks == 0) return 0;
+    dim3 grid(blocks);
     if (hnd)
-        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(256), 0, s, (const half_t*)q, (half_t*)o, meta, n_out);
+        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(256), 0, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
     else
-        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(256), 0, s, (const half_t*)q, (half_t*)o, meta, n_out);
+        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(256), 0, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
     QUEST_LAUNCH_CHECK();
     return 0;
 }
 
 template <int D>
-static int dispatch_group(uint32_t G, const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, hipStream_t s) {
+static int dispatch_group(uint32_t G, const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta,
+                          const AppendTail& tail, hipStream_t s) {
     switch (G) {
-        case 1: return launch_estimate<D, 1>(q, o, n_out, meta, s);
-        case 2: return launch_estimate<D, 2>(q, o, n_out, meta, s);
-        case 4: return launch_estimate<D, 4>(q, o, n_out, meta, s);
-        case 8: return launch_estimate<D, 8>(q, o, n_out, meta, s);
+        case 1: return launch_estimate<D, 1>(q, o, n_out, meta, tail, s);
+        case 2: return launch_estimate<D, 2>(q, o, n_out, meta, tail, s);
+        case 4: return launch_estimate<D, 4>(q, o, n_out, meta, tail, s);
+        case 8: return launch_estimate<D, 8>(q, o, n_out, meta, tail, s);
         default: return QUEST_EUNSUPPORTED;
     }
 }
@@ -101,19 +138,43 @@ static int dispatch_group(uint32_t G, const void* q, void* o, uint32_t n_out, co
 
 using namespace quest;
 
-extern "C" int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo_heads, uint32_t n_out,
-                                         quest_paged_kv_t metadata, quest_stream_t stream) {
-    if (!q || !metadata.data || !metadata.indices || !metadata.indptr) return QUEST_EINVAL;
+namespace quest {
+int check_pool(const quest_paged_kv_t& p);  // append.hip
+}
+
+static int estimate_entry(const void* q, void* o, uint32_t num_qo_heads, uint32_t n_out, const quest_paged_kv_t& metadata,
+                          const AppendTail& tail, hipStream_t s) {
+    if (!q || !metadata.data || !metadata.indices) return QUEST_EINVAL;
     if (metadata.layout > QUEST_LAYOUT_HND || metadata.num_heads == 0 || metadata.page_size == 0) return QUEST_EINVAL;
     if (num_qo_heads == 0 || num_qo_heads % metadata.num_heads != 0) return QUEST_EINVAL;
-    if (n_out == 0) return 0;  // nothing to score (single page)
-    if (!o) return QUEST_EINVAL;
+    if (n_out > 0 && !o) return QUEST_EINVAL;
+    if (n_out == 0 && !tail.enabled) return 0;  // nothing to score (single page)
     const uint32_t G = num_qo_heads / metadata.num_heads;
-    hipStream_t s = (hipStream_t)stream;
     switch (metadata.head_dim) {
-        case 64: return dispatch_group<64>(G, q, o, n_out, metadata, s);
-        case 128: return dispatch_group<128>(G, q, o, n_out, metadata, s);
-        case 256: return dispatch_group<256>(G, q, o, n_out, metadata, s);
+        case 64: return dispatch_group<64>(G, q, o, n_out, metadata, tail, s);
+        case 128: return dispatch_group<128>(G, q, o, n_out, metadata, tail, s);
+        case 256: return dispatch_group<256>(G, q, o, n_out, metadata, tail, s);
         default: return QUEST_EUNSUPPORTED;
     }
+}
+
+extern "C" int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo_heads, uint32_t n_out,
+                                         quest_paged_kv_t metadata, quest_stream_t stream) {
+    AppendTail tail{};
+    return estimate_entry(q, o, num_qo_heads, n_out, metadata, tail, (hipStream_t)stream);
+}
+
+extern "C" int quest_append_estimate(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                     uint32_t num_qo_heads, uint32_t n_out, quest_paged_kv_t metadata,
+                                     quest_stream_t stream) {
+    if (!k || !v) return QUEST_EINVAL;
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
+    AppendTail tail{};
+    tail.kv = kv;
+    tail.key = (const uint16_t*)k;
+    tail.value = (const uint16_t*)v;
+    tail.enabled = 1;
+    return estimate_entry(q, o, num_qo_heads, n_out, metadata, tail, (hipStream_t)stream);
 }

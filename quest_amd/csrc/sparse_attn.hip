@@ -21,7 +21,7 @@
 // kernel that also normalises and casts (VariableLengthMergeStates' job).
 #include <new>
 
-#include "quest_common.cuh"
+#include "topk_select.cuh"
 
 namespace quest {
 
@@ -45,7 +45,14 @@ struct DecodeParams {
     uint32_t pages_per_chunk;
     uint32_t n_chunks;
     float scale_log2;  // 1/sqrt(D) * log2(e)
+    // fused top-k front end (FC > 0): `indices` is then the sequence's page table [n_scores + 1]
+    const uint16_t* scores;  // [Hq][n_scores] fp16 estimate output
+    uint32_t n_scores;
+    uint16_t* sel_val_out;   // optional [Hq][n_sel]
+    int32_t* sel_idx_out;    // optional [Hq][n_sel]
 };
+
+constexpr int kFusedMaxPpc = 64;  // pages per workgroup the fused front end can stage in LDS
 
 template <int D>
 struct RowState {
@@ -53,66 +60,58 @@ struct RowState {
     float8 acc = (float8)(0.f);
 };
 
-// Fold one group of R token rows (one load instruction's worth) into the row state.
-template <int D, int T>
-__device__ __forceinline__ void fold_page(RowState<D>& st, const float8& qv, const half8 (&k)[T], const half8 (&v)[T],
-                                          int row, uint32_t len) {
-    constexpr int LPR = D / kVec, R = kWave / LPR;
-    float s[T];
+// Fold NG groups of R token rows (one load instruction each) into the row state with ONE rescale.
+// len[g] is the number of valid rows counted from group g's first row (<= 0: none).
+template <int D, int NG>
+__device__ __forceinline__ void fold_groups(RowState<D>& st, const float8& qv, const half8 (&k)[NG], const half8 (&v)[NG],
+                                            const int (&rows_left)[NG], int row) {
+    constexpr int LPR = D / kVec;
+    float s[NG];
     float m_new = st.m;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float8 kf = to_f32(k[t]);
+    for (int g = 0; g < NG; ++g) {
+        const float8 kf = to_f32(k[g]);
         float dot = 0.f;
 #pragma unroll
         for (int i = 0; i < kVec; ++i) dot = __builtin_fmaf(qv[i], kf[i], dot);
         dot = row_allreduce_sum<LPR>(dot);
-        const bool valid = (uint32_t)(t * R + row) < len;
-        s[t] = valid ? dot : kNegFloor;
-        m_new = __builtin_fmaxf(m_new, s[t]);
+        s[g] = row < rows_left[g] ? dot : kNegFloor;
+        m_new = __builtin_fmaxf(m_new, s[g]);
     }
     const float scale = __builtin_amdgcn_exp2f(st.m - m_new);
     st.d *= scale;
     st.acc *= scale;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const bool valid = (uint32_t)(t * R + row) < len;
-        const float p = valid ? __builtin_amdgcn_exp2f(s[t] - m_new) : 0.f;
+    for (int g = 0; g < NG; ++g) {
+        // rows past the page length hold stale pool bytes (possibly NaN/Inf): select, never multiply by 0
+        const bool valid = row < rows_left[g];
+        const float p = valid ? __builtin_amdgcn_exp2f(s[g] - m_new) : 0.f;
         st.d += p;
-        const float8 vf = to_f32(v[t]);
+        const float8 vf = valid ? to_f32(v[g]) : (float8)(0.f);
 #pragma unroll
         for (int i = 0; i < kVec; ++i) st.acc[i] = __builtin_fmaf(p, vf[i], st.acc[i]);
     }
     st.m = m_new;
 }
 
-template <int D, int T>
-__device__ __forceinline__ void load_page(half8 (&k)[T], half8 (&v)[T], const half_t* pk, uint32_t entry_stride,
-                                          uint32_t v_off, int row, uint32_t len) {
-    constexpr int R = kWave / (D / kVec);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const uint32_t tok = t * R + row;
-        // rows past `len` (only possible in the sequence's last page) are not fetched
-        if (tok < len) {
-            const half_t* p = pk + (size_t)tok * entry_stride;
-            k[t] = ld8(p);
-            v[t] = ld8(p + v_off);
-        } else {
-            k[t] = (half8)(0);
-            v[t] = (half8)(0);
-        }
-    }
-}
-
 // S_T = compile-time page size (16) or 0 for the generic run-time path.
-template <int D, int S_T>
-__global__ __launch_bounds__(kDecWaves* kWave) void sparse_decode_kernel(DecodeParams p) {
+//
+// Addressing: the (page, kv head) tile base is wave-uniform (page id through readfirstlane -> SGPR
+// pair), the per-lane part (row*entry_stride + col*8) is a 32-bit offset fixed for the whole kernel,
+// so every load is `global_load_dwordx4 v, v_off, s[base] offset:imm` and the 16 loads of a slot pair
+// cost 64 data VGPRs and no address VGPRs.
+//
+// FC > 0 enables the fused top-k front end: the 256 threads own FC columns each of the head's score
+// row, run the shared selection routine (topk_select.cuh -- the same code as the stand-alone top-k
+// kernel, hence the same pages), and the columns whose output slot falls in this workgroup's chunk
+// drop their physical page id into LDS.  All workgroups of a head repeat the (cheap, L2-resident)
+// selection instead of waiting for one another.
+template <int D, int S_T, int FC>
+__global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(DecodeParams p) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hq = blockIdx.y, hk = hq / p.group;
-    const uint32_t S = S_T ? (uint32_t)S_T : p.page_size;
     const uint32_t n_slots = p.n_sel + 1;  // selected pages + the current page
     const uint32_t slot_begin = chunk * p.pages_per_chunk;
     const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
@@ -120,52 +119,93 @@ __global__ __launch_bounds__(kDecWaves* kWave) void sparse_decode_kernel(DecodeP
     float8 qv = to_f32(ld8(p.q + (size_t)hq * D + col * kVec));
     qv *= p.scale_log2;
 
-    const half_t* base = p.kv + (size_t)hk * p.st.head + col * kVec;
-    const int32_t* idx_row = p.indices + (size_t)hq * p.idx_stride;
+    const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
+    const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
+    const int32_t* idx_row = p.indices + (size_t)hq * p.idx_stride;  // uniform
     RowState<D> st;
 
-    auto page_ptr = [&](uint32_t slot, uint32_t& len) -> const half_t* {
-        const bool sel = slot < p.n_sel;
-        const int32_t page = sel ? idx_row[slot] : p.last_page_idx;
-        len = sel ? S : p.last_page_len;
-        return base + (size_t)page * p.st.page;
+    __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
+    if constexpr (FC > 0) {
+        __shared__ TopkSmem<kDecWaves * kWave> sm;
+        constexpr bool PRE = FC <= 16;  // page ids of the owned columns fetched with the scores
+        const uint32_t n = p.n_scores, c0 = threadIdx.x * FC;
+        const uint16_t* srow = p.scores + (size_t)hq * n;
+        const int32_t* table = p.indices;
+        uint32_t key[FC];
+        int32_t pid[PRE ? FC : 1];
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const bool in = c0 + i < n;
+            key[i] = in ? half_key(srow[c0 + i]) : 0u;
+            if (PRE) pid[i] = in ? table[c0 + i] : 0;
+        }
+        TopkCursor cur = topk_select<kDecWaves * kWave, FC>(sm, key, n, p.n_sel);
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            uint32_t slot;
+            if (topk_take(cur, key[i], c0 + i < n, slot) && slot >= slot_begin && slot < slot_end) {
+                const int32_t pg = PRE ? pid[i] : table[c0 + i];
+                s_sel[slot - slot_begin] = pg;
+                if (p.sel_idx_out) p.sel_idx_out[(size_t)hq * p.n_sel + slot] = pg;
+                if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + slot] = key_to_half_bits(key[i]);
+            }
+        }
+        __syncthreads();
+    }
+    // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
+    auto slot_page = [&](uint32_t slot) -> int32_t {
+        if (slot >= p.n_sel) return p.last_page_idx;
+        if constexpr (FC > 0) return s_sel[slot - slot_begin];
+        else return idx_row[slot];
     };
 
     if constexpr (S_T > 0) {
-        constexpr int T = (S_T + R - 1) / R;
-        half8 ka[T], va[T], kb[T], vb[T];
-        uint32_t len_a = 0, len_b = 0;
-        uint32_t slot = slot_begin + wave;
-        if (slot < slot_end) {
-            const half_t* pk = page_ptr(slot, len_a);
-            load_page<D, T>(ka, va, pk, p.st.entry, p.st.v_off, row, len_a);
-        }
-        while (slot < slot_end) {
-            uint32_t nxt = slot + kDecWaves;
-            if (nxt < slot_end) {
-                const half_t* pk = page_ptr(nxt, len_b);
-                load_page<D, T>(kb, vb, pk, p.st.entry, p.st.v_off, row, len_b);
+        constexpr int T = (S_T + R - 1) / R;  // load instructions per page per tensor
+        const uint32_t step = R * p.st.entry;
+        for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += 2 * kDecWaves) {
+            const uint32_t s1 = s0 + kDecWaves;
+            const bool has1 = s1 < slot_end;
+            int32_t pg0 = slot_page(s0);
+            int32_t pg1 = has1 ? slot_page(s1) : pg0;
+            pg0 = __builtin_amdgcn_readfirstlane(pg0);
+            pg1 = __builtin_amdgcn_readfirstlane(pg1);
+            const int len0 = s0 < p.n_sel ? S_T : (int)p.last_page_len;
+            const int len1 = has1 ? (s1 < p.n_sel ? S_T : (int)p.last_page_len) : 0;
+            const half_t* b0 = head_base + (size_t)pg0 * p.st.page;
+            const half_t* b1 = head_base + (size_t)pg1 * p.st.page;
+            half8 k[2 * T], v[2 * T];
+            int left[2 * T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                left[t] = len0 - t * R;
+                left[T + t] = len1 - t * R;
+                // rows past the page's length exist in the pool (the page is allocated) but hold
+                // stale bytes; they are fetched only for the sequence's last page and masked in fold
+                k[t] = ld8(b0 + lane_off + t * step);
+                v[t] = ld8(b0 + lane_off + t * step + p.st.v_off);
             }
-            fold_page<D, T>(st, qv, ka, va, row, len_a);
-            slot = nxt;
-            if (slot >= slot_end) break;
-            nxt = slot + kDecWaves;
-            if (nxt < slot_end) {
-                const half_t* pk = page_ptr(nxt, len_a);
-                load_page<D, T>(ka, va, pk, p.st.entry, p.st.v_off, row, len_a);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                k[T + t] = ld8(b1 + lane_off + t * step);
+                v[T + t] = ld8(b1 + lane_off + t * step + p.st.v_off);
             }
-            fold_page<D, T>(st, qv, kb, vb, row, len_b);
-            slot = nxt;
+            fold_groups<D, 2 * T>(st, qv, k, v, left, row);
         }
     } else {
+        const uint32_t S = p.page_size;
         for (uint32_t slot = slot_begin + wave; slot < slot_end; slot += kDecWaves) {
-            uint32_t len;
-            const half_t* pk = page_ptr(slot, len);
-            for (uint32_t t0 = 0; t0 < len; t0 += R) {
+            const bool sel = slot < p.n_sel;
+            const int32_t pg = __builtin_amdgcn_readfirstlane(slot_page(slot));
+            const int len = sel ? (int)S : (int)p.last_page_len;
+            const half_t* b = head_base + (size_t)pg * p.st.page;
+            for (int t0 = 0; t0 < len; t0 += R) {
                 half8 k1[1], v1[1];
-                const uint32_t rem = len - t0;
-                load_page<D, 1>(k1, v1, pk + (size_t)t0 * p.st.entry, p.st.entry, p.st.v_off, row, rem);
-                fold_page<D, 1>(st, qv, k1, v1, row, rem);
+                const int left[1] = {len - t0};
+                const bool in = row < left[0];
+                const half_t* ptr = b + lane_off + (size_t)t0 * p.st.entry;
+                k1[0] = in ? ld8(ptr) : (half8)(0);
+                v1[0] = in ? ld8(ptr + p.st.v_off) : (half8)(0);
+                fold_groups<D, 1>(st, qv, k1, v1, left, row);
             }
         }
     }
@@ -220,23 +260,76 @@ __global__ __launch_bounds__(kDecWaves* kWave) void sparse_decode_kernel(DecodeP
     }
 }
 
-// Merge the per-chunk partial states of a head, normalise, cast to fp16.
+// Merge the per-chunk partial states of a head, normalise, cast to fp16 (the job of flashinfer's
+// VariableLengthMergeStates).  kMergeGroups thread groups each take every kMergeGroups-th chunk with
+// all of their loads independent (unrolled), then combine through LDS: two memory round trips total.
+constexpr int kMergeGroups = 4;
+
 template <int D>
-__global__ __launch_bounds__(D) void merge_states_kernel(const float* __restrict__ ws, half_t* __restrict__ o,
-                                                         float* __restrict__ lse, uint32_t n_chunks) {
-    const uint32_t hq = blockIdx.x, f = threadIdx.x;
+__global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const float* __restrict__ ws,
+                                                                        half_t* __restrict__ o,
+                                                                        float* __restrict__ lse, uint32_t n_chunks) {
+    __shared__ float s_w[1024];  // per-chunk weight exp2(m_c - M); planner keeps n_chunks <= 1024
+    __shared__ float s_red[kMergeGroups][D + 1];
+    __shared__ float s_M;
+    const uint32_t hq = blockIdx.x, tid = threadIdx.x;
+    const uint32_t f = tid % D, g = tid / D;
     const float* w = ws + (size_t)hq * n_chunks * (D + 2);
-    float M = kNegFloor;
-    for (uint32_t c = 0; c < n_chunks; ++c) M = __builtin_fmaxf(M, w[(size_t)c * (D + 2) + D]);
-    float acc = 0.f, den = 0.f;
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-        const float* wc = w + (size_t)c * (D + 2);
-        const float e = __builtin_amdgcn_exp2f(wc[D] - M);
-        acc += e * wc[f];
-        den += e * wc[D + 1];
+    // the first kPre partial rows of this thread's chunks are requested up front so the whole merge is
+    // one memory round trip for n_chunks <= kPre * kMergeGroups
+    constexpr int kPre = 8;
+    float pre[kPre];
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+        const uint32_t c = g + j * kMergeGroups;
+        pre[j] = c < n_chunks ? w[(size_t)c * (D + 2) + f] : 0.f;
     }
-    o[(size_t)hq * D + f] = (half_t)(acc / den);
-    if (lse && f == 0) lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
+    // pass 1: chunk maxima -> M, weights, denominator
+    float M = kNegFloor;
+    for (uint32_t c = tid; c < n_chunks; c += blockDim.x) M = __builtin_fmaxf(M, w[(size_t)c * (D + 2) + D]);
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) M = __builtin_fmaxf(M, __shfl_xor(M, off, kWave));
+    if ((tid & 63) == 0) s_red[0][tid >> 6] = M;
+    __syncthreads();
+    if (tid == 0) {
+        float mm = s_red[0][0];
+        for (uint32_t i = 1; i < (blockDim.x >> 6); ++i) mm = __builtin_fmaxf(mm, s_red[0][i]);
+        s_M = mm;
+    }
+    __syncthreads();
+    M = s_M;
+    float den = 0.f;
+    for (uint32_t c = tid; c < n_chunks; c += blockDim.x) {
+        const float e = __builtin_amdgcn_exp2f(w[(size_t)c * (D + 2) + D] - M);
+        s_w[c] = e;
+        den += e * w[(size_t)c * (D + 2) + D + 1];
+    }
+    __syncthreads();
+    // pass 2: weighted sum of the partial outputs
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+        const uint32_t c = g + j * kMergeGroups;
+        if (c < n_chunks) acc += s_w[c] * pre[j];
+    }
+#pragma unroll 8
+    for (uint32_t c = g + kPre * kMergeGroups; c < n_chunks; c += kMergeGroups)
+        acc += s_w[c] * w[(size_t)c * (D + 2) + f];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) den += __shfl_xor(den, off, kWave);
+    s_red[g][f] = acc;
+    __shared__ float s_den[16];
+    if ((tid & 63) == 0) s_den[tid >> 6] = den;
+    __syncthreads();
+    if (g == 0) {
+        float a = s_red[0][f];
+#pragma unroll
+        for (int j = 1; j < kMergeGroups; ++j) a += s_red[j][f];
+        float dn = 0.f;
+        for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) dn += s_den[i];
+        o[(size_t)hq * D + f] = (half_t)(a / dn);
+        if (lse && f == 0) lse[hq] = (M + __builtin_amdgcn_logf(dn)) * 0.6931471805599453f;
+    }
 }
 
 }  // namespace quest
@@ -253,8 +346,10 @@ struct quest_decode_handler {
     size_t ws_bytes = 0;
 };
 
-// Workgroups the planner aims for: 4 per CU x 256 CUs keeps ~128 KiB of loads in flight per CU.
-static constexpr uint32_t kTargetWorkgroups = 1024;
+// Workgroups the planner aims for: the kernel is built for 2 workgroups (8 waves) per CU, so 512
+// workgroups are one fully resident round on 256 CUs, each wave with 16 x 1 KiB loads in flight.
+static constexpr uint32_t kTargetWorkgroups = 512;
+static constexpr uint32_t kMaxChunks = 1024;  // merge kernel's LDS weight table
 
 extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout) {
     if (!out || layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
@@ -299,6 +394,7 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
         if (chunks > n_slots) chunks = n_slots;
         ppc = (n_slots + chunks - 1) / chunks;
     }
+    if ((n_slots + ppc - 1) / ppc > kMaxChunks) ppc = (n_slots + kMaxChunks - 1) / kMaxChunks;
     h->pages_per_chunk = ppc;
     h->n_chunks = (n_slots + ppc - 1) / ppc;
     const size_t need = (size_t)num_qo_heads * h->n_chunks * (head_dim + 2) * sizeof(float);
@@ -328,28 +424,50 @@ extern "C" int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t*
     return 0;
 }
 
-template <int D>
-static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, hipStream_t s) {
+template <int D, int FC>
+static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, hipStream_t s) {
     dim3 grid(h->n_chunks, num_qo_heads), block(kDecWaves * kWave);
     if (p.page_size == 16)
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 16>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC>), grid, block, 0, s, p);
     else
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 0>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC>), grid, block, 0, s, p);
     QUEST_LAUNCH_CHECK();
     if (h->n_chunks > 1) {
-        hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D), 0, s, (const float*)p.ws, p.o, p.lse,
-                           h->n_chunks);
+        hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D * kMergeGroups), 0, s,
+                           (const float*)p.ws, p.o, p.lse, h->n_chunks);
         QUEST_LAUNCH_CHECK();
     }
     return 0;
 }
 
-extern "C" int quest_decode_forward(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
-                                    uint32_t num_qo_heads, float* lse, quest_stream_t stream) {
+// fc = columns per thread of the fused top-k front end (0 = page ids come from an index tensor)
+template <int D>
+static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t fc,
+                         hipStream_t s) {
+    switch (fc) {
+        case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, s);
+        case 8: return launch_decode_fc<D, 8>(h, p, num_qo_heads, s);
+        case 16: return launch_decode_fc<D, 16>(h, p, num_qo_heads, s);
+        case 32: return launch_decode_fc<D, 32>(h, p, num_qo_heads, s);
+        case 64: return launch_decode_fc<D, 64>(h, p, num_qo_heads, s);
+        default: return QUEST_EUNSUPPORTED;
+    }
+}
+
+static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, const quest_paged_kv_t& kv,
+                        uint32_t num_qo_heads, const void* scores, uint32_t n_scores, void* topk_val_out,
+                        int32_t* topk_idx_out, float* lse, hipStream_t s) {
     if (!h) return QUEST_EINVAL;
     if (!h->started) return QUEST_ESTATE;
     if (!q || !o || !kv.data) return QUEST_EINVAL;
-    if (h->n_sel > 0 && (!kv.indices || kv.page_budget < h->n_sel)) return QUEST_EINVAL;
+    const bool fused = scores != nullptr;
+    if (fused) {
+        if (!kv.indices || h->n_sel == 0 || h->n_sel > n_scores) return QUEST_EINVAL;
+        if (n_scores > QUEST_TOPK_MAX_ROW) return QUEST_ETOOLARGE;
+        if (h->pages_per_chunk > (uint32_t)kFusedMaxPpc) return QUEST_EUNSUPPORTED;
+    } else if (h->n_sel > 0 && (!kv.indices || kv.page_budget < h->n_sel)) {
+        return QUEST_EINVAL;
+    }
     if (kv.layout != h->layout || kv.head_dim != h->head_dim || kv.page_size != h->page_size ||
         kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
         return QUEST_EINVAL;
@@ -362,7 +480,7 @@ extern "C" int quest_decode_forward(quest_decode_handler_t* h, const void* q, vo
     p.indices = kv.indices;
     p.ws = h->ws;
     p.st = pool_strides(kv);
-    p.idx_stride = kv.page_budget;
+    p.idx_stride = fused ? 0 : kv.page_budget;
     p.n_sel = h->n_sel;
     p.last_page_len = kv.last_page_len;
     p.last_page_idx = kv.last_page_idx;
@@ -371,13 +489,35 @@ extern "C" int quest_decode_forward(quest_decode_handler_t* h, const void* q, vo
     p.pages_per_chunk = h->pages_per_chunk;
     p.n_chunks = h->n_chunks;
     p.scale_log2 = (float)(1.4426950408889634 / sqrt((double)kv.head_dim));
-    hipStream_t s = (hipStream_t)stream;
+    p.scores = (const uint16_t*)scores;
+    p.n_scores = n_scores;
+    p.sel_val_out = (uint16_t*)topk_val_out;
+    p.sel_idx_out = topk_idx_out;
+    uint32_t fc = 0;
+    if (fused) {
+        const uint32_t per_thread = (n_scores + kDecWaves * kWave - 1) / (kDecWaves * kWave);
+        fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
+    }
     switch (kv.head_dim) {
-        case 64: return launch_decode<64>(h, p, num_qo_heads, s);
-        case 128: return launch_decode<128>(h, p, num_qo_heads, s);
-        case 256: return launch_decode<256>(h, p, num_qo_heads, s);
+        case 64: return launch_decode<64>(h, p, num_qo_heads, fc, s);
+        case 128: return launch_decode<128>(h, p, num_qo_heads, fc, s);
+        case 256: return launch_decode<256>(h, p, num_qo_heads, fc, s);
         default: return QUEST_EUNSUPPORTED;
     }
+}
+
+extern "C" int quest_decode_forward(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
+                                    uint32_t num_qo_heads, float* lse, quest_stream_t stream) {
+    return decode_entry(h, q, o, kv, num_qo_heads, nullptr, 0, nullptr, nullptr, lse, (hipStream_t)stream);
+}
+
+extern "C" int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
+                                               uint32_t num_qo_heads, const void* scores, uint32_t n_scores,
+                                               void* topk_val_out, int32_t* topk_idx_out, float* lse,
+                                               quest_stream_t stream) {
+    if (!scores) return QUEST_EINVAL;
+    return decode_entry(h, q, o, kv, num_qo_heads, scores, n_scores, topk_val_out, topk_idx_out, lse,
+                        (hipStream_t)stream);
 }
 
 extern "C" const char* quest_error_string(int code) {

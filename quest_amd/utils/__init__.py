@@ -27,6 +27,9 @@ __all__ = [
     "decode_sparse_attn",
     "rms_norm_forward",
     "apply_rope_in_place",
+    # extensions (fused launches; same results as the op pairs they replace)
+    "decode_append_estimate",
+    "decode_topk_sparse_attn",
 ]
 
 
@@ -96,4 +99,36 @@ def decode_sparse_attn(q: torch.Tensor, iController: InferenceController, layer_
     iController._decode_handler.forward(q, o, iController.kv_cache.buf_layer(layer_idx), topk_indices,
                                         iController.kv_indptr_for_approx_decode, iController.kv_cache.last_page_len,
                                         iController.kv_last_page_idx, rope_scale, rope_theta)
+    return o
+
+
+# ---------------------------------------------------------------------------- fused extensions
+# The reference issues five launches per layer for a decode token (append, estimate, top-k, attention,
+# merge).  On MI355X each dependent launch costs ~1.5-2 us of boundary + a memory round trip, comparable
+# to the 5 us the data movement itself takes, so the two pairs below are also offered as single launches.
+# They are bit-identical to the pairs (tests/test_gpu_parity.py::test_fused_equals_unfused).
+
+def decode_append_estimate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
+                           layer_idx: int) -> torch.Tensor:
+    """``append_kv(k, v)`` + ``decode_estimate(q)`` in one launch; returns the scores ``[Hq, n_pages-1]``."""
+    meta = iController.metadata_cache
+    o = torch.empty((iController.num_heads, meta.seqlen - 1), dtype=q.dtype, device=q.device)
+    a = _append_args(iController, layer_idx)
+    _kernels.append_estimate(k, v, a[0], a[1], a[2], a[3], a[4], q, o, a[5], a[6], a[7], a[8], a[9], a[10])
+    return o
+
+
+def decode_topk_sparse_attn(q: torch.Tensor, estimated_attn_score: torch.Tensor, iController: InferenceController,
+                            layer_idx: int, write_topk: bool = True) -> torch.Tensor:
+    """``decode_topk(scores)`` + ``decode_sparse_attn(q, topk_dindices_buffer)`` in one launch.  With
+    ``write_topk`` the selection also lands in ``topk_dout_buffer`` / ``topk_dindices_buffer``."""
+    o = torch.empty_like(q)
+    ok = iController._decode_handler.forward_fused_topk(
+        q, o, iController.kv_cache.buf_layer(layer_idx), iController.kv_indices_with_last, estimated_attn_score,
+        iController.topk_dout_buffer if write_topk else None,
+        iController.topk_dindices_buffer if write_topk else None,
+        iController.kv_cache.last_page_len, iController.kv_last_page_idx)
+    if not ok:  # plan with very large chunks: take the two-launch path
+        decode_topk(estimated_attn_score, iController)
+        return decode_sparse_attn(q, iController, layer_idx, iController.topk_dindices_buffer)
     return o

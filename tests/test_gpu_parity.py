@@ -366,3 +366,53 @@ def test_cfg3_full_size_properties():
     pd = torch.softmax((kh @ q[0].float()[:, :, None]).squeeze(-1) / 128 ** 0.5, dim=-1)
     torch.testing.assert_close(od[0].float(), (pd[:, None] @ vh).squeeze(1), rtol=5e-3, atol=5e-3)
     ctl.end_forward()
+
+
+# ---------------------------------------------------------------------------- fused launches
+
+@pytest.mark.parametrize("Hq,Hkv,D,page,B,L,layout", [(32, 32, 128, 16, 128, 4099, 0), (32, 8, 128, 16, 12, 613, 1),
+                                                       (8, 8, 128, 16, 40, 1541, 0), (8, 2, 64, 16, 9, 777, 0),
+                                                       (8, 8, 256, 16, 5, 300, 1), (4, 4, 128, 8, 17, 500, 0),
+                                                       (8, 8, 128, 16, 200, 9000, 0), (4, 2, 128, 16, 300, 40000, 0)])
+def test_fused_equals_unfused(Hq, Hkv, D, page, B, L, layout):
+    """append+estimate in one launch and top-k+attention in one launch must reproduce the separate
+    ops bit for bit (pools, scores, selected pages) and the attention output exactly as well."""
+    qu = _qu()
+    q, k, v = inputs(900 + Hq + D + page + B, L, Hq, Hkv, D)
+    outs = []
+    for fused in (False, True):
+        ctl = make_controller(L, Hq, Hkv, D, page, B, layout=layout, shuffle_seed=11)
+        kc, vc, qc = cuda(k), cuda(v), cuda(q)
+        ctl.prepare_metadata(L - 1)
+        ctl.begin_forward(L - 1)
+        qu.append_kv(kc[:-1], vc[:-1], ctl, 0)
+        ctl.end_forward()
+        ctl.prepare_metadata(1)
+        ctl.begin_forward(1)
+        assert ctl.need_estimate()
+        if fused:
+            est = qu.decode_append_estimate(qc, kc[-1:], vc[-1:], ctl, 0)
+            o = qu.decode_topk_sparse_attn(qc, est, ctl, 0)
+        else:
+            qu.append_kv(kc[-1:], vc[-1:], ctl, 0)
+            est = qu.decode_estimate(qc, ctl, 0)
+            qu.decode_topk(est, ctl)
+            o = qu.decode_sparse_attn(qc, ctl, 0, ctl.topk_dindices_buffer)
+        ctl.end_forward()
+        n_pages = len(ctl.kv_cache.indicies)
+        outs.append((est.cpu().numpy(), ctl.topk_dindices_buffer.cpu().numpy().copy(),
+                     ctl.topk_dout_buffer.cpu().numpy().copy(), o.cpu().numpy(),
+                     ctl.kv_cache.buf_layer(0)[ctl.kv_indices_with_last.long()].cpu().numpy(),
+                     ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()].cpu().numpy(), n_pages))
+    a, b = outs
+    assert np.array_equal(U16(a[0]), U16(b[0])), "scores"
+    assert np.array_equal(a[1], b[1]), "selected pages"
+    assert np.array_equal(U16(a[2]), U16(b[2])), "selected values"
+    assert np.array_equal(U16(a[3]), U16(b[3])), "attention output"
+    # pools: compare only valid entries (the tail of the last page / last metadata page is uninitialised)
+    from _harness import gather_entries
+    for x, y, n in ((a[4], b[4], L), (a[5], b[5], a[6])):
+        idx = np.arange(x.shape[0])
+        kx, vx = gather_entries(x, idx, n, layout)
+        ky, vy = gather_entries(y, idx, n, layout)
+        assert np.array_equal(U16(kx), U16(ky)) and np.array_equal(U16(vx), U16(vy))
