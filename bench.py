@@ -48,6 +48,9 @@ def parse():
                     help="graph: the whole step captured in one hipGraph and replayed; eager: Python op by op")
     ap.add_argument("--skip-layers", type=int, default=0,
                     help="run the first n layers with full KV like quest/models/llama.py:428-439 (default 0)")
+    ap.add_argument("--unfused", action="store_true",
+                    help="issue the reference's five launches per layer instead of the fused append+estimate and "
+                         "top-k+attention launches (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--cpu-sample-s", type=float, default=12.0)
@@ -103,13 +106,17 @@ class Workload:
                 ctl.set_page_budget(self.page_budget)
                 ctl.begin_forward(1, updateTensor=False)
             q = self.q[layer]
-            qu.append_kv(self.k1[layer], self.v1[layer], ctl, layer)
             if not ctl.need_estimate():
+                qu.append_kv(self.k1[layer], self.v1[layer], ctl, layer)
                 o = qu.decode_sparse_attn(q, ctl, layer, ctl.kv_indices_without_last)
-            else:
+            elif a.unfused:
+                qu.append_kv(self.k1[layer], self.v1[layer], ctl, layer)
                 est = qu.decode_estimate(q, ctl, layer)
                 qu.decode_topk(est, ctl)
                 o = qu.decode_sparse_attn(q, ctl, layer, ctl.topk_dindices_buffer)
+            else:
+                est = qu.decode_append_estimate(q, self.k1[layer], self.v1[layer], ctl, layer)
+                o = qu.decode_topk_sparse_attn(q, est, ctl, layer)
             self.outs[layer] = o
         ctl.end_forward()
         return o
@@ -286,6 +293,8 @@ def main():
                        "head_dim": a.head_dim, "seqlen": a.seqlen, "page_size": a.page_size,
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
                        "kv_layout": a.layout, "mode": a.mode, "skip_layers": a.skip_layers,
+                       "launches_per_layer": "5 (reference op sequence)" if a.unfused else
+                       "3 (append+estimate | top-k+sparse attn | merge)",
                        "sequences_per_gpu": 1, "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
             "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel (+merge_states_kernel)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

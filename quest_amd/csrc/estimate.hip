@@ -71,17 +71,14 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
         ent[j] = e;
         head[j] = hk;
         ok[j] = e < n_out;
-        mx[j] = (half8)(0);
-        mn[j] = (half8)(0);
-        if (ok[j]) {
-            const size_t page = (size_t)idx[e / S];
-            const half_t* p = data + page * ms.page + (size_t)hk * ms.head + (size_t)(e % S) * ms.entry + col * kVec;
-            mx[j] = ld8(p);
-            mn[j] = ld8(p + ms.v_off);
-            if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)hk * D + col * kVec));
-        } else if (QPRE) {
-            qv[j][0] = (float8)(0.f);
-        }
+        // Loads are unconditional from a clamped entry: a predicated load compiles to branch + load +
+        // wait and serialises the kEstIter round trips.  Clamped rows re-read entry n_out-1 (tail only).
+        const uint32_t ec = ok[j] ? e : n_out - 1;
+        const size_t page = (size_t)idx[ec / S];
+        const half_t* p = data + page * ms.page + (size_t)hk * ms.head + (size_t)(ec % S) * ms.entry + col * kVec;
+        mx[j] = ld8(p);
+        mn[j] = ld8(p + ms.v_off);
+        if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)hk * D + col * kVec));
     }
 
 #pragma unroll
@@ -91,7 +88,7 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
         for (int g = 0; g < G; ++g) {
             float8 qg;
             if (QPRE) qg = qv[j][0];
-            else qg = ok[j] ? to_f32(ld8(q + ((size_t)head[j] * G + g) * D + col * kVec)) : (float8)(0.f);
+            else qg = to_f32(ld8(q + ((size_t)head[j] * G + g) * D + col * kVec));
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < kVec; ++i) acc += __builtin_fmaxf(qg[i] * a[i], qg[i] * b[i]);

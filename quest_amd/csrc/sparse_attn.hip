@@ -124,7 +124,39 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
     const int32_t* idx_row = p.indices + (size_t)hq * p.idx_stride;  // uniform
     RowState<D> st;
 
-    __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
+    __shared__ int32_t s_sel[FC != 0 ? kFusedMaxPpc : 1];
+    if constexpr (FC < 0) {
+        // rows up to 64*(-FC) columns: wave 0 alone selects (no barriers inside), the other waves go
+        // straight to the one barrier below
+        constexpr int C = -FC;
+        __shared__ TopkWaveSmem wsm;
+        if (wave == 0) {
+            const uint32_t n = p.n_scores;
+            const uint16_t* srow = p.scores + (size_t)hq * n;
+            const int32_t* table = p.indices;
+            uint32_t key[C];
+            int32_t pid[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const uint32_t c = i * kWave + lane, cc = c < n ? c : n - 1;  // clamped, unconditional loads
+                key[i] = half_key(srow[cc]);
+                pid[i] = table[cc];
+            }
+            const TopkWaveResult r = topk_select_wave<C>(wsm, key, n, p.n_sel, lane);
+            TopkWaveCursor cur;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                uint32_t slot;
+                if (topk_wave_take(cur, r, key[i], (uint32_t)(i * kWave + lane) < n, lane, slot) && slot >= slot_begin &&
+                    slot < slot_end) {
+                    s_sel[slot - slot_begin] = pid[i];
+                    if (p.sel_idx_out) p.sel_idx_out[(size_t)hq * p.n_sel + slot] = pid[i];
+                    if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + slot] = key_to_half_bits(key[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
     if constexpr (FC > 0) {
         __shared__ TopkSmem<kDecWaves * kWave> sm;
         constexpr bool PRE = FC <= 16;  // page ids of the owned columns fetched with the scores
@@ -135,9 +167,9 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
         int32_t pid[PRE ? FC : 1];
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
-            const bool in = c0 + i < n;
-            key[i] = in ? half_key(srow[c0 + i]) : 0u;
-            if (PRE) pid[i] = in ? table[c0 + i] : 0;
+            const uint32_t cc = c0 + i < n ? c0 + i : n - 1;  // clamped, unconditional loads
+            key[i] = half_key(srow[cc]);
+            if (PRE) pid[i] = table[cc];
         }
         TopkCursor cur = topk_select<kDecWaves * kWave, FC>(sm, key, n, p.n_sel);
 #pragma unroll
@@ -155,7 +187,7 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
     // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
     auto slot_page = [&](uint32_t slot) -> int32_t {
         if (slot >= p.n_sel) return p.last_page_idx;
-        if constexpr (FC > 0) return s_sel[slot - slot_begin];
+        if constexpr (FC != 0) return s_sel[slot - slot_begin];
         else return idx_row[slot];
     };
 
@@ -201,10 +233,12 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
             for (int t0 = 0; t0 < len; t0 += R) {
                 half8 k1[1], v1[1];
                 const int left[1] = {len - t0};
-                const bool in = row < left[0];
-                const half_t* ptr = b + lane_off + (size_t)t0 * p.st.entry;
-                k1[0] = in ? ld8(ptr) : (half8)(0);
-                v1[0] = in ? ld8(ptr + p.st.v_off) : (half8)(0);
+                // rows past `len` stay inside the (allocated) page for page sizes that are a multiple of R;
+                // otherwise clamp to the page's first row -- masked in fold either way
+                const uint32_t r_in = (uint32_t)(t0 + row) < S ? (uint32_t)t0 : 0u;
+                const half_t* ptr = b + lane_off + (size_t)r_in * p.st.entry - (r_in == (uint32_t)t0 ? 0 : (size_t)row * p.st.entry);
+                k1[0] = ld8(ptr);
+                v1[0] = ld8(ptr + p.st.v_off);
                 fold_groups<D, 1>(st, qv, k1, v1, left, row);
             }
         }
@@ -281,8 +315,8 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
     float pre[kPre];
 #pragma unroll
     for (int j = 0; j < kPre; ++j) {
-        const uint32_t c = g + j * kMergeGroups;
-        pre[j] = c < n_chunks ? w[(size_t)c * (D + 2) + f] : 0.f;
+        const uint32_t c = g + j * kMergeGroups, cc = c < n_chunks ? c : n_chunks - 1;  // clamped: no branch
+        pre[j] = w[(size_t)cc * (D + 2) + f];
     }
     // pass 1: chunk maxima -> M, weights, denominator
     float M = kNegFloor;
@@ -440,9 +474,9 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     return 0;
 }
 
-// fc = columns per thread of the fused top-k front end (0 = page ids come from an index tensor)
+// fc: fused top-k front end variant (0 = page ids come from an index tensor)
 template <int D>
-static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t fc,
+static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, int fc,
                          hipStream_t s) {
     switch (fc) {
         case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, s);
@@ -493,7 +527,8 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, const
     p.n_scores = n_scores;
     p.sel_val_out = (uint16_t*)topk_val_out;
     p.sel_idx_out = topk_idx_out;
-    uint32_t fc = 0;
+    // fc < 0: single-wave selection with -fc columns per lane (rows <= 4096); fc > 0: block selection
+    int fc = 0;
     if (fused) {
         const uint32_t per_thread = (n_scores + kDecWaves * kWave - 1) / (kDecWaves * kWave);
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
