@@ -136,21 +136,31 @@ def bytes_per_layer(a):
 
 
 def time_kernel_loop(fn, layers, reps):
-    """Average duration of `fn(layer)` launched back to back on torch's current stream (the stream
-    the kernels are launched on), bracketed by two HIP events."""
-    for layer in range(min(4, layers)):
-        fn(layer)
+    """Average duration of one `fn(layer)` launch: `layers` back-to-back launches (one per layer, so
+    every launch reads a different pool) are captured into a hipGraph on torch's current stream -- the
+    stream the kernels are launched on -- and `reps` replays are bracketed by two HIP events.  The
+    figure includes the dependent-launch boundary (~1.5 us), i.e. what the op costs inside a step."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for layer in range(layers):
+            fn(layer)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for layer in range(layers):
+            fn(layer)
+    for _ in range(2):
+        g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = 0
     for _ in range(reps):
-        for layer in range(layers):
-            fn(layer)
-            n += 1
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / n  # us
+    return e0.elapsed_time(e1) * 1e3 / (reps * layers)  # us
 
 
 def cpu_baseline(a, budget_s):
@@ -259,20 +269,25 @@ def main():
         for l in range(a.layers):
             qu.decode_topk(est0[l], ctl)
         idx = ctl.topk_dindices_buffer
-        reps = 6
+        reps = 10
         t_att = time_kernel_loop(lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, idx), a.layers, reps)
         t_est = time_kernel_loop(lambda l: qu.decode_estimate(w.q[l], ctl, l), a.layers, reps)
         t_topk = time_kernel_loop(lambda l: qu.decode_topk(est0[l], ctl), a.layers, reps)
         t_app = time_kernel_loop(lambda l: qu.append_kv(w.k1[l], w.v1[l], ctl, l), a.layers, reps)
+        t_ae = time_kernel_loop(lambda l: qu.decode_append_estimate(w.q[l], w.k1[l], w.v1[l], ctl, l), a.layers, reps)
+        t_ts = time_kernel_loop(lambda l: qu.decode_topk_sparse_attn(w.q[l], est0[l], ctl, l), a.layers, reps)
         ctl.end_forward()
-        ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_us": t_att,
-               "chain_us_in_step": ms_per_step * 1e3 / a.layers}
+        ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_plus_merge_us": t_att,
+               "fused_append_estimate_us": t_ae, "fused_topk_sparse_attn_plus_merge_us": t_ts,
+               "chain_us_in_step": ms_per_step * 1e3 / a.layers,
+               "note": "per launch inside a hipGraph of 32 back-to-back launches (one per layer), "
+                       "dependent-launch boundary included"}
         dense_us = None
         if not a.no_dense:
             ctl.set_page_budget(1 << 20)
             ctl.begin_forward(1, updateTensor=False)
             dense_us = time_kernel_loop(
-                lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, ctl.kv_indices_without_last), a.layers, 2)
+                lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, ctl.kv_indices_without_last), a.layers, 3)
             ctl.end_forward()
         achieved = bpl["attn"] / (t_att * 1e-6) / 1e9
         traffic = None
@@ -296,7 +311,7 @@ def main():
                        "launches_per_layer": "5 (reference op sequence)" if a.unfused else
                        "3 (append+estimate | top-k+sparse attn | merge)",
                        "sequences_per_gpu": 1, "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
-            "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel (+merge_states_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel + merge_states_kernel (one decode_sparse_attn op)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att,

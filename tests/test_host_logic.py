@@ -1,0 +1,171 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the
+``_kernels`` shim validates arguments like the reference's CHECK_* macros, and the controller / KV-cache
+bookkeeping follows quest/utils/controller.py and kv_cache.py."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from quest_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "quest_hip.h")).read()
+    declared = set(re.findall(r"\b(quest_[a-z0-9_]+)\s*\(", header))
+    declared -= {"quest_stream_t"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(_lib.lib, name)
+    assert b"gfx950" in _lib.lib.quest_build_info()
+    assert b"begin_forward" in _lib.lib.quest_error_string(-3)
+
+
+def test_c_abi_argument_errors_without_gpu():
+    """Argument validation returns error codes before any launch (no GPU needed)."""
+    import ctypes
+
+    from quest_amd._lib import PagedKV, lib
+
+    empty = PagedKV()
+    assert lib.quest_append_kv_cache_decode(None, None, empty, empty, None) == -1
+    assert lib.quest_estimate_attn_score(None, None, 32, 10, empty, None) == -1
+    assert lib.quest_topk_filtering(None, None, None, None, None, 32, 10, 5, None) == -1
+    h = ctypes.c_void_p()
+    assert lib.quest_decode_handler_create(ctypes.byref(h), 7) == -1
+    assert lib.quest_decode_handler_create(ctypes.byref(h), 0) == 0
+    one = ctypes.c_void_p(16)
+    kv = PagedKV(data=16, indices=16, indptr=16, num_heads=32, page_size=16, head_dim=128, page_budget=4,
+                 last_page_len=1, last_page_idx=0, layout=0)
+    assert lib.quest_decode_forward(h, one, one, kv, 32, None, None) == -3  # forward before begin_forward
+    assert lib.quest_decode_begin_forward(h, 3, 32, 5, 128, 16, None) == -1   # heads not divisible
+    assert lib.quest_decode_begin_forward(h, 3, 32, 32, 100, 16, None) == -2  # unsupported head_dim
+    lib.quest_decode_handler_destroy(h)
+
+
+def test_kernels_shim_rejects_cpu_tensors_like_check_cuda():
+    from quest_amd import _kernels
+
+    q = torch.zeros(1, 4, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        _kernels.apply_rope_in_place(q, q, 0, 1.0, 1e4)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        _kernels.topk_filtering(torch.zeros(4, 8, dtype=torch.float16), torch.zeros(4, 8, dtype=torch.int32),
+                                torch.zeros(4, 2, dtype=torch.float16), torch.zeros(4, 2, dtype=torch.int32), None, 2)
+    names = ["apply_rope_in_place", "rms_norm_forward", "topk_filtering", "estimate_attn_score",
+             "append_kv_cache_prefill", "append_kv_cache_decode", "prefill_with_paged_kv_cache",
+             "BatchDecodeWithPagedKVCachePyTorchWrapper"]  # bsk_ops.cu:4-20
+    for n in names:
+        assert hasattr(_kernels, n)
+    w = _kernels.BatchDecodeWithPagedKVCachePyTorchWrapper(0)
+    for m in ("begin_forward", "end_forward", "forward"):
+        assert hasattr(w, m)
+    with pytest.raises(RuntimeError, match="dispatch with dtype"):
+        w.begin_forward(torch.tensor([0, 3], dtype=torch.int32), 32, 32, 128, 16, torch.empty(0, dtype=torch.bfloat16))
+
+
+def test_utils_surface_matches_reference():
+    import quest_amd.utils as qu
+
+    ref_all = ["TensorLayout", "KvCache", "InferenceController", "BatchDecodeWithPagedKVCacheWrapper", "append_kv",
+               "prefill_forward", "decode_estimate", "decode_topk", "decode_sparse_attn", "rms_norm_forward",
+               "apply_rope_in_place"]  # quest/utils/__init__.py:11-23
+    for n in ref_all:
+        assert hasattr(qu, n) and n in qu.__all__
+    assert qu.TensorLayout.NHD == 0 and qu.TensorLayout.HND == 1
+    with pytest.raises(KeyError):
+        qu.BatchDecodeWithPagedKVCacheWrapper("XYZ")
+
+
+def test_kv_cache_bookkeeping():
+    """append_seq / last_page_len / release follow kv_cache.py:104-132."""
+    from quest_amd.utils import KvCache
+
+    c = KvCache(2, 4, 128, 100, 16, torch.float16, "cpu")
+    assert c.pool.capacity == 7 and c.pool.block_len == 16 and c.pool.num_layers == 2
+    assert c.buf_layer(1).shape == (7, 2, 16, 4, 128)
+    assert c.append_seq(0) == 0
+    assert c.append_seq(17) == 2 and c.seqlen == 17 and c.last_page_len == 1 and len(c.indicies) == 2
+    assert c.append_seq(15) == 0 and c.last_page_len == 16
+    assert c.append_seq(1) == 1 and c.last_page_len == 1 and len(c.indicies) == 3
+    assert c.pool.num_free_blocks == 4
+    with pytest.raises(RuntimeError):
+        c.append_seq(16 * 5)
+    hnd = KvCache(1, 4, 128, 32, 16, torch.float16, "cpu", layout=1)
+    assert hnd.buf_layer(0).shape == (2, 2, 4, 16, 128)
+    c.release()
+    assert c.seqlen == 0 and c.indicies == [] and c.pool.num_free_blocks == 7
+    shuf = KvCache(1, 1, 64, 160, 16, torch.float16, "cpu", shuffle_seed=3)
+    shuf.append_seq(160)
+    assert sorted(shuf.indicies) == list(range(10)) and shuf.indicies != list(range(10))
+    assert shuf.device_table().tolist() == shuf.indicies
+
+
+def test_controller_budget_logic(monkeypatch):
+    """need_estimate / inference_page_budget / index tensors (controller.py:80-142), with the handler stubbed
+    (it needs the GPU only for its workspace)."""
+    import quest_amd.utils.controller as ctl_mod
+
+    class _Stub:
+        def __init__(self, kv_layout="NHD"):
+            self.calls = []
+
+        def begin_forward(self, indptr, hq, hkv, d, s, dt):
+            self.calls.append((indptr.tolist(), hq, hkv, d, s))
+
+        def end_forward(self):
+            self.calls.append("end")
+
+    monkeypatch.setattr(ctl_mod, "BatchDecodeWithPagedKVCacheWrapper", _Stub)
+    c = ctl_mod.InferenceController(2, 8, 128, 16, 4, 1000, torch.float16, "cpu", num_kv_heads=2)
+    assert c.page_budget_pages == 4 and c.token_budget == 64
+    assert c.kv_cache.buf_layer(0).shape[3] == 2  # pools hold kv heads
+    assert not c.need_estimate()
+    c.prepare_metadata(40)
+    c.begin_forward(40)
+    assert c.kv_indptr_for_append.tolist() == [0, 3] and c.metadata_indptr_for_append.tolist() == [0, 1]
+    assert c.kv_indices_with_last.tolist() == c.kv_cache.indicies
+    c.end_forward()
+    c.prepare_metadata(1)
+    c.begin_forward(1)
+    assert c.inference_page_budget == 3 and not c.need_estimate()  # 3 pages <= budget 4
+    assert c.kv_indices_without_last.shape == (8, 2)
+    assert c.kv_indptr_for_approx_decode.tolist() == [0, 2]
+    assert c._decode_handler.calls[-1] == ([0, 2], 8, 2, 128, 16)
+    c.end_forward()
+    c.prepare_metadata(60)
+    c.begin_forward(60)
+    c.end_forward()
+    c.prepare_metadata(1)
+    c.begin_forward(1)
+    n_pages = len(c.kv_cache.indicies)
+    assert n_pages == 7 and c.inference_page_budget == 4 and c.need_estimate()
+    assert c.topk_dindices_buffer.shape == (8, 3) and c.topk_dout_buffer.dtype == torch.float16
+    assert c.kv_indices_without_last.shape == (8, 6)
+    assert c.kv_last_page_idx == c.kv_cache.indicies[-1]
+    # layer-skip re-plan: a huge budget without touching index tensors (llama.py:428-439)
+    c.end_forward()
+    c.set_page_budget(1 << 20)
+    c.begin_forward(1, updateTensor=False)
+    assert c.inference_page_budget == 7 and not c.need_estimate()
+    c.clean_states()
+    assert c.kv_cache.seqlen == 0 and c.metadata_cache.seqlen == 0
+
+
+def test_quest_attention_module_api():
+    from types import SimpleNamespace
+
+    from quest_amd.models import QuestAttention
+
+    cfg = SimpleNamespace(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=4096,
+                          rope_scaling={"type": "linear", "factor": 8.0})
+    m = QuestAttention(cfg, layer_idx=3)
+    assert m.head_dim == 128 and m.rope_scale == 8.0 and m.layer_idx == 3
+    assert sorted(n for n, _ in m.named_parameters()) == ["k_proj.weight", "o_proj.weight", "q_proj.weight",
+                                                           "v_proj.weight"]
+    assert m.k_proj.weight.shape == (256, 512)
+    with pytest.raises(ValueError):
+        QuestAttention(SimpleNamespace(hidden_size=512, num_attention_heads=4, rope_scaling={"type": "yarn"}), 0)
