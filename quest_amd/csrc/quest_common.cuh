@@ -53,6 +53,53 @@ __device__ __forceinline__ float row_allreduce_sum(float x) {
     return x;
 }
 
+// ---- DPP cross-lane helpers (gfx9 encodings).  One VALU instruction each, no LDS crossbar trip.
+// masked-off / out-of-range lanes contribute `old` = 0.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, true);
+}
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, dpp_i<CTRL, ROW_MASK, BANK_MASK>(__builtin_bit_cast(int, x)));
+}
+constexpr int kDppRowShr = 0x110, kDppRowRor = 0x120, kDppHalfMirror = 0x141, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
+
+// Sum over the W lanes of a row, every lane gets the total.  Association order differs from
+// row_allreduce_sum (rotations instead of the xor butterfly): use where bit-exactness against the
+// oracle is not required (the attention kernel), not in the estimate.
+template <int W>
+__device__ __forceinline__ float row_allreduce_sum_fast(float x) {
+    static_assert(W == 8 || W == 16 || W == 32, "row width");
+    if constexpr (W == 8) {
+        x += dpp_f<kDppQuadXor1>(x);
+        x += dpp_f<kDppQuadXor2>(x);
+        x += dpp_f<kDppHalfMirror>(x);
+    } else {
+        x += dpp_f<kDppRowRor + 8>(x);
+        x += dpp_f<kDppRowRor + 4>(x);
+        x += dpp_f<kDppRowRor + 2>(x);
+        x += dpp_f<kDppRowRor + 1>(x);
+        if constexpr (W == 32) x += __shfl_xor(x, 16, kWave);
+    }
+    return x;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave in 7 DPP adds.
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t x) {
+    int v = (int)x;
+    const int s1 = dpp_i<kDppRowShr + 1>(v), s2 = dpp_i<kDppRowShr + 2>(v), s3 = dpp_i<kDppRowShr + 3>(v);
+    v += s1;
+    v += s2;
+    v += s3;
+    v += dpp_i<kDppRowShr + 4, 0xF, 0xE>(v);
+    v += dpp_i<kDppRowShr + 8, 0xF, 0xC>(v);
+    v += dpp_i<kDppBcast15, 0xA, 0xF>(v);
+    v += dpp_i<kDppBcast31, 0xC, 0xF>(v);
+    return (uint32_t)v;
+}
+
 __device__ __forceinline__ uint16_t half_bits(half_t h) { return __builtin_bit_cast(uint16_t, h); }
 __device__ __forceinline__ half_t bits_half(uint16_t b) { return __builtin_bit_cast(half_t, b); }
 

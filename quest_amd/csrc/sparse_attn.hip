@@ -19,6 +19,7 @@
 // The 16 lanes of a row reduce q.k with an xor butterfly; every row keeps its own online-softmax
 // state (m, d, acc[8]/lane), rows merge by shuffles, waves through LDS, chunks by a small second
 // kernel that also normalises and casts (VariableLengthMergeStates' job).
+#include <cstdlib>
 #include <new>
 
 #include "topk_select.cuh"
@@ -50,7 +51,19 @@ struct DecodeParams {
     uint32_t n_scores;
     uint16_t* sel_val_out;   // optional [Hq][n_sel]
     int32_t* sel_idx_out;    // optional [Hq][n_sel]
+    // in-kernel merge (fuse_merge): per-head arrival counters, zero between launches
+    uint32_t* counters;
+    uint32_t fuse_merge;
+    uint32_t ws_stride;  // floats per partial record (>= D + 2, multiple of 32 -> records own whole 128 B lines)
 };
+
+// Agent-scope (sc1) accessors for the in-kernel hand-off of partial states between workgroups.
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 constexpr int kFusedMaxPpc = 64;  // pages per workgroup the fused front end can stage in LDS
 
@@ -74,7 +87,7 @@ __device__ __forceinline__ void fold_groups(RowState<D>& st, const float8& qv, c
         float dot = 0.f;
 #pragma unroll
         for (int i = 0; i < kVec; ++i) dot = __builtin_fmaf(qv[i], kf[i], dot);
-        dot = row_allreduce_sum<LPR>(dot);
+        dot = row_allreduce_sum_fast<LPR>(dot);
         s[g] = row < rows_left[g] ? dot : kNegFloor;
         m_new = __builtin_fmaxf(m_new, s[g]);
     }
@@ -283,13 +296,91 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
         if (p.n_chunks == 1) {
             p.o[(size_t)hq * D + f] = (half_t)(acc / den);
             if (p.lse && f == 0) p.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
-        } else {
-            float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * (D + 2);
+        } else if (!p.fuse_merge) {
+            float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
             w[f] = acc;
             if (f == 0) {
                 w[D] = M;
                 w[D + 1] = den;
             }
+        } else {
+            // write-through (sc1) so the bytes are in memory, not in this XCD's L2, when the counter moves
+            float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
+            st_agent(w + f, acc);
+            if (f == 0) {
+                st_agent(w + D, M);
+                st_agent(w + D + 1, den);
+            }
+        }
+    }
+    if (p.n_chunks > 1 && p.fuse_merge) {
+        // Last-arriver merge.  Hand-off form (MI355X guide, inter-workgroup visibility, "valid forms"):
+        // every storing wave drains its sc1 stores (vmcnt(0)), workgroup barrier, ONE lane does an
+        // agent-scope atomic add; the workgroup whose add returns n_chunks-1 knows every partial of this
+        // head is in memory and reads them with sc1 loads (which bypass the CU's L1; no XCD L2 holds a
+        // copy because sc1 stores drop the line and nobody read the records earlier in this launch).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ uint32_t s_last;
+        if (threadIdx.x == 0) {
+            const uint32_t old = __hip_atomic_fetch_add(p.counters + hq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == p.n_chunks - 1;
+        }
+        __syncthreads();
+        if (s_last) {
+            const float* wh = p.ws + (size_t)hq * p.n_chunks * p.ws_stride;
+            constexpr int NT = kDecWaves * kWave;
+            constexpr int NG = NT / D > 0 ? NT / D : 1;  // thread groups splitting the chunk loop
+            const uint32_t tid = threadIdx.x;
+            const uint32_t ff = tid % D, g = tid / D;
+            constexpr int kPre = 8;
+            float pre[kPre];
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) {
+                const uint32_t c = g + j * NG, cc = c < p.n_chunks ? c : p.n_chunks - 1;
+                pre[j] = ld_agent(wh + (size_t)cc * p.ws_stride + ff);
+            }
+            __shared__ float s_w[1024];
+            float Mx = kNegFloor;
+            for (uint32_t c = tid; c < p.n_chunks; c += NT) Mx = __builtin_fmaxf(Mx, ld_agent(wh + (size_t)c * p.ws_stride + D));
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) Mx = __builtin_fmaxf(Mx, __shfl_xor(Mx, off, kWave));
+            if ((tid & 63) == 0) s_md[tid >> 6][0] = Mx;
+            __syncthreads();
+            Mx = s_md[0][0];
+#pragma unroll
+            for (int w2 = 1; w2 < kDecWaves; ++w2) Mx = __builtin_fmaxf(Mx, s_md[w2][0]);
+            float dn = 0.f;
+            for (uint32_t c = tid; c < p.n_chunks; c += NT) {
+                const float e = __builtin_amdgcn_exp2f(ld_agent(wh + (size_t)c * p.ws_stride + D) - Mx);
+                s_w[c] = e;
+                dn += e * ld_agent(wh + (size_t)c * p.ws_stride + D + 1);
+            }
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) dn += __shfl_xor(dn, off, kWave);
+            if ((tid & 63) == 0) s_md[tid >> 6][1] = dn;
+            __syncthreads();
+            float a = 0.f;
+            if (g < (uint32_t)NG) {
+#pragma unroll
+                for (int j = 0; j < kPre; ++j) {
+                    const uint32_t c = g + j * NG;
+                    if (c < p.n_chunks) a += s_w[c] * pre[j];
+                }
+                for (uint32_t c = g + kPre * NG; c < p.n_chunks; c += NG) a += s_w[c] * ld_agent(wh + (size_t)c * p.ws_stride + ff);
+                s_acc[g % kDecWaves][ff] = a;  // NG <= 4 == kDecWaves rows of s_acc
+            }
+            __syncthreads();
+            if (tid < (uint32_t)D) {
+                float tot = 0.f, dsum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) tot += s_acc[j][tid];
+#pragma unroll
+                for (int w2 = 0; w2 < kDecWaves; ++w2) dsum += s_md[w2][1];
+                p.o[(size_t)hq * D + tid] = (half_t)(tot / dsum);
+                if (p.lse && tid == 0) p.lse[hq] = (Mx + __builtin_amdgcn_logf(dsum)) * 0.6931471805599453f;
+            }
+            if (tid == 0) __hip_atomic_store(p.counters + hq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -302,13 +393,14 @@ constexpr int kMergeGroups = 4;
 template <int D>
 __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const float* __restrict__ ws,
                                                                         half_t* __restrict__ o,
-                                                                        float* __restrict__ lse, uint32_t n_chunks) {
+                                                                        float* __restrict__ lse, uint32_t n_chunks,
+                                                                        uint32_t ws_stride) {
     __shared__ float s_w[1024];  // per-chunk weight exp2(m_c - M); planner keeps n_chunks <= 1024
     __shared__ float s_red[kMergeGroups][D + 1];
     __shared__ float s_M;
     const uint32_t hq = blockIdx.x, tid = threadIdx.x;
     const uint32_t f = tid % D, g = tid / D;
-    const float* w = ws + (size_t)hq * n_chunks * (D + 2);
+    const float* w = ws + (size_t)hq * n_chunks * ws_stride;
     // the first kPre partial rows of this thread's chunks are requested up front so the whole merge is
     // one memory round trip for n_chunks <= kPre * kMergeGroups
     constexpr int kPre = 8;
@@ -316,11 +408,11 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
 #pragma unroll
     for (int j = 0; j < kPre; ++j) {
         const uint32_t c = g + j * kMergeGroups, cc = c < n_chunks ? c : n_chunks - 1;  // clamped: no branch
-        pre[j] = w[(size_t)cc * (D + 2) + f];
+        pre[j] = w[(size_t)cc * ws_stride + f];
     }
     // pass 1: chunk maxima -> M, weights, denominator
     float M = kNegFloor;
-    for (uint32_t c = tid; c < n_chunks; c += blockDim.x) M = __builtin_fmaxf(M, w[(size_t)c * (D + 2) + D]);
+    for (uint32_t c = tid; c < n_chunks; c += blockDim.x) M = __builtin_fmaxf(M, w[(size_t)c * ws_stride + D]);
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) M = __builtin_fmaxf(M, __shfl_xor(M, off, kWave));
     if ((tid & 63) == 0) s_red[0][tid >> 6] = M;
@@ -334,9 +426,9 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
     M = s_M;
     float den = 0.f;
     for (uint32_t c = tid; c < n_chunks; c += blockDim.x) {
-        const float e = __builtin_amdgcn_exp2f(w[(size_t)c * (D + 2) + D] - M);
+        const float e = __builtin_amdgcn_exp2f(w[(size_t)c * ws_stride + D] - M);
         s_w[c] = e;
-        den += e * w[(size_t)c * (D + 2) + D + 1];
+        den += e * w[(size_t)c * ws_stride + D + 1];
     }
     __syncthreads();
     // pass 2: weighted sum of the partial outputs
@@ -348,7 +440,7 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
     }
 #pragma unroll 8
     for (uint32_t c = g + kPre * kMergeGroups; c < n_chunks; c += kMergeGroups)
-        acc += s_w[c] * w[(size_t)c * (D + 2) + f];
+        acc += s_w[c] * w[(size_t)c * ws_stride + f];
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) den += __shfl_xor(den, off, kWave);
     s_red[g][f] = acc;
@@ -378,7 +470,16 @@ struct quest_decode_handler {
     uint32_t forced_ppc = 0;
     float* ws = nullptr;
     size_t ws_bytes = 0;
+    uint32_t* counters = nullptr;  // [num_qo_heads] arrival counters of the in-kernel merge
+    uint32_t counters_len = 0;
+    uint32_t ws_stride = 0;
+    bool fuse_merge = false;
 };
+
+static bool env_flag_on(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] == '1';
+}
 
 // Workgroups the planner aims for: the kernel is built for 2 workgroups (8 waves) per CU, so 512
 // workgroups are one fully resident round on 256 CUs, each wave with 16 x 1 KiB loads in flight.
@@ -390,6 +491,11 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
     quest_decode_handler* h = new (std::nothrow) quest_decode_handler();
     if (!h) return (int)hipErrorOutOfMemory;
     h->layout = layout;
+    // QUEST_FUSE_MERGE=1: merge chunk states inside the attention kernel (last-arriving workgroup, sc1
+    // hand-off) instead of the merge kernel.  Measured on MI355X at cfg 3: 13.64 vs 13.58 us per op --
+    // the cross-CU hand-off (write-through + atomic + re-read) costs what the extra launch costs, so the
+    // simpler two-kernel form is the default.
+    h->fuse_merge = env_flag_on("QUEST_FUSE_MERGE");
     *out = h;
     return 0;
 }
@@ -397,6 +503,7 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
 extern "C" void quest_decode_handler_destroy(quest_decode_handler_t* h) {
     if (!h) return;
     if (h->ws) (void)hipFree(h->ws);
+    if (h->counters) (void)hipFree(h->counters);
     delete h;
 }
 
@@ -431,7 +538,18 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     if ((n_slots + ppc - 1) / ppc > kMaxChunks) ppc = (n_slots + kMaxChunks - 1) / kMaxChunks;
     h->pages_per_chunk = ppc;
     h->n_chunks = (n_slots + ppc - 1) / ppc;
-    const size_t need = (size_t)num_qo_heads * h->n_chunks * (head_dim + 2) * sizeof(float);
+    h->ws_stride = (head_dim + 2 + 31) / 32 * 32;
+    const size_t need = (size_t)num_qo_heads * h->n_chunks * h->ws_stride * sizeof(float);
+    if (h->counters_len < num_qo_heads) {
+        if (h->counters) (void)hipFree(h->counters);
+        h->counters = nullptr;
+        h->counters_len = 0;
+        hipError_t e = hipMalloc((void**)&h->counters, num_qo_heads * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+        e = hipMemset(h->counters, 0, num_qo_heads * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+        h->counters_len = num_qo_heads;
+    }
     if (h->n_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
         if (h->ws) (void)hipFree(h->ws);
         h->ws = nullptr;
@@ -466,9 +584,9 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     else
         hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC>), grid, block, 0, s, p);
     QUEST_LAUNCH_CHECK();
-    if (h->n_chunks > 1) {
+    if (h->n_chunks > 1 && !p.fuse_merge) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D * kMergeGroups), 0, s,
-                           (const float*)p.ws, p.o, p.lse, h->n_chunks);
+                           (const float*)p.ws, p.o, p.lse, h->n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
     }
     return 0;
@@ -527,6 +645,9 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, const
     p.n_scores = n_scores;
     p.sel_val_out = (uint16_t*)topk_val_out;
     p.sel_idx_out = topk_idx_out;
+    p.counters = h->counters;
+    p.fuse_merge = h->fuse_merge ? 1u : 0u;
+    p.ws_stride = h->ws_stride;
     // fc < 0: single-wave selection with -fc columns per lane (rows <= 4096); fc > 0: block selection
     int fc = 0;
     if (fused) {

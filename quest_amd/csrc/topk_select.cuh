@@ -30,11 +30,7 @@ struct TopkSmem {
 template <int NT>
 __device__ __forceinline__ uint32_t block_scan_incl(uint32_t x, uint32_t* wave_tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t y = __shfl_up(x, off, kWave);
-        if (lane >= off) x += y;
-    }
+    x = wave_scan_incl_dpp(x);
     if (lane == kWave - 1) wave_tot[wave] = x;
     __syncthreads();
     uint32_t base = 0;
@@ -93,12 +89,7 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
     if (tid < kWave) {  // wave 0: lane l looks at low digit 31-l, suffix sums by shuffle
         const uint32_t above0 = sm.misc[1];
         const uint32_t cnt = tid < kBins2 ? sm.hist2[kBins2 - 1 - tid] : 0u;
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int off = 1; off < kBins2; off <<= 1) {
-            const uint32_t y = __shfl_up(incl, off, kWave);
-            if (tid >= (uint32_t)off) incl += y;
-        }
+        const uint32_t incl = wave_scan_incl_dpp(cnt);
         const uint32_t excl = incl - cnt;
         if (tid < kBins2 && above0 + excl < k && k <= above0 + incl) {
             sm.misc[2] = (thr_bin << kLowBits) | (kBins2 - 1 - tid);
@@ -160,12 +151,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, int lane) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t y = __shfl_up(x, off, kWave);
-        if (lane >= off) x += y;
-    }
-    return x;
+    (void)lane;
+    return wave_scan_incl_dpp(x);
 }
 
 struct TopkWaveResult {

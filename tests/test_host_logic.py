@@ -169,3 +169,45 @@ def test_quest_attention_module_api():
     assert m.k_proj.weight.shape == (256, 512)
     with pytest.raises(ValueError):
         QuestAttention(SimpleNamespace(hidden_size=512, num_attention_heads=4, rope_scaling={"type": "yarn"}), 0)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/quest"), reason="reference tree only exists in the build container")
+def test_reference_python_stack_runs_on_our_kernels_module():
+    """INTEGRATION.md route A: register quest_amd._kernels as `quest._kernels`; the reference's own
+    quest.utils (controller, kv cache, wrappers) must import and drive our handler unchanged."""
+    import importlib
+    import sys
+
+    import quest_amd._kernels as ours
+
+    saved = {k: v for k, v in sys.modules.items() if k == "quest" or k.startswith("quest.")}
+    sys.path.insert(0, "/root/reference")
+    sys.dont_write_bytecode = True
+    try:
+        sys.modules["quest._kernels"] = ours
+        qutils = importlib.import_module("quest.utils")
+        assert qutils._kernels is ours
+        ctl = qutils.InferenceController(2, 32, 128, 16, 8, 1024, torch.float16, torch.device("cpu"))
+        ctl.prepare_metadata(300)
+        ctl.begin_forward(300)
+        ctl.end_forward()
+        ctl.prepare_metadata(1)
+        # builds the reference's index tensors and calls OUR begin_forward with the reference's arguments;
+        # without a GPU the call gets as far as the workspace hipMalloc inside libquest_hip.so
+        if torch.cuda.is_available():
+            ctl.begin_forward(1)
+            assert ctl._decode_handler._wrapper.plan_info()[0] >= 1
+            ctl.end_forward()
+        else:
+            with pytest.raises(RuntimeError, match="BatchDecodeWithPagedKVCache failed with error code 100"):
+                ctl.begin_forward(1)
+        assert ctl.need_estimate() and ctl.inference_page_budget == 8
+        # the op wrappers reach our validation (CPU tensors are rejected exactly like CHECK_CUDA)
+        q = torch.zeros(1, 32, 128, dtype=torch.float16)
+        with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+            qutils.decode_estimate(q, ctl, 0)
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k == "quest" or k.startswith("quest.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
