@@ -131,7 +131,7 @@ def bytes_per_layer(a):
     est = N * Hkv * 2 * D * 2 + Hq * D * 2 + 4 * ((N + S - 1) // S) + Hq * (N - 1) * 2
     topk = Hq * (N - 1) * (2 + 4) + Hq * (B - 1) * (2 + 4)
     att = B * S * 2 * Hq * D * 2 + Hq * D * 2 + Hq * (B - 1) * 4 + Hq * D * 2
-    dense = N * S * 2 * Hq * D * 2 + Hq * D * 2 + Hq * (N - 1) * 4 + Hq * D * 2
+    dense = N * S * 2 * Hkv * D * 2 + Hq * D * 2 + Hq * (N - 1) * 4 + Hq * D * 2  # every kv head read once
     return {"append": app, "estimate": est, "topk": topk, "attn": att, "chain": app + est + topk + att, "dense": dense}
 
 

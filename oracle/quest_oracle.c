@@ -229,11 +229,42 @@ void qo_append_prefill(const qo_paged_t* kv, const qo_paged_t* meta, const qo_ha
  * out[qo_head][e] for e in [0, chunk_len), chunk_len = (n_meta_pages-1)*S +
  * meta.last_page_len - 1 (:266-272: the current KV page is excluded).
  *
- * Summation order is the kernel's: vec_size = 8 consecutive features per lane
- * accumulated left to right in fp32 from 0.f (:152-156), then a 16-lane xor
- * butterfly with offsets bdx/2 .. 1 (:157-160), then one fp32->fp16 cast
- * (:164).  bdx = head_dim / 8 (decode_attn.cuh:1108-1110 with fp16).
+ * Summation: vec_size = 8 consecutive features per lane accumulated left to
+ * right in fp32 from 0.f (as the reference kernel, :152-156; bdx = head_dim / 8
+ * lanes per row, decode_attn.cuh:1108-1110 with fp16).  The cross-lane step is
+ * THIS BUILD's, chosen for CDNA4's DPP unit, and the HIP kernel implements the
+ * same tree (quest_common.cuh row_allreduce_sum_fast), so HIP == oracle bit for
+ * bit: within each 16-lane row, four rotation steps lane[i] += lane[(i-n) mod 16]
+ * for n = 8, 4, 2, 1 (all lanes updated simultaneously); 32-lane rows (D=256) add
+ * lane[i ^ 16] last; 8-lane rows (D=64) use xor 1, xor 2, then the mirror 7-i.
+ * The result is lane 0's value, cast once to fp16 (RNE).  The reference kernel
+ * uses an xor butterfly instead (:157-160); either order is far inside its own
+ * tolerance (5e-3; measured <= 4 fp16 ulp against the reference's torch oracle).
  * fp16 x fp16 products are exact in fp32, so no FMA-contraction ambiguity. */
+static void qo_row_reduce(float* lane, uint32_t w) {
+    float nxt[32];
+    if (w == 8) {
+        for (uint32_t off = 1; off <= 2; off <<= 1) {
+            for (uint32_t i = 0; i < 8; ++i) nxt[i] = lane[i] + lane[i ^ off];
+            memcpy(lane, nxt, sizeof(float) * 8);
+        }
+        for (uint32_t i = 0; i < 8; ++i) nxt[i] = lane[i] + lane[7 - i];
+        memcpy(lane, nxt, sizeof(float) * 8);
+        return;
+    }
+    for (uint32_t n = 8; n >= 1; n >>= 1) {
+        for (uint32_t i = 0; i < w; ++i) {
+            uint32_t base = i & ~15u, l = i & 15u;
+            nxt[i] = lane[i] + lane[base + ((l + 16u - n) & 15u)];
+        }
+        memcpy(lane, nxt, sizeof(float) * w);
+    }
+    if (w == 32) {
+        for (uint32_t i = 0; i < 32; ++i) nxt[i] = lane[i] + lane[i ^ 16u];
+        memcpy(lane, nxt, sizeof(float) * 32);
+    }
+}
+
 void qo_estimate(const qo_half* q, const qo_paged_t* meta, uint32_t num_qo_heads, qo_half* out) {
     uint32_t S = meta->page_size, Hkv = meta->num_heads, D = meta->head_dim;
     uint32_t group = num_qo_heads / Hkv; /* qo_head = kv_head*bdy + ty, :256 */
@@ -260,11 +291,7 @@ void qo_estimate(const qo_half* q, const qo_paged_t* meta, uint32_t num_qo_heads
                 }
                 lane[tx] = acc;
             }
-            for (uint32_t off = bdx / 2; off > 0; off /= 2) {
-                float nxt[32];
-                for (uint32_t tx = 0; tx < bdx; ++tx) nxt[tx] = lane[tx] + lane[tx ^ off];
-                memcpy(lane, nxt, sizeof(float) * bdx);
-            }
+            qo_row_reduce(lane, bdx);
             out[(size_t)hq * chunk_len + e] = qo_f2h(lane[0]);
         }
     }

@@ -8,9 +8,12 @@
 // (2 entries x 32 heads at cfg 3 -> 1024 workgroups), each streaming 2 x 16 KiB contiguous
 // with all of its loads in flight at once (8 x 16 B per lane), no LDS.
 //
-// Bit-exactness: per lane 8 consecutive features are accumulated left to right in fp32, rows
-// are reduced with the xor butterfly (offsets LPR/2..1), one fp32->fp16 RNE cast -- the
-// reference kernel's order, which the oracle (qo_estimate) restates.  Bound: HBM.
+// Bit-exactness: per lane 8 consecutive features are accumulated left to right in fp32 (as the
+// reference kernel does, decode_attn.cuh:152-156); the 16 lanes of a row are then reduced with the
+// DPP rotation tree of row_allreduce_sum_fast (row_ror 8,4,2,1 -- one VALU op per step instead of an
+// LDS-crossbar ds_bpermute round trip per step of the reference's xor butterfly, which cost 0.6 us at
+// MHA and 2.3 us at GQA-4 here), lane 0's value is cast once to fp16 (RNE).  The oracle (qo_estimate)
+// restates exactly this tree, so HIP == oracle bit for bit.  Bound: HBM.
 #include "append_device.cuh"
 
 namespace quest {
@@ -49,9 +52,12 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
     const uint32_t row0 = (blockIdx.x * 4 + wave) * (kEstIter * R) + row;
 
     half8 mx[kEstIter], mn[kEstIter];
-    // MHA: q is requested together with the metadata (one extra 16 B load per row).  GQA: G vectors per
-    // row would cost 8*G VGPRs per row, so they are read (L1/L2-resident, 8 KiB total) when consumed.
+    // MHA: q is requested together with the metadata (one extra 16 B load per row).  GQA: a row needs the
+    // G query vectors of its kv head; all Hq vectors (8 KiB for 32 x 128) are staged in LDS once per
+    // workgroup -- issued after the metadata loads so both are in flight together -- and read per (row, g).
     constexpr int QPRE = (G == 1) ? 1 : 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char est_smem[];
+    half_t* q_s = reinterpret_cast<half_t*>(est_smem);
     float8 qv[kEstIter][QPRE ? 1 : 1];
     uint32_t ent[kEstIter], head[kEstIter];
     bool ok[kEstIter];
@@ -80,6 +86,11 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
         mn[j] = ld8(p + ms.v_off);
         if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)hk * D + col * kVec));
     }
+    if (!QPRE) {
+        const uint32_t total = Hkv * G * D;
+        for (uint32_t i = threadIdx.x * kVec; i < total; i += 256 * kVec) st8(q_s + i, ld8(q + i));
+        __syncthreads();
+    }
 
 #pragma unroll
     for (int j = 0; j < kEstIter; ++j) {
@@ -88,11 +99,11 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
         for (int g = 0; g < G; ++g) {
             float8 qg;
             if (QPRE) qg = qv[j][0];
-            else qg = to_f32(ld8(q + ((size_t)head[j] * G + g) * D + col * kVec));
+            else qg = to_f32(ld8(q_s + ((size_t)head[j] * G + g) * D + col * kVec));
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < kVec; ++i) acc += __builtin_fmaxf(qg[i] * a[i], qg[i] * b[i]);
-            acc = row_allreduce_sum<LPR>(acc);
+            acc = row_allreduce_sum_fast<LPR>(acc);
             if (ok[j] && col == 0) o[((size_t)head[j] * G + g) * n_out + ent[j]] = (half_t)acc;
         }
     }
@@ -111,10 +122,12 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + 255) / 256;
     if (blocks == 0) return 0;
     dim3 grid(blocks);
+    const size_t lds = G == 1 ? 0 : (size_t)meta.num_heads * G * D * sizeof(half_t);  // staged q (GQA only)
+    if (lds > 64 * 1024) return QUEST_EUNSUPPORTED;
     if (hnd)
-        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(256), 0, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
+        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(256), lds, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
     else
-        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(256), 0, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
+        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(256), lds, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
     QUEST_LAUNCH_CHECK();
     return 0;
 }
