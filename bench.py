@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--unfused", action="store_true",
                     help="issue the reference's five launches per layer instead of the fused append+estimate and "
                          "top-k+attention launches (same results)")
+    ap.add_argument("--seqs-per-gpu", type=int, default=1,
+                    help="independent sequences per GPU (BASELINE configs[4] uses 8); each runs its chain on its "
+                         "own HIP stream inside the step graph so their latency phases overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--cpu-sample-s", type=float, default=12.0)
@@ -60,7 +63,7 @@ def parse():
 class Workload:
     """One sequence: controller + filled pools + per-layer decode inputs."""
 
-    def __init__(self, a, dev):
+    def __init__(self, a, dev, seq_id=0):
         import quest_amd.utils as qu
 
         self.qu = qu
@@ -71,7 +74,7 @@ class Workload:
         self.ctl = qu.InferenceController(a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
                                           L + 2 * a.page_size, torch.float16, dev, num_kv_heads=a.kv_heads,
                                           layout=a.layout, shuffle_seed=1234)
-        g = torch.Generator(device=dev).manual_seed(1000 + dev.index)
+        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id)
         ctl = self.ctl
         # prefill L-1 tokens (device-side append with fused min/max metadata), then one decode token
         ctl.prepare_metadata(L - 1)
@@ -210,25 +213,40 @@ def main():
 
     from quest_amd.parallel import gather_tokens
 
-    w = Workload(a, dev)
+    ws = [Workload(a, dev, i) for i in range(a.seqs_per_gpu)]
+    w = ws[0]
+    streams = [torch.cuda.Stream() for _ in ws] if len(ws) > 1 else None
     torch.cuda.synchronize()
+
+    def step_all():
+        """One decode token for every local sequence; sequences are independent, so with more than one
+        each chain goes to its own stream (fork/join around the step)."""
+        if streams is None:
+            return w.step()
+        cur = torch.cuda.current_stream()
+        for st, wl in zip(streams, ws):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                wl.step()
+        for st in streams:
+            cur.wait_stream(st)
 
     # ---- the step, eager or captured
     if a.mode == "graph":
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            w.step()  # warm the allocator / plan before capture
+            step_all()  # warm the allocator / plan before capture
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            w.step()
+            step_all()
         run = graph.replay
     else:
-        run = w.step
+        run = step_all
 
-    tok = torch.zeros(1, dtype=torch.int64, device=dev)  # stand-in for the sampled token id of this rank's sequence
+    tok = torch.zeros(len(ws), dtype=torch.int64, device=dev)  # stand-in for the sampled token ids of the local sequences
 
     def one_step():
         run()
@@ -255,7 +273,7 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed * 1e3 / a.steps
-    value = world * a.steps / elapsed  # one sequence per GPU, one token per step
+    value = world * len(ws) * a.steps / elapsed  # one token per local sequence per step
 
     out = None
     if rank == 0:
@@ -279,7 +297,7 @@ def main():
         ctl.end_forward()
         ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_plus_merge_us": t_att,
                "fused_append_estimate_us": t_ae, "fused_topk_sparse_attn_plus_merge_us": t_ts,
-               "chain_us_in_step": ms_per_step * 1e3 / a.layers,
+               "chain_us_in_step": ms_per_step * 1e3 / a.layers / len(ws),
                "note": "per launch inside a hipGraph of 32 back-to-back launches (one per layer), "
                        "dependent-launch boundary included"}
         dense_us = None
@@ -310,21 +328,21 @@ def main():
                        "kv_layout": a.layout, "mode": a.mode, "skip_layers": a.skip_layers,
                        "launches_per_layer": "5 (reference op sequence)" if a.unfused else
                        "3 (append+estimate | top-k+sparse attn | merge)",
-                       "sequences_per_gpu": 1, "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
+                       "sequences_per_gpu": len(ws), "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
             "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel + merge_states_kernel (one decode_sparse_attn op)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att,
                          "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}},
             "ops_us": ops,
-            "selfattn_us_per_layer": ms_per_step * 1e3 / a.layers,
+            "selfattn_us_per_layer": ms_per_step * 1e3 / a.layers / len(ws),
             "chain_bytes_per_layer": bpl["chain"],
-            "chain_frac_of_hbm_peak": bpl["chain"] / (ms_per_step * 1e-3 / a.layers) / 1e9 / HBM_PEAK_GBS,
+            "chain_frac_of_hbm_peak": bpl["chain"] * len(ws) / (ms_per_step * 1e-3 / a.layers) / 1e9 / HBM_PEAK_GBS,
         }
         if dense_us is not None:
             out["dense_full_kv_us"] = dense_us
             out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
-            out["speedup_vs_dense"] = dense_us / (ms_per_step * 1e3 / a.layers)
+            out["speedup_vs_dense"] = dense_us / (ms_per_step * 1e3 / a.layers / len(ws))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, a.cpu_sample_s)
         else:
