@@ -119,7 +119,7 @@ class Workload:
                 o = qu.decode_sparse_attn(q, ctl, layer, ctl.topk_dindices_buffer)
             else:
                 est = qu.decode_append_estimate(q, self.k1[layer], self.v1[layer], ctl, layer)
-                o = qu.decode_topk_sparse_attn(q, est, ctl, layer)
+                o = qu.decode_topk_sparse_attn(q, est, ctl, layer, write_topk=False)
             self.outs[layer] = o
         ctl.end_forward()
         return o

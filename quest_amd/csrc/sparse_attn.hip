@@ -26,7 +26,7 @@
 
 namespace quest {
 
-constexpr int kDecWaves = 4;
+constexpr int kDecWaves = 4;  // default waves per workgroup (NW template parameter)
 constexpr float kNegFloor = -1.0e30f;  // finite "-inf": exp2(floor - floor) stays finite, weights it carries are 0
 
 struct DecodeParams {
@@ -51,19 +51,8 @@ struct DecodeParams {
     uint32_t n_scores;
     uint16_t* sel_val_out;   // optional [Hq][n_sel]
     int32_t* sel_idx_out;    // optional [Hq][n_sel]
-    // in-kernel merge (fuse_merge): per-head arrival counters, zero between launches
-    uint32_t* counters;
-    uint32_t fuse_merge;
     uint32_t ws_stride;  // floats per partial record (>= D + 2, multiple of 32 -> records own whole 128 B lines)
 };
-
-// Agent-scope (sc1) accessors for the in-kernel hand-off of partial states between workgroups.
-__device__ __forceinline__ void st_agent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 constexpr int kFusedMaxPpc = 64;  // pages per workgroup the fused front end can stage in LDS
 
@@ -119,10 +108,11 @@ __device__ __forceinline__ void fold_groups(RowState<D>& st, const float8& qv, c
 // kernel, hence the same pages), and the columns whose output slot falls in this workgroup's chunk
 // drop their physical page id into LDS.  All workgroups of a head repeat the (cheap, L2-resident)
 // selection instead of waiting for one another.
-template <int D, int S_T, int FC>
-__global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(DecodeParams p) {
+template <int D, int S_T, int FC, int NW>
+__global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(DecodeParams p) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave index as an SGPR so per-wave control flow below is scalar branching
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hq = blockIdx.y, hk = hq / p.group;
     const uint32_t n_slots = p.n_sel + 1;  // selected pages + the current page
@@ -171,7 +161,7 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
         __syncthreads();
     }
     if constexpr (FC > 0) {
-        __shared__ TopkSmem<kDecWaves * kWave> sm;
+        __shared__ TopkSmem<NW * kWave> sm;
         constexpr bool PRE = FC <= 16;  // page ids of the owned columns fetched with the scores
         const uint32_t n = p.n_scores, c0 = threadIdx.x * FC;
         const uint16_t* srow = p.scores + (size_t)hq * n;
@@ -184,18 +174,29 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
             key[i] = half_key(srow[cc]);
             if (PRE) pid[i] = table[cc];
         }
-        TopkCursor cur = topk_select<kDecWaves * kWave, FC>(sm, key, n, p.n_sel);
+        topk_clear<NW * kWave>(sm);  // overlaps the score / page-id loads above
+        __syncthreads();
+        TopkCursor cur = topk_select<NW * kWave, FC>(sm, key, n, p.n_sel);
+        uint32_t my_slot[FC];
+        bool mine[FC];
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             uint32_t slot;
-            if (topk_take(cur, key[i], c0 + i < n, slot) && slot >= slot_begin && slot < slot_end) {
-                const int32_t pg = PRE ? pid[i] : table[c0 + i];
-                s_sel[slot - slot_begin] = pg;
-                if (p.sel_idx_out) p.sel_idx_out[(size_t)hq * p.n_sel + slot] = pg;
-                if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + slot] = key_to_half_bits(key[i]);
-            }
+            mine[i] = topk_take(cur, key[i], c0 + i < n, slot) && slot >= slot_begin && slot < slot_end;
+            my_slot[i] = slot;
+            if (mine[i]) s_sel[slot - slot_begin] = PRE ? pid[i] : table[c0 + i];
         }
         __syncthreads();
+        // optional copy of the selection for callers that inspect it: issued after the barrier so no
+        // workgroup waits on these stores before it starts fetching K/V
+        if (p.sel_idx_out) {
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+                if (mine[i]) {
+                    p.sel_idx_out[(size_t)hq * p.n_sel + my_slot[i]] = s_sel[my_slot[i] - slot_begin];
+                    if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + my_slot[i]] = key_to_half_bits(key[i]);
+                }
+        }
     }
     // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
     auto slot_page = [&](uint32_t slot) -> int32_t {
@@ -207,13 +208,11 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
     if constexpr (S_T > 0) {
         constexpr int T = (S_T + R - 1) / R;  // load instructions per page per tensor
         const uint32_t step = R * p.st.entry;
-        for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += 2 * kDecWaves) {
-            const uint32_t s1 = s0 + kDecWaves;
+        for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += 2 * NW) {
+            const uint32_t s1 = s0 + NW;
             const bool has1 = s1 < slot_end;
-            int32_t pg0 = slot_page(s0);
-            int32_t pg1 = has1 ? slot_page(s1) : pg0;
-            pg0 = __builtin_amdgcn_readfirstlane(pg0);
-            pg1 = __builtin_amdgcn_readfirstlane(pg1);
+            const int32_t pg0 = __builtin_amdgcn_readfirstlane(slot_page(s0));
+            const int32_t pg1 = __builtin_amdgcn_readfirstlane(has1 ? slot_page(s1) : pg0);
             const int len0 = s0 < p.n_sel ? S_T : (int)p.last_page_len;
             const int len1 = has1 ? (s1 < p.n_sel ? S_T : (int)p.last_page_len) : 0;
             const half_t* b0 = head_base + (size_t)pg0 * p.st.page;
@@ -229,16 +228,28 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
                 k[t] = ld8(b0 + lane_off + t * step);
                 v[t] = ld8(b0 + lane_off + t * step + p.st.v_off);
             }
+            if (has1) {  // wave-uniform
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                k[T + t] = ld8(b1 + lane_off + t * step);
-                v[T + t] = ld8(b1 + lane_off + t * step + p.st.v_off);
+                for (int t = 0; t < T; ++t) {
+                    k[T + t] = ld8(b1 + lane_off + t * step);
+                    v[T + t] = ld8(b1 + lane_off + t * step + p.st.v_off);
+                }
+                fold_groups<D, 2 * T>(st, qv, k, v, left, row);
+            } else {
+                half8 k0[T], v0[T];
+                int left0[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    k0[t] = k[t];
+                    v0[t] = v[t];
+                    left0[t] = left[t];
+                }
+                fold_groups<D, T>(st, qv, k0, v0, left0, row);
             }
-            fold_groups<D, 2 * T>(st, qv, k, v, left, row);
         }
     } else {
         const uint32_t S = p.page_size;
-        for (uint32_t slot = slot_begin + wave; slot < slot_end; slot += kDecWaves) {
+        for (uint32_t slot = slot_begin + wave; slot < slot_end; slot += NW) {
             const bool sel = slot < p.n_sel;
             const int32_t pg = __builtin_amdgcn_readfirstlane(slot_page(slot));
             const int len = sel ? (int)S : (int)p.last_page_len;
@@ -270,8 +281,8 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
     }
 
     // waves -> workgroup through LDS
-    __shared__ float s_acc[kDecWaves][D];
-    __shared__ float s_md[kDecWaves][2];
+    __shared__ float s_acc[NW][D];
+    __shared__ float s_md[NW][2];
     if (row == 0) {
 #pragma unroll
         for (int i = 0; i < kVec; ++i) s_acc[wave][col * kVec + i] = st.acc[i];
@@ -285,10 +296,10 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
     if (f < D) {
         float M = s_md[0][0];
 #pragma unroll
-        for (int w = 1; w < kDecWaves; ++w) M = __builtin_fmaxf(M, s_md[w][0]);
+        for (int w = 1; w < NW; ++w) M = __builtin_fmaxf(M, s_md[w][0]);
         float acc = 0.f, den = 0.f;
 #pragma unroll
-        for (int w = 0; w < kDecWaves; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float e = __builtin_amdgcn_exp2f(s_md[w][0] - M);
             acc += e * s_acc[w][f];
             den += e * s_md[w][1];
@@ -296,91 +307,13 @@ __global__ __launch_bounds__(kDecWaves* kWave, 2) void sparse_decode_kernel(Deco
         if (p.n_chunks == 1) {
             p.o[(size_t)hq * D + f] = (half_t)(acc / den);
             if (p.lse && f == 0) p.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
-        } else if (!p.fuse_merge) {
+        } else {
             float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
             w[f] = acc;
             if (f == 0) {
                 w[D] = M;
                 w[D + 1] = den;
             }
-        } else {
-            // write-through (sc1) so the bytes are in memory, not in this XCD's L2, when the counter moves
-            float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
-            st_agent(w + f, acc);
-            if (f == 0) {
-                st_agent(w + D, M);
-                st_agent(w + D + 1, den);
-            }
-        }
-    }
-    if (p.n_chunks > 1 && p.fuse_merge) {
-        // Last-arriver merge.  Hand-off form (MI355X guide, inter-workgroup visibility, "valid forms"):
-        // every storing wave drains its sc1 stores (vmcnt(0)), workgroup barrier, ONE lane does an
-        // agent-scope atomic add; the workgroup whose add returns n_chunks-1 knows every partial of this
-        // head is in memory and reads them with sc1 loads (which bypass the CU's L1; no XCD L2 holds a
-        // copy because sc1 stores drop the line and nobody read the records earlier in this launch).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __shared__ uint32_t s_last;
-        if (threadIdx.x == 0) {
-            const uint32_t old = __hip_atomic_fetch_add(p.counters + hq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == p.n_chunks - 1;
-        }
-        __syncthreads();
-        if (s_last) {
-            const float* wh = p.ws + (size_t)hq * p.n_chunks * p.ws_stride;
-            constexpr int NT = kDecWaves * kWave;
-            constexpr int NG = NT / D > 0 ? NT / D : 1;  // thread groups splitting the chunk loop
-            const uint32_t tid = threadIdx.x;
-            const uint32_t ff = tid % D, g = tid / D;
-            constexpr int kPre = 8;
-            float pre[kPre];
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) {
-                const uint32_t c = g + j * NG, cc = c < p.n_chunks ? c : p.n_chunks - 1;
-                pre[j] = ld_agent(wh + (size_t)cc * p.ws_stride + ff);
-            }
-            __shared__ float s_w[1024];
-            float Mx = kNegFloor;
-            for (uint32_t c = tid; c < p.n_chunks; c += NT) Mx = __builtin_fmaxf(Mx, ld_agent(wh + (size_t)c * p.ws_stride + D));
-#pragma unroll
-            for (int off = kWave / 2; off > 0; off >>= 1) Mx = __builtin_fmaxf(Mx, __shfl_xor(Mx, off, kWave));
-            if ((tid & 63) == 0) s_md[tid >> 6][0] = Mx;
-            __syncthreads();
-            Mx = s_md[0][0];
-#pragma unroll
-            for (int w2 = 1; w2 < kDecWaves; ++w2) Mx = __builtin_fmaxf(Mx, s_md[w2][0]);
-            float dn = 0.f;
-            for (uint32_t c = tid; c < p.n_chunks; c += NT) {
-                const float e = __builtin_amdgcn_exp2f(ld_agent(wh + (size_t)c * p.ws_stride + D) - Mx);
-                s_w[c] = e;
-                dn += e * ld_agent(wh + (size_t)c * p.ws_stride + D + 1);
-            }
-#pragma unroll
-            for (int off = kWave / 2; off > 0; off >>= 1) dn += __shfl_xor(dn, off, kWave);
-            if ((tid & 63) == 0) s_md[tid >> 6][1] = dn;
-            __syncthreads();
-            float a = 0.f;
-            if (g < (uint32_t)NG) {
-#pragma unroll
-                for (int j = 0; j < kPre; ++j) {
-                    const uint32_t c = g + j * NG;
-                    if (c < p.n_chunks) a += s_w[c] * pre[j];
-                }
-                for (uint32_t c = g + kPre * NG; c < p.n_chunks; c += NG) a += s_w[c] * ld_agent(wh + (size_t)c * p.ws_stride + ff);
-                s_acc[g % kDecWaves][ff] = a;  // NG <= 4 == kDecWaves rows of s_acc
-            }
-            __syncthreads();
-            if (tid < (uint32_t)D) {
-                float tot = 0.f, dsum = 0.f;
-#pragma unroll
-                for (int j = 0; j < NG; ++j) tot += s_acc[j][tid];
-#pragma unroll
-                for (int w2 = 0; w2 < kDecWaves; ++w2) dsum += s_md[w2][1];
-                p.o[(size_t)hq * D + tid] = (half_t)(tot / dsum);
-                if (p.lse && tid == 0) p.lse[hq] = (Mx + __builtin_amdgcn_logf(dsum)) * 0.6931471805599453f;
-            }
-            if (tid == 0) __hip_atomic_store(p.counters + hq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -470,16 +403,9 @@ struct quest_decode_handler {
     uint32_t forced_ppc = 0;
     float* ws = nullptr;
     size_t ws_bytes = 0;
-    uint32_t* counters = nullptr;  // [num_qo_heads] arrival counters of the in-kernel merge
-    uint32_t counters_len = 0;
     uint32_t ws_stride = 0;
-    bool fuse_merge = false;
+    uint32_t dec_waves = 4;
 };
-
-static bool env_flag_on(const char* name) {
-    const char* v = getenv(name);
-    return v && v[0] == '1';
-}
 
 // Workgroups the planner aims for: the kernel is built for 2 workgroups (8 waves) per CU, so 512
 // workgroups are one fully resident round on 256 CUs, each wave with 16 x 1 KiB loads in flight.
@@ -491,11 +417,7 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
     quest_decode_handler* h = new (std::nothrow) quest_decode_handler();
     if (!h) return (int)hipErrorOutOfMemory;
     h->layout = layout;
-    // QUEST_FUSE_MERGE=1: merge chunk states inside the attention kernel (last-arriving workgroup, sc1
-    // hand-off) instead of the merge kernel.  Measured on MI355X at cfg 3: 13.64 vs 13.58 us per op --
-    // the cross-CU hand-off (write-through + atomic + re-read) costs what the extra launch costs, so the
-    // simpler two-kernel form is the default.
-    h->fuse_merge = env_flag_on("QUEST_FUSE_MERGE");
+    if (const char* e = getenv("QUEST_DEC_WAVES")) h->dec_waves = atoi(e) == 8 ? 8 : 4;  // tuning knob
     *out = h;
     return 0;
 }
@@ -503,7 +425,6 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
 extern "C" void quest_decode_handler_destroy(quest_decode_handler_t* h) {
     if (!h) return;
     if (h->ws) (void)hipFree(h->ws);
-    if (h->counters) (void)hipFree(h->counters);
     delete h;
 }
 
@@ -540,16 +461,6 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     h->n_chunks = (n_slots + ppc - 1) / ppc;
     h->ws_stride = (head_dim + 2 + 31) / 32 * 32;
     const size_t need = (size_t)num_qo_heads * h->n_chunks * h->ws_stride * sizeof(float);
-    if (h->counters_len < num_qo_heads) {
-        if (h->counters) (void)hipFree(h->counters);
-        h->counters = nullptr;
-        h->counters_len = 0;
-        hipError_t e = hipMalloc((void**)&h->counters, num_qo_heads * sizeof(uint32_t));
-        if (e != hipSuccess) return (int)e;
-        e = hipMemset(h->counters, 0, num_qo_heads * sizeof(uint32_t));
-        if (e != hipSuccess) return (int)e;
-        h->counters_len = num_qo_heads;
-    }
     if (h->n_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
         if (h->ws) (void)hipFree(h->ws);
         h->ws = nullptr;
@@ -578,13 +489,15 @@ extern "C" int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t*
 
 template <int D, int FC>
 static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, hipStream_t s) {
-    dim3 grid(h->n_chunks, num_qo_heads), block(kDecWaves * kWave);
-    if (p.page_size == 16)
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC>), grid, block, 0, s, p);
+    dim3 grid(h->n_chunks, num_qo_heads);
+    if (p.page_size == 16 && h->dec_waves == 8)
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), 0, s, p);
+    else if (p.page_size == 16)
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 4>), grid, dim3(4 * kWave), 0, s, p);
     else
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), 0, s, p);
     QUEST_LAUNCH_CHECK();
-    if (h->n_chunks > 1 && !p.fuse_merge) {
+    if (h->n_chunks > 1) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, p.lse, h->n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
@@ -649,13 +562,12 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, const
     p.n_scores = n_scores;
     p.sel_val_out = (uint16_t*)topk_val_out;
     p.sel_idx_out = topk_idx_out;
-    p.counters = h->counters;
-    p.fuse_merge = h->fuse_merge ? 1u : 0u;
     p.ws_stride = h->ws_stride;
     // fc < 0: single-wave selection with -fc columns per lane (rows <= 4096); fc > 0: block selection
     int fc = 0;
     if (fused) {
-        const uint32_t per_thread = (n_scores + kDecWaves * kWave - 1) / (kDecWaves * kWave);
+        const uint32_t nt = (kv.page_size == 16 ? h->dec_waves : 4u) * kWave;
+        const uint32_t per_thread = (n_scores + nt - 1) / nt;
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
     }
     switch (kv.head_dim) {

@@ -43,6 +43,8 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
         key[i] = half_key(v[cc]);
         pid[i] = ii[cc];
     }
+    topk_clear<kTkThreads>(sm);  // overlaps the loads above
+    __syncthreads();
     TopkCursor cur = topk_select<kTkThreads, C>(sm, key, n, k);
     uint16_t* ov = out_val + row * k;
     int32_t* oi = out_idx + row * k;

@@ -46,6 +46,17 @@ struct TopkCursor {
     uint32_t T, need, pos, eq_rank;
 };
 
+// Clear the histograms.  Call BEFORE the first use of the keys (i.e. while the global loads that
+// produce them are still in flight) and follow with one __syncthreads() -- the barrier's wait is then
+// the load latency the kernel pays anyway.
+template <int NT>
+__device__ __forceinline__ void topk_clear(TopkSmem<NT>& sm) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < kBins1; i += NT) sm.hist1[i] = 0;
+    if (tid < kBins2) sm.hist2[tid] = 0;
+}
+
+// Precondition: topk_clear() + __syncthreads() already done.
 template <int NT, int C>
 __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k) {
     constexpr int BPT = kBins1 / NT;  // histogram bins per thread in the suffix scan
@@ -53,9 +64,6 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
     const uint32_t tid = threadIdx.x;
     const uint32_t c0 = tid * C;
 
-    for (uint32_t i = tid; i < kBins1; i += NT) sm.hist1[i] = 0;
-    if (tid < kBins2) sm.hist2[tid] = 0;
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < C; ++i)
         if (c0 + i < n) atomicAdd(&sm.hist1[key[i] >> kLowBits], 1u);

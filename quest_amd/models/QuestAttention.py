@@ -92,7 +92,8 @@ class QuestAttention(nn.Module):
             scores = qutils.decode_append_estimate(q, k, v, iController, self.layer_idx)
             nvtx.range_pop()
             nvtx.range_push("topk+approx_attn")
-            attn = qutils.decode_topk_sparse_attn(q, scores, iController, self.layer_idx)
+            # the selected page ids stay inside the kernel (nothing downstream reads topk_dindices_buffer)
+            attn = qutils.decode_topk_sparse_attn(q, scores, iController, self.layer_idx, write_topk=False)
             nvtx.range_pop()
         else:
             nvtx.range_push("append_kv")

@@ -89,12 +89,12 @@ def main():
             print(f"chain:    {t_c:7.2f} us  {bpl['chain'] / t_c / 1e3:7.1f} GB/s")
             t_ae = graph_time(lambda l: qu.decode_append_estimate(w.q[l], w.k1[l], w.v1[l], ctl, l), L)
             print(f"append+estimate (1 launch): {t_ae:7.2f} us")
-            t_ts = graph_time(lambda l: qu.decode_topk_sparse_attn(w.q[l], est[l], ctl, l), L)
+            t_ts = graph_time(lambda l: qu.decode_topk_sparse_attn(w.q[l], est[l], ctl, l, write_topk=False), L)
             print(f"topk+sparse_attn(+merge):   {t_ts:7.2f} us")
 
             def fchain(l):
                 e = qu.decode_append_estimate(w.q[l], w.k1[l], w.v1[l], ctl, l)
-                qu.decode_topk_sparse_attn(w.q[l], e, ctl, l)
+                qu.decode_topk_sparse_attn(w.q[l], e, ctl, l, write_topk=False)
 
             t_fc = graph_time(fchain, L)
             print(f"fused chain: {t_fc:7.2f} us  {bpl['chain'] / t_fc / 1e3:7.1f} GB/s")
