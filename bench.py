@@ -44,8 +44,10 @@ def parse():
     ap.add_argument("--token-budget", type=int, default=2048)
     ap.add_argument("--page-size", type=int, default=16)
     ap.add_argument("--layout", choices=["NHD", "HND"], default="NHD")
-    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
-                    help="graph: the whole step captured in one hipGraph and replayed; eager: Python op by op")
+    ap.add_argument("--mode", choices=["graph", "graph-static", "eager"], default="graph",
+                    help="graph: ONE hipGraph of the whole step, replayed while the sequence grows by a token per "
+                         "step (device-resident step state); graph-static: the same graph without the state "
+                         "(re-decodes the same position); eager: Python op by op")
     ap.add_argument("--skip-layers", type=int, default=0,
                     help="run the first n layers with full KV like quest/models/llama.py:428-439 (default 0)")
     ap.add_argument("--unfused", action="store_true",
@@ -72,7 +74,8 @@ class Workload:
         self.page_budget = a.token_budget // a.page_size
         L = a.seqlen
         self.ctl = qu.InferenceController(a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
-                                          L + 2 * a.page_size, torch.float16, dev, num_kv_heads=a.kv_heads,
+                                          L + a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,
+                                          num_kv_heads=a.kv_heads,
                                           layout=a.layout, shuffle_seed=1234)
         g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id)
         ctl = self.ctl
@@ -90,11 +93,32 @@ class Workload:
         self.q = torch.randn(a.layers, 1, a.heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
         self.k1 = torch.randn(a.layers, 1, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
         self.v1 = torch.randn(a.layers, 1, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
-        ctl.prepare_metadata(1)
         self.outs = [None] * a.layers
+        self.dyn = a.mode == "graph" and a.skip_layers == 0 and not a.unfused
+        if self.dyn:
+            # state-driven stepping: the graph's first node reserves the token on the device
+            ctl.enable_device_state()
+            ctl.begin_graph_decode()
+            self.scores = torch.empty(a.heads, ctl.max_pages, dtype=torch.float16, device=dev)
+        else:
+            ctl.prepare_metadata(1)
+
+    def step_dyn(self):
+        """One decode token, every length read from device memory (replayable as the sequence grows)."""
+        qu, ctl, a = self.qu, self.ctl, self.a
+        qu.step_advance_dyn(ctl)
+        for layer in range(a.layers):
+            self.outs[layer] = qu.decode_layer_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer,
+                                                   self.scores)
+
+    def after_replay(self):
+        if self.dyn:
+            self.ctl.prepare_metadata(1)  # host mirror of the device-side reservation (Python ints only)
 
     def step(self):
         """One decode token: llama.py:424-439 controller sequence + QuestAttention.py:99-157 per layer."""
+        if self.dyn:
+            return self.step_dyn()
         qu, ctl, a = self.qu, self.ctl, self.a
         skip = a.skip_layers
         if skip > 0:
@@ -232,17 +256,24 @@ def main():
             cur.wait_stream(st)
 
     # ---- the step, eager or captured
-    if a.mode == "graph":
+    if a.mode in ("graph", "graph-static"):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             step_all()  # warm the allocator / plan before capture
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        for wl in ws:
+            if wl.dyn:
+                wl.ctl.sync_device_state()  # the warm-up advanced the device state; start from the prefilled cache
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step_all()
-        run = graph.replay
+
+        def run():
+            graph.replay()
+            for wl in ws:
+                wl.after_replay()
     else:
         run = step_all
 
@@ -280,6 +311,8 @@ def main():
         qu, ctl = w.qu, w.ctl
         bpl = bytes_per_layer(a)
         # ---- per-operator launch time with HIP events on the launch stream (steady state of this very step)
+        if w.dyn:
+            ctl.end_forward()
         ctl.set_page_budget(w.page_budget)
         ctl.begin_forward(1)
         ppc, chunks = ctl._decode_handler.plan_info()
@@ -293,7 +326,8 @@ def main():
         t_topk = time_kernel_loop(lambda l: qu.decode_topk(est0[l], ctl), a.layers, reps)
         t_app = time_kernel_loop(lambda l: qu.append_kv(w.k1[l], w.v1[l], ctl, l), a.layers, reps)
         t_ae = time_kernel_loop(lambda l: qu.decode_append_estimate(w.q[l], w.k1[l], w.v1[l], ctl, l), a.layers, reps)
-        t_ts = time_kernel_loop(lambda l: qu.decode_topk_sparse_attn(w.q[l], est0[l], ctl, l), a.layers, reps)
+        t_ts = time_kernel_loop(lambda l: qu.decode_topk_sparse_attn(w.q[l], est0[l], ctl, l, write_topk=False),
+                                a.layers, reps)
         ctl.end_forward()
         ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_plus_merge_us": t_att,
                "fused_append_estimate_us": t_ae, "fused_topk_sparse_attn_plus_merge_us": t_ts,
@@ -323,7 +357,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: Yarn-Llama-2-7B-128K shapes, 1 sequence per GPU, "
                                    "self-attention chain (append+estimate+top-k+sparse attn) x all layers per token",
                        "layers": a.layers, "num_qo_heads": a.heads, "num_kv_heads": a.kv_heads,
-                       "head_dim": a.head_dim, "seqlen": a.seqlen, "page_size": a.page_size,
+                       "head_dim": a.head_dim, "seqlen": a.seqlen, "seqlen_after_run": w.ctl.kv_cache.seqlen, "page_size": a.page_size,
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
                        "kv_layout": a.layout, "mode": a.mode, "skip_layers": a.skip_layers,
                        "launches_per_layer": "5 (reference op sequence)" if a.unfused else

@@ -153,6 +153,49 @@ int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, vo
                                     uint32_t num_qo_heads, const void* scores, uint32_t n_scores,
                                     void* topk_val_out, int32_t* topk_idx_out, float* lse, quest_stream_t stream);
 
+/*
+ * Device-resident step state (host planning rewrite).  The reference rebuilds page-table
+ * tensors and re-plans on the host for every token (quest/utils/controller.py:80-129); with the sequence
+ * state in device memory a decode step captured ONCE in a hipGraph can be replayed token after token while
+ * the sequence grows: quest_step_state_advance is prepare_metadata(1) on the device, and the *_dyn entry
+ * points read lengths / last-page ids from the state instead of from their by-value arguments.
+ * The page tables must be materialised up to the pool capacity (page i of the sequence = kv_table[i]).
+ */
+typedef struct quest_step_state {
+    int32_t seq_len;            /* tokens in the cache, including the one being decoded */
+    int32_t n_pages;            /* KV pages in use */
+    int32_t kv_last_page_len;   /* 1..page_size */
+    int32_t kv_last_page_idx;   /* physical id */
+    int32_t n_meta_pages;
+    int32_t meta_last_page_len;
+    int32_t meta_last_page_idx;
+    int32_t reserved;
+} quest_step_state_t;
+
+/* Reserve room for one more token: the device-side prepare_metadata(1) (controller.py:72-76). */
+int quest_step_state_advance(quest_step_state_t* state, const int32_t* kv_table, const int32_t* meta_table,
+                             uint32_t page_size, quest_stream_t stream);
+
+/* quest_append_estimate with lengths / last-page ids / n_out (= state->n_pages - 1) taken from `state`.
+ * o is [num_qo_heads][o_stride] with o_stride >= max_n_out, the largest n_out the graph will ever see
+ * (the grid is sized for it; surplus workgroups exit). */
+int quest_append_estimate_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                              uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                              quest_paged_kv_t metadata, const quest_step_state_t* state, quest_stream_t stream);
+
+/* quest_decode_forward_fused_topk with the row length (state->n_pages - 1) and the current page taken
+ * from `state`; scores is [num_qo_heads][score_stride].  The plan (selected-page count) is the one of
+ * begin_forward and must not exceed state->n_pages - 1 for the life of the graph. */
+int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                        uint32_t num_qo_heads, const void* scores, uint32_t score_stride,
+                                        uint32_t max_n_scores, const quest_step_state_t* state, float* lse,
+                                        quest_stream_t stream);
+
+/* quest_apply_rope_in_place for one decode token with past_kv_len = state->seq_len - 1. */
+int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_heads, uint32_t num_kv_heads, uint32_t head_dim,
+                                  float rope_scale, float rope_theta, const quest_step_state_t* state,
+                                  quest_stream_t stream);
+
 /* Introspection of the current plan (for benches/tests): pages per workgroup, workgroups per head. */
 int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_chunk,
                            uint32_t* chunks_per_head);

@@ -215,6 +215,53 @@ def append_estimate(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_len: int,
                                     meta, _stream(k)), "append_estimate")
 
 
+# ---- state-driven (graph-replayable) forms: EXTENSIONS, see include/quest_hip.h quest_step_state_t
+
+STEP_STATE_INTS = 8  # int32 fields of quest_step_state_t
+
+
+def step_state_advance(state, kv_table, meta_table, page_size: int) -> None:
+    """Device-side prepare_metadata(1): ``state`` int32[8] (quest_step_state_t), tables int32 up to capacity."""
+    for t, n in ((state, "state"), (kv_table, "kv_table"), (meta_table, "meta_table")):
+        _check_input(t, n)
+        _check_eq(t.dtype, torch.int32, f"{n}.scalar_type(), torch::kInt32")
+    _check_eq(state.numel(), STEP_STATE_INTS, "state.numel(), 8")
+    check(lib.quest_step_state_advance(state.data_ptr(), kv_table.data_ptr(), meta_table.data_ptr(), int(page_size),
+                                       _stream(state)), "step_state_advance")
+
+
+def append_estimate_dyn(k, v, kv_data, kv_table, q, o, metadata_data, meta_table, state, max_n_out: int,
+                        layout: int) -> None:
+    """append_estimate whose lengths / last-page ids / n_out come from ``state``; ``o`` is ``[Hq, stride]``."""
+    for t, n in ((k, "k"), (v, "v"), (kv_data, "kv_data"), (kv_table, "kv_table"), (q, "q"), (o, "o"),
+                 (metadata_data, "metadata_data"), (meta_table, "meta_table"), (state, "state")):
+        _check_input(t, n)
+    _check_dim(3, k, "k")
+    _check_dim(3, q, "q")
+    _check_dim(2, o, "o")
+    _check_eq(k.size(0), 1, "k.size(0), 1")
+    _check_eq(o.size(0), q.size(1), "o.size(0), num_heads")
+    _check_ge(o.size(1), max_n_out, "o.size(1), max_n_out")
+    _check_half(k, "Append_kv_cache_decode")
+    _check_half(q, "Estimate_attn_score")
+    kv = _paged(kv_data, kv_table, None, 1, 0, layout)
+    meta = _paged(metadata_data, meta_table, None, 1, 0, layout)
+    check(lib.quest_append_estimate_dyn(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1),
+                                        o.size(1), int(max_n_out), meta, state.data_ptr(), _stream(k)),
+          "append_estimate_dyn")
+
+
+def apply_rope_in_place_dyn(q, k, rope_scale: float, rope_theta: float, state) -> None:
+    _check_input(q, "q")
+    _check_input(k, "k")
+    _check_input(state, "state")
+    _check_eq(q.size(0), 1, "q.size(0), 1")
+    _check_half(q, "apply_rope_in_place")
+    check(lib.quest_apply_rope_in_place_dyn(q.data_ptr(), k.data_ptr(), q.size(1), k.size(1), q.size(2),
+                                            float(rope_scale), float(rope_theta), state.data_ptr(), _stream(q)),
+          "apply_rope_in_place_dyn")
+
+
 def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, causal: bool, layout: int,
                                 allow_fp16_qk_reduction: bool, rope_scale: float, rope_theta: float):
     """batch_prefill.cu:27-117 -- NOT on the sparse-decode path; torch SDPA over the gathered pages."""
@@ -326,6 +373,21 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
             return False
         check(code, "BatchDecodeWithPagedKVCache")
         return True
+
+    def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
+        """forward_fused_topk whose row length and current page come from ``state`` (graph replay)."""
+        for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (page_table, "page_table"),
+                     (scores, "scores"), (state, "state")):
+            _check_input(t, n)
+        _check_dim(2, scores, "scores")
+        _check_eq(scores.size(0), q.size(1), "scores.size(0), num_qo_heads")
+        _check_ge(scores.size(1), max_n_scores, "scores.size(1), max_n_scores")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, page_table, None, 1, 0, self._layout)
+        check(lib.quest_decode_forward_fused_topk_dyn(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1),
+                                                      scores.data_ptr(), scores.size(1), int(max_n_scores),
+                                                      state.data_ptr(), None, _stream(q)),
+              "BatchDecodeWithPagedKVCache")
 
     # introspection used by the bench / tuning sweeps (not part of the reference surface)
     def plan_info(self):

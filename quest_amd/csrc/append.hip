@@ -77,8 +77,31 @@ __global__ __launch_bounds__(256) void append_prefill_kernel(quest_paged_kv_t kv
     *reinterpret_cast<ushort8*>(mmin) = mn;
 }
 
+__global__ void step_state_advance_kernel(quest_step_state_t* st, const int32_t* __restrict__ kv_table,
+                                          const int32_t* __restrict__ meta_table, uint32_t S) {
+    // prepare_metadata(1) of quest/utils/controller.py:72-76 + kv_cache.py:115-126, on the device
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    quest_step_state_t s = *st;
+    s.seq_len += 1;
+    if (s.kv_last_page_len == (int32_t)S) {  // the token opens a new KV page ...
+        s.n_pages += 1;
+        s.kv_last_page_len = 1;
+        s.kv_last_page_idx = kv_table[s.n_pages - 1];
+        if (s.meta_last_page_len == (int32_t)S) {  // ... whose metadata entry may open a new metadata page
+            s.n_meta_pages += 1;
+            s.meta_last_page_len = 1;
+            s.meta_last_page_idx = meta_table[s.n_meta_pages - 1];
+        } else {
+            s.meta_last_page_len += 1;
+        }
+    } else {
+        s.kv_last_page_len += 1;
+    }
+    *st = s;
+}
+
 int check_pool(const quest_paged_kv_t& p) {
-    if (!p.data || !p.indices || !p.indptr) return QUEST_EINVAL;
+    if (!p.data || !p.indices) return QUEST_EINVAL;
     if (p.layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
     if (p.num_heads == 0 || p.page_size == 0) return QUEST_EINVAL;
     if (p.head_dim != 64 && p.head_dim != 128 && p.head_dim != 256) return QUEST_EUNSUPPORTED;
@@ -108,6 +131,7 @@ extern "C" int quest_append_kv_cache_prefill(const void* k, const void* v, uint3
                                              uint32_t n_pages_host, quest_paged_kv_t kv,
                                              quest_paged_kv_t metadata, quest_stream_t stream) {
     if (!k || !v || append_len == 0 || n_pages_host == 0) return QUEST_EINVAL;
+    if (!kv.indptr || !metadata.indptr) return QUEST_EINVAL;
     if (int e = check_pool(kv)) return e;
     if (int e = check_pool(metadata)) return e;
     if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
@@ -122,6 +146,15 @@ extern "C" int quest_append_kv_cache_prefill(const void* k, const void* v, uint3
     const uint32_t grid = (uint32_t)((rows + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(append_prefill_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, kv, metadata,
                        (const uint16_t*)k, (const uint16_t*)v, append_len);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int quest_step_state_advance(quest_step_state_t* state, const int32_t* kv_table, const int32_t* meta_table,
+                                        uint32_t page_size, quest_stream_t stream) {
+    if (!state || !kv_table || !meta_table || page_size == 0) return QUEST_EINVAL;
+    hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, kv_table, meta_table,
+                       page_size);
     QUEST_LAUNCH_CHECK();
     return 0;
 }

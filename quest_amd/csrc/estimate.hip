@@ -29,11 +29,24 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
     const uint16_t* value;
     uint32_t est_blocks;
     uint32_t enabled;
+    const quest_step_state_t* state;  // optional device-resident lengths / last-page ids (graph replay)
+    uint32_t o_stride;                // row stride of o (== n_out unless state-driven)
 };
 
 template <int D, int G, bool HND>
 __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict__ q, half_t* __restrict__ o,
                                                        quest_paged_kv_t meta, uint32_t n_out, AppendTail tail) {
+    // n_out as passed bounds every address (state-driven launches pass the largest n_out the graph will
+    // see; page tables and pools cover it).  The live n_out is read from the state AFTER the page-table
+    // loads are issued, so that scalar load overlaps them instead of preceding them.
+    const uint32_t n_cap = n_out;
+    if (tail.state && tail.enabled && blockIdx.x >= tail.est_blocks) {
+        const quest_step_state_t st = *tail.state;
+        meta.last_page_len = (uint32_t)st.meta_last_page_len;
+        meta.last_page_idx = st.meta_last_page_idx;
+        tail.kv.last_page_len = (uint32_t)st.kv_last_page_len;
+        tail.kv.last_page_idx = st.kv_last_page_idx;
+    }
     if (tail.enabled && blockIdx.x >= tail.est_blocks) {
         // The appended token only touches the CURRENT page's KV entry and metadata entry (index n_out),
         // which the estimate excludes (e < n_out), so the two halves of the launch share no byte.
@@ -50,7 +63,6 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
     const half_t* data = reinterpret_cast<const half_t*>(meta.data);
     const int32_t* idx = meta.indices;  // batch_size == 1: indptr[0] == 0 (estimate.cu:14)
     const uint32_t row0 = (blockIdx.x * 4 + wave) * (kEstIter * R) + row;
-
     half8 mx[kEstIter], mn[kEstIter];
     // MHA: q is requested together with the metadata (one extra 16 B load per row).  GQA: a row needs the
     // G query vectors of its kv head; all Hq vectors (8 KiB for 32 x 128) are staged in LDS once per
@@ -61,6 +73,8 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
     float8 qv[kEstIter][QPRE ? 1 : 1];
     uint32_t ent[kEstIter], head[kEstIter];
     bool ok[kEstIter];
+    size_t page[kEstIter];
+    uint32_t ecl[kEstIter];
 #pragma unroll
     for (int j = 0; j < kEstIter; ++j) {
         const uint32_t r = row0 + j * R;
@@ -76,15 +90,24 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
         }
         ent[j] = e;
         head[j] = hk;
-        ok[j] = e < n_out;
         // Loads are unconditional from a clamped entry: a predicated load compiles to branch + load +
-        // wait and serialises the kEstIter round trips.  Clamped rows re-read entry n_out-1 (tail only).
-        const uint32_t ec = ok[j] ? e : n_out - 1;
-        const size_t page = (size_t)idx[ec / S];
-        const half_t* p = data + page * ms.page + (size_t)hk * ms.head + (size_t)(ec % S) * ms.entry + col * kVec;
+        // wait and serialises the kEstIter round trips.  Clamped rows re-read the last entry (tail only).
+        ecl[j] = e < n_cap ? e : n_cap - 1;
+        page[j] = (size_t)idx[ecl[j] / S];
+    }
+    if (tail.state) {  // live length (<= n_cap); whole workgroups past it have nothing to do
+        n_out = (uint32_t)(tail.state->n_pages - 1);
+        const uint32_t first = blockIdx.x * 4 * (kEstIter * R);
+        const uint32_t first_entry = HND ? (first / (Hkv * S)) * S : first / Hkv;
+        if (first_entry >= n_out) return;
+    }
+#pragma unroll
+    for (int j = 0; j < kEstIter; ++j) {
+        ok[j] = ent[j] < n_out;
+        const half_t* p = data + page[j] * ms.page + (size_t)head[j] * ms.head + (size_t)(ecl[j] % S) * ms.entry + col * kVec;
         mx[j] = ld8(p);
         mn[j] = ld8(p + ms.v_off);
-        if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)hk * D + col * kVec));
+        if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)head[j] * D + col * kVec));
     }
     if (!QPRE) {
         const uint32_t total = Hkv * G * D;
@@ -104,7 +127,7 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
 #pragma unroll
             for (int i = 0; i < kVec; ++i) acc += __builtin_fmaxf(qg[i] * a[i], qg[i] * b[i]);
             acc = row_allreduce_sum_fast<LPR>(acc);
-            if (ok[j] && col == 0) o[((size_t)head[j] * G + g) * n_out + ent[j]] = (half_t)acc;
+            if (ok[j] && col == 0) o[((size_t)head[j] * G + g) * tail.o_stride + ent[j]] = (half_t)acc;
         }
     }
 }
@@ -114,6 +137,7 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
                            hipStream_t s) {
     constexpr int R = kWave / (D / kVec);
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
+    if (!tail.state) tail.o_stride = n_out;
     const uint64_t entries = hnd ? (uint64_t)((n_out + meta.page_size - 1) / meta.page_size) * meta.page_size : n_out;
     const uint64_t rows = entries * meta.num_heads;
     const uint32_t rows_per_block = 4 * kEstIter * R;
@@ -172,6 +196,25 @@ extern "C" int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo
                                          quest_paged_kv_t metadata, quest_stream_t stream) {
     AppendTail tail{};
     return estimate_entry(q, o, num_qo_heads, n_out, metadata, tail, (hipStream_t)stream);
+}
+
+extern "C" int quest_append_estimate_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                         uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                                         quest_paged_kv_t metadata, const quest_step_state_t* state,
+                                         quest_stream_t stream) {
+    if (!k || !v || !state || max_n_out == 0 || o_stride < max_n_out) return QUEST_EINVAL;
+    kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
+    AppendTail tail{};
+    tail.kv = kv;
+    tail.key = (const uint16_t*)k;
+    tail.value = (const uint16_t*)v;
+    tail.enabled = 1;
+    tail.state = state;
+    tail.o_stride = o_stride;
+    return estimate_entry(q, o, num_qo_heads, max_n_out, metadata, tail, (hipStream_t)stream);
 }
 
 extern "C" int quest_append_estimate(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,

@@ -13,7 +13,8 @@ namespace quest {
 template <int D>
 __global__ __launch_bounds__(256) void rope_kernel(half_t* __restrict__ q, half_t* __restrict__ k, uint32_t n,
                                                    uint32_t past_len, uint32_t hq, uint32_t hk, float rcp_scale,
-                                                   float log2_rcp_theta) {
+                                                   float log2_rcp_theta, const quest_step_state_t* state) {
+    if (state) past_len = (uint32_t)(state->seq_len - 1);  // decode token of a state-driven step
     constexpr int LPR = D / kVec;
     constexpr int RPB = 256 / LPR;  // vectors per block
     const uint32_t vec = blockIdx.x * RPB + threadIdx.x / LPR;
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(1024) void rms_norm_kernel(const half_t* __restrict
 
 using namespace quest;
 
-extern "C" int quest_apply_rope_in_place(void* q, void* k, uint32_t n, uint32_t past_kv_len, uint32_t num_qo_heads,
-                                         uint32_t num_kv_heads, uint32_t head_dim, float rope_scale, float rope_theta,
-                                         quest_stream_t stream) {
+static int rope_entry(void* q, void* k, uint32_t n, uint32_t past_kv_len, uint32_t num_qo_heads, uint32_t num_kv_heads,
+                      uint32_t head_dim, float rope_scale, float rope_theta, const quest_step_state_t* state,
+                      quest_stream_t stream) {
     if (!q || !k || num_qo_heads == 0 || num_kv_heads == 0) return QUEST_EINVAL;
     if (rope_scale == 0.f || rope_theta <= 0.f) return QUEST_EINVAL;
     if (n == 0) return 0;
@@ -89,7 +90,8 @@ extern "C" int quest_apply_rope_in_place(void* q, void* k, uint32_t n, uint32_t 
     case DD: {                                                                                                    \
         const uint32_t rpb = 256 / (DD / kVec);                                                                   \
         hipLaunchKernelGGL((rope_kernel<DD>), dim3((vecs + rpb - 1) / rpb), dim3(256), 0, s, (half_t*)q,          \
-                           (half_t*)k, n, past_kv_len, num_qo_heads, num_kv_heads, rcp_scale, log2_rcp_theta);   \
+                           (half_t*)k, n, past_kv_len, num_qo_heads, num_kv_heads, rcp_scale, log2_rcp_theta,    \
+                           state);                                                                               \
         break;                                                                                                    \
     }
     switch (head_dim) {
@@ -101,6 +103,19 @@ extern "C" int quest_apply_rope_in_place(void* q, void* k, uint32_t n, uint32_t 
 #undef QUEST_ROPE_CASE
     QUEST_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int quest_apply_rope_in_place(void* q, void* k, uint32_t n, uint32_t past_kv_len, uint32_t num_qo_heads,
+                                         uint32_t num_kv_heads, uint32_t head_dim, float rope_scale, float rope_theta,
+                                         quest_stream_t stream) {
+    return rope_entry(q, k, n, past_kv_len, num_qo_heads, num_kv_heads, head_dim, rope_scale, rope_theta, nullptr, stream);
+}
+
+extern "C" int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_heads, uint32_t num_kv_heads,
+                                             uint32_t head_dim, float rope_scale, float rope_theta,
+                                             const quest_step_state_t* state, quest_stream_t stream) {
+    if (!state) return QUEST_EINVAL;
+    return rope_entry(q, k, 1, 0, num_qo_heads, num_kv_heads, head_dim, rope_scale, rope_theta, state, stream);
 }
 
 extern "C" int quest_rms_norm_forward(const void* input, const void* weight, void* output, uint32_t rows, uint32_t cols,

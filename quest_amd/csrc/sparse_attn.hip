@@ -52,6 +52,8 @@ struct DecodeParams {
     uint16_t* sel_val_out;   // optional [Hq][n_sel]
     int32_t* sel_idx_out;    // optional [Hq][n_sel]
     uint32_t ws_stride;  // floats per partial record (>= D + 2, multiple of 32 -> records own whole 128 B lines)
+    uint32_t score_stride;  // row stride of `scores`
+    const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
 };
 
 constexpr int kFusedMaxPpc = 64;  // pages per workgroup the fused front end can stage in LDS
@@ -115,6 +117,14 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hq = blockIdx.y, hk = hq / p.group;
+    // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
+    // row length comes from the state
+    if (FC <= 0 && p.state) {  // variants without the block-wide front end: plain up-front read
+        const quest_step_state_t st = *p.state;
+        p.n_scores = (uint32_t)(st.n_pages - 1);
+        p.last_page_len = (uint32_t)st.kv_last_page_len;
+        p.last_page_idx = st.kv_last_page_idx;
+    }
     const uint32_t n_slots = p.n_sel + 1;  // selected pages + the current page
     const uint32_t slot_begin = chunk * p.pages_per_chunk;
     const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         __shared__ TopkWaveSmem wsm;
         if (wave == 0) {
             const uint32_t n = p.n_scores;
-            const uint16_t* srow = p.scores + (size_t)hq * n;
+            const uint16_t* srow = p.scores + (size_t)hq * p.score_stride;
             const int32_t* table = p.indices;
             uint32_t key[C];
             int32_t pid[C];
@@ -163,26 +173,36 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
         constexpr bool PRE = FC <= 16;  // page ids of the owned columns fetched with the scores
-        const uint32_t n = p.n_scores, c0 = threadIdx.x * FC;
-        const uint16_t* srow = p.scores + (size_t)hq * n;
+        if (p.state) {  // live lengths (the column ownership below depends on the live row length)
+            const quest_step_state_t st = *p.state;
+            p.n_scores = (uint32_t)(st.n_pages - 1);
+            p.last_page_len = (uint32_t)st.kv_last_page_len;
+            p.last_page_idx = st.kv_last_page_idx;
+        }
+        const uint32_t n = p.n_scores;
+        const uint32_t cpt = topk_cols_per_thread<NW * kWave>(n);  // <= FC (FC is sized for n_cap >= n)
+        const uint32_t c0 = threadIdx.x * cpt;
+        const uint16_t* srow = p.scores + (size_t)hq * p.score_stride;
         const int32_t* table = p.indices;
         uint32_t key[FC];
         int32_t pid[PRE ? FC : 1];
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
-            const uint32_t cc = c0 + i < n ? c0 + i : n - 1;  // clamped, unconditional loads
+            // clamped, UNCONDITIONAL loads (any guard here becomes a branch with a wait per load); slots
+            // i >= cpt re-read the row's last column and are ignored by the in-range tests below
+            const uint32_t cc = c0 + i < n ? c0 + i : n - 1;
             key[i] = half_key(srow[cc]);
             if (PRE) pid[i] = table[cc];
         }
         topk_clear<NW * kWave>(sm);  // overlaps the score / page-id loads above
         __syncthreads();
-        TopkCursor cur = topk_select<NW * kWave, FC>(sm, key, n, p.n_sel);
+        TopkCursor cur = topk_select<NW * kWave, FC>(sm, key, n, p.n_sel, cpt);
         uint32_t my_slot[FC];
         bool mine[FC];
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             uint32_t slot;
-            mine[i] = topk_take(cur, key[i], c0 + i < n, slot) && slot >= slot_begin && slot < slot_end;
+            mine[i] = topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot) && slot >= slot_begin && slot < slot_end;
             my_slot[i] = slot;
             if (mine[i]) s_sel[slot - slot_begin] = PRE ? pid[i] : table[c0 + i];
         }
@@ -488,9 +508,10 @@ extern "C" int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t*
 }
 
 template <int D, int FC>
-static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, hipStream_t s) {
+static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t waves,
+                            hipStream_t s) {
     dim3 grid(h->n_chunks, num_qo_heads);
-    if (p.page_size == 16 && h->dec_waves == 8)
+    if (p.page_size == 16 && waves == 8)
         hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), 0, s, p);
     else if (p.page_size == 16)
         hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 4>), grid, dim3(4 * kWave), 0, s, p);
@@ -508,20 +529,22 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
 // fc: fused top-k front end variant (0 = page ids come from an index tensor)
 template <int D>
 static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, int fc,
-                         hipStream_t s) {
+                         uint32_t waves, hipStream_t s) {
     switch (fc) {
-        case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, s);
-        case 8: return launch_decode_fc<D, 8>(h, p, num_qo_heads, s);
-        case 16: return launch_decode_fc<D, 16>(h, p, num_qo_heads, s);
-        case 32: return launch_decode_fc<D, 32>(h, p, num_qo_heads, s);
-        case 64: return launch_decode_fc<D, 64>(h, p, num_qo_heads, s);
+        case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, waves, s);
+        case 8: return launch_decode_fc<D, 8>(h, p, num_qo_heads, waves, s);
+        case 16: return launch_decode_fc<D, 16>(h, p, num_qo_heads, waves, s);
+        case 32: return launch_decode_fc<D, 32>(h, p, num_qo_heads, waves, s);
+        case 64: return launch_decode_fc<D, 64>(h, p, num_qo_heads, waves, s);
         default: return QUEST_EUNSUPPORTED;
     }
 }
 
-static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, const quest_paged_kv_t& kv,
+static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
                         uint32_t num_qo_heads, const void* scores, uint32_t n_scores, void* topk_val_out,
-                        int32_t* topk_idx_out, float* lse, hipStream_t s) {
+                        int32_t* topk_idx_out, float* lse, hipStream_t s, uint32_t score_stride = 0,
+                        const quest_step_state_t* state = nullptr) {
+    if (state) kv.last_page_len = 1;  // placeholder; the kernel reads the real one from `state`
     if (!h) return QUEST_EINVAL;
     if (!h->started) return QUEST_ESTATE;
     if (!q || !o || !kv.data) return QUEST_EINVAL;
@@ -532,8 +555,9 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, const
         if (h->pages_per_chunk > (uint32_t)kFusedMaxPpc) return QUEST_EUNSUPPORTED;
         // beyond 4096 pages the per-workgroup selection (>= 32 keys per thread, repeated by every
         // workgroup of the head) costs more than the stand-alone top-k launch it replaces (measured at
-        // 8191 pages: 33.9 vs 30.1 us) -> tell the caller to take the two-launch path
-        if (n_scores > 16u * kDecWaves * kWave) return QUEST_EUNSUPPORTED;
+        // 8191 pages: 33.9 vs 30.1 us) -> tell the caller to take the two-launch path.  State-driven
+        // launches pass a capacity, not a length (the work follows the live length), so they are exempt.
+        if (!state && n_scores > 16u * kDecWaves * kWave) return QUEST_EUNSUPPORTED;
     } else if (h->n_sel > 0 && (!kv.indices || kv.page_budget < h->n_sel)) {
         return QUEST_EINVAL;
     }
@@ -563,17 +587,23 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, const
     p.sel_val_out = (uint16_t*)topk_val_out;
     p.sel_idx_out = topk_idx_out;
     p.ws_stride = h->ws_stride;
+    p.score_stride = score_stride ? score_stride : n_scores;
+    p.state = state;
     // fc < 0: single-wave selection with -fc columns per lane (rows <= 4096); fc > 0: block selection
     int fc = 0;
+    uint32_t waves = h->dec_waves;
     if (fused) {
-        const uint32_t nt = (kv.page_size == 16 ? h->dec_waves : 4u) * kWave;
+        // keys per thread stay <= 8 up to 4096 pages by doubling the workgroup (the attention part runs
+        // the same with 4 or 8 waves; the selection's cost follows keys per thread)
+        if (kv.page_size == 16 && n_scores > 8u * 4u * kWave) waves = 8;
+        const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
         const uint32_t per_thread = (n_scores + nt - 1) / nt;
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
     }
     switch (kv.head_dim) {
-        case 64: return launch_decode<64>(h, p, num_qo_heads, fc, s);
-        case 128: return launch_decode<128>(h, p, num_qo_heads, fc, s);
-        case 256: return launch_decode<256>(h, p, num_qo_heads, fc, s);
+        case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s);
+        case 128: return launch_decode<128>(h, p, num_qo_heads, fc, waves, s);
+        case 256: return launch_decode<256>(h, p, num_qo_heads, fc, waves, s);
         default: return QUEST_EUNSUPPORTED;
     }
 }
@@ -590,6 +620,16 @@ extern "C" int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const 
     if (!scores) return QUEST_EINVAL;
     return decode_entry(h, q, o, kv, num_qo_heads, scores, n_scores, topk_val_out, topk_idx_out, lse,
                         (hipStream_t)stream);
+}
+
+extern "C" int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q, void* o,
+                                                   quest_paged_kv_t kv, uint32_t num_qo_heads, const void* scores,
+                                                   uint32_t score_stride, uint32_t max_n_scores,
+                                                   const quest_step_state_t* state, float* lse, quest_stream_t stream) {
+    if (!scores || !state || score_stride < max_n_scores) return QUEST_EINVAL;
+    // dispatch (keys per thread) is chosen for the longest row the graph will see
+    return decode_entry(h, q, o, kv, num_qo_heads, scores, max_n_scores, nullptr, nullptr, lse, (hipStream_t)stream,
+                        score_stride, state);
 }
 
 extern "C" const char* quest_error_string(int code) {

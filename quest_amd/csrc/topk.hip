@@ -31,27 +31,28 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
     const size_t row = blockIdx.x;
     const uint16_t* v = vals + row * n;
     const int32_t* ii = in_idx + row * n;
-    const uint32_t c0 = tid * C;
+    const uint32_t cpt = topk_cols_per_thread<kTkThreads>(n);
+    const uint32_t c0 = tid * cpt;
 
     uint32_t key[C];
     int32_t pid[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         // unconditional loads from a clamped column (a predicated load becomes branch + load + wait,
-        // which serialises the round trips); out-of-range columns are masked by `c < n` later
+        // which serialises the round trips); out-of-range columns are masked later
         const uint32_t c = c0 + i, cc = c < n ? c : n - 1;
         key[i] = half_key(v[cc]);
         pid[i] = ii[cc];
     }
     topk_clear<kTkThreads>(sm);  // overlaps the loads above
     __syncthreads();
-    TopkCursor cur = topk_select<kTkThreads, C>(sm, key, n, k);
+    TopkCursor cur = topk_select<kTkThreads, C>(sm, key, n, k, cpt);
     uint16_t* ov = out_val + row * k;
     int32_t* oi = out_idx + row * k;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         uint32_t slot;
-        if (topk_take(cur, key[i], c0 + i < n, slot)) {
+        if (topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot)) {
             ov[slot] = key_to_half_bits(key[i]);
             oi[slot] = pid[i];
         }

@@ -6,7 +6,9 @@
 // above the threshold key T, plus the `need` LOWEST columns among keys equal to T; a selected column's
 // output slot is its rank among selected columns in ascending column order.
 //
-// Thread t of NT owns the contiguous columns [t*C, t*C+C).  Method: 11-bit histogram (2048 bins, LDS
+// Thread t of NT owns the contiguous columns [t*cpt, t*cpt+cpt) with cpt = ceil(n / NT) <= C at run time
+// (C is only the compile-time capacity of the register arrays, so a kernel built for long rows does not
+// do long-row work on short ones).  Method: 11-bit histogram (2048 bins, LDS
 // atomics) + block suffix scan -> threshold bin; 5-bit histogram of that bin's members -> exact T;
 // packed block scan of per-thread (>T, ==T) counts -> output slots.
 #pragma once
@@ -56,17 +58,24 @@ __device__ __forceinline__ void topk_clear(TopkSmem<NT>& sm) {
     if (tid < kBins2) sm.hist2[tid] = 0;
 }
 
-// Precondition: topk_clear() + __syncthreads() already done.
+// Columns per thread for a row of n columns.
+template <int NT>
+__device__ __forceinline__ uint32_t topk_cols_per_thread(uint32_t n) {
+    return (n + NT - 1) / NT;
+}
+
+// Precondition: topk_clear() + __syncthreads() already done; key[i] holds column tid*cpt + i for i < cpt.
 template <int NT, int C>
-__device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k) {
+__device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k,
+                                                  uint32_t cpt) {
     constexpr int BPT = kBins1 / NT;  // histogram bins per thread in the suffix scan
     static_assert(kBins1 % NT == 0 && NT >= kWave, "thread count must divide the bin count");
     const uint32_t tid = threadIdx.x;
-    const uint32_t c0 = tid * C;
+    const uint32_t c0 = tid * cpt;
 
 #pragma unroll
     for (int i = 0; i < C; ++i)
-        if (c0 + i < n) atomicAdd(&sm.hist1[key[i] >> kLowBits], 1u);
+        if ((uint32_t)i < cpt && c0 + i < n) atomicAdd(&sm.hist1[key[i] >> kLowBits], 1u);
     __syncthreads();
 
     {  // suffix scan from the top bin: thread t owns bins kBins1-1-BPT*t .. kBins1-BPT*(t+1), descending
@@ -91,7 +100,8 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
     const uint32_t thr_bin = sm.misc[0];
 #pragma unroll
     for (int i = 0; i < C; ++i)
-        if (c0 + i < n && (key[i] >> kLowBits) == thr_bin) atomicAdd(&sm.hist2[key[i] & (kBins2 - 1)], 1u);
+        if ((uint32_t)i < cpt && c0 + i < n && (key[i] >> kLowBits) == thr_bin)
+            atomicAdd(&sm.hist2[key[i] & (kBins2 - 1)], 1u);
     __syncthreads();
 
     if (tid < kWave) {  // wave 0: lane l looks at low digit 31-l, suffix sums by shuffle
@@ -112,7 +122,7 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
     uint32_t gt = 0, eq = 0;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        const bool in = c0 + i < n;
+        const bool in = (uint32_t)i < cpt && c0 + i < n;
         gt += in && key[i] > cur.T;
         eq += in && key[i] == cur.T;
     }

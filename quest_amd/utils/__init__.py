@@ -30,6 +30,9 @@ __all__ = [
     # extensions (fused launches; same results as the op pairs they replace)
     "decode_append_estimate",
     "decode_topk_sparse_attn",
+    # state-driven forms for hipGraph replay across tokens
+    "step_advance_dyn",
+    "decode_layer_dyn",
 ]
 
 
@@ -131,4 +134,40 @@ def decode_topk_sparse_attn(q: torch.Tensor, estimated_attn_score: torch.Tensor,
     if not ok:  # plan with very large chunks: take the two-launch path
         decode_topk(estimated_attn_score, iController)
         return decode_sparse_attn(q, iController, layer_idx, iController.topk_dindices_buffer)
+    return o
+
+
+# ---------------------------------------------------------------------------- graph-replayable step
+# With ``iController.enable_device_state()`` the per-token quantities live in device memory; a step built
+# from the two calls below can be captured once (torch.cuda.graph) and replayed for every new token:
+#
+#     ctl.prepare_metadata(1); ctl.begin_forward(1)            # plan for the budget (host, once)
+#     ctl.end_forward(); <undo the host-side reservation: see tests/test_gpu_graph_decode.py>
+#     with torch.cuda.graph(g):
+#         step_advance_dyn(ctl)                                # device-side prepare_metadata(1)
+#         for layer: o[layer] = decode_layer_dyn(q[layer], k[layer], v[layer], ctl, layer, scores)
+#     per token:  fill q/k/v buffers; g.replay(); ctl.prepare_metadata(1)   # host mirror only
+
+def step_advance_dyn(iController: InferenceController) -> None:
+    _kernels.step_state_advance(iController.step_state, iController.kv_table_full, iController.meta_table_full,
+                                iController.page_size)
+
+
+def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
+                     layer_idx: int, scores: torch.Tensor, rope_scale: Optional[float] = None,
+                     rope_theta: Optional[float] = None, apply_rope: bool = False) -> torch.Tensor:
+    """One layer of a decode token in the sparse regime (pages > budget), every length read from the
+    device-resident state: [RoPE] -> append+estimate -> top-k+attention (+merge).  ``scores`` is a
+    caller-owned ``[Hq, >= max_pages]`` fp16 scratch."""
+    ctl = iController
+    if apply_rope:
+        scale, theta = _rope_defaults(rope_scale, rope_theta)
+        _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
+    max_n = ctl.max_pages - 1
+    _kernels.append_estimate_dyn(k, v, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, q, scores,
+                                 ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, ctl.step_state, max_n,
+                                 ctl.layout)
+    o = torch.empty_like(q)
+    ctl._decode_handler.forward_fused_topk_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, scores,
+                                               ctl.step_state, max_n)
     return o

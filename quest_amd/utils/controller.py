@@ -129,6 +129,33 @@ class InferenceController:
     def end_forward(self) -> None:
         self._decode_handler.end_forward()
 
+    # ------------------------------------------------------------------ device-resident step state
+    def enable_device_state(self) -> None:
+        """Put the sequence's step state (lengths, last-page ids) in device memory so that a decode step
+        captured in a hipGraph can be replayed while the sequence grows (EXTENSION).  Call
+        after prefill; the state describes the cache BEFORE the next token -- the graph's first node,
+        ``_kernels.step_state_advance``, moves it forward by one token on the device."""
+        self.kv_table_full = self.kv_cache.full_device_table()
+        self.meta_table_full = self.metadata_cache.full_device_table()
+        self.max_pages = self.kv_table_full.numel()
+        self.step_state = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.sync_device_state()
+
+    def begin_graph_decode(self) -> None:
+        """Plan the sparse decode for the configured budget once, for a graph that will be replayed over
+        many tokens (the plan depends only on the budget, which is constant once pages >= budget)."""
+        budget = self._page_budget
+        assert len(self.kv_cache.indicies) >= budget, "graph decode needs the sparse regime (pages >= budget)"
+        self.inference_page_budget = budget
+        self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
+                                           self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
+
+    def sync_device_state(self) -> None:
+        kv, meta = self.kv_cache, self.metadata_cache
+        host = torch.tensor([kv.seqlen, len(kv.indicies), kv.last_page_len, kv.indicies[-1], len(meta.indicies),
+                             meta.last_page_len, meta.indicies[-1], 0], dtype=torch.int32)
+        self.step_state.copy_(host)
+
     def need_estimate(self) -> bool:
         if self.inference_page_budget is None:
             return False

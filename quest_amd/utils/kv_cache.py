@@ -129,6 +129,14 @@ class KvCache:
             self._table_len = n
         return self._table[:n]
 
+    def full_device_table(self) -> torch.Tensor:
+        """int32 device table of EVERY page this sequence will ever use, in allocation order: the pages in
+        use followed by the free list in the order ``alloc_block`` will hand them out.  Valid because the
+        pool belongs to this sequence alone (kv_cache.py:86-94 builds one pool per KvCache).  Used by the
+        device-resident step state: page i of the sequence is ``table[i]`` before it is allocated."""
+        future = list(reversed(self._pool._free))
+        return torch.tensor(self._indicies + future, dtype=torch.int32, device=self._table.device)
+
     def release(self) -> None:
         self._seqlen = 0
         for idx in self._indicies:

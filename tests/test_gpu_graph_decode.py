@@ -1,0 +1,98 @@
+"""Device-resident step state: ONE captured hipGraph replayed token after token while the sequence grows
+must reproduce the eager per-token path bit for bit -- across KV-page and metadata-page boundaries."""
+import numpy as np
+import pytest
+import torch
+
+from _harness import cuda, inputs, make_controller
+
+pytestmark = pytest.mark.gpu
+PAGE = 16
+
+
+@pytest.mark.parametrize("Hq,Hkv,layout,L0,steps", [(4, 4, 0, 16 * 31 + 10, 45), (8, 2, 1, 16 * 15 + 16, 40)])
+def test_graph_replay_matches_eager_over_growing_sequence(Hq, Hkv, layout, L0, steps):
+    import quest_amd.utils as qu
+    from quest_amd import _kernels
+
+    dev = torch.device("cuda:0")
+    layers, D, B = 2, 128, 7
+    q0, k0, v0 = inputs(77, L0, Hq, Hkv, D)
+    g = torch.Generator(device=dev).manual_seed(3)
+    new_q = torch.randn(steps, layers, 1, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, layers, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, layers, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    def prefilled():
+        ctl = make_controller(L0 + steps + 40, Hq, Hkv, D, PAGE, B, layout=layout, shuffle_seed=21, num_layers=layers,
+                              max_seq_len=L0 + steps + 40)
+        ctl.prepare_metadata(L0)
+        ctl.begin_forward(L0)
+        for l in range(layers):
+            qu.append_kv(cuda(k0), cuda(v0), ctl, l)
+        ctl.end_forward()
+        return ctl
+
+    # ---- eager path, one token at a time (controller re-plans on the host every token)
+    ea = prefilled()
+    eager_out = []
+    for t in range(steps):
+        ea.prepare_metadata(1)
+        ea.begin_forward(1)
+        assert ea.need_estimate()
+        outs = []
+        for l in range(layers):
+            q, k = new_q[t, l].clone(), new_k[t, l].clone()
+            qu.apply_rope_in_place(q, k, ea.kv_cache.seqlen - 1)
+            est = qu.decode_append_estimate(q, k, new_v[t, l], ea, l)
+            outs.append(qu.decode_topk_sparse_attn(q, est, ea, l, write_topk=False))
+        ea.end_forward()
+        eager_out.append(torch.stack(outs))
+
+    # ---- graph path: capture once, replay `steps` times
+    gr = prefilled()
+    gr.enable_device_state()
+    gr.begin_graph_decode()
+    qbuf = torch.empty(layers, 1, Hq, D, device=dev, dtype=torch.float16)
+    kbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
+    vbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
+    scores = torch.empty(Hq, gr.max_pages, device=dev, dtype=torch.float16)
+    obuf = [None] * layers
+
+    def step():
+        qu.step_advance_dyn(gr)
+        for l in range(layers):
+            obuf[l] = qu.decode_layer_dyn(qbuf[l], kbuf[l], vbuf[l], gr, l, scores, apply_rope=True)
+
+    # warm-up on a side stream would advance the state: run it, then restore the state before capture
+    qbuf.copy_(new_q[0]); kbuf.copy_(new_k[0]); vbuf.copy_(new_v[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr.sync_device_state()  # back to "before the first decode token" (pool bytes written by the warm-up are rewritten)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    gr.sync_device_state()  # capture does not execute, but keep the invariant explicit
+
+    for t in range(steps):
+        qbuf.copy_(new_q[t]); kbuf.copy_(new_k[t]); vbuf.copy_(new_v[t])
+        graph.replay()
+        gr.prepare_metadata(1)  # host mirror of what the graph's first node did on the device
+        got = torch.stack([o.clone() for o in obuf])
+        assert torch.equal(got, eager_out[t]), f"token {t}: graph replay differs from eager"
+        st = gr.step_state.cpu().tolist()
+        kv, meta = gr.kv_cache, gr.metadata_cache
+        assert st[:7] == [kv.seqlen, len(kv.indicies), kv.last_page_len, kv.indicies[-1], len(meta.indicies),
+                          meta.last_page_len, meta.indicies[-1]]
+    gr.end_forward()
+    # pools identical at the end
+    n_pages = len(ea.kv_cache.indicies)
+    assert gr.kv_cache.indicies == ea.kv_cache.indicies and gr.metadata_cache.indicies == ea.metadata_cache.indicies
+    assert n_pages > (L0 + PAGE - 1) // PAGE + 1, "the run must cross page boundaries"
+    for l in range(layers):
+        ia = torch.tensor(ea.kv_cache.indicies[:-1], device=dev)
+        assert torch.equal(ea.kv_cache.buf_layer(l)[ia], gr.kv_cache.buf_layer(l)[ia])
