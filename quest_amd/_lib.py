@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libquest_hip.so")
+LIB_PATH = os.environ.get("QUEST_HIP_LIB") or os.path.join(_HERE, "libquest_hip.so")  # override: tuning builds
 
 c_u32, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
 

@@ -27,6 +27,13 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(out_path: str, extra_flags) -> str:
+    """Tuning aid: build a second .so with extra -D flags (loaded with QUEST_HIP_LIB=<path>)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out_path])
+    return out_path
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB

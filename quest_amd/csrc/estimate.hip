@@ -18,7 +18,10 @@
 
 namespace quest {
 
-constexpr int kEstIter = 4;  // load instructions per tensor per wave, all in flight together
+#ifndef QUEST_EST_ITER
+#define QUEST_EST_ITER 4
+#endif
+constexpr int kEstIter = QUEST_EST_ITER;  // load instructions per tensor per wave, all in flight together
 
 // Work is the flat list of (entry, kv head) rows in MEMORY order, so consecutive rows are
 // consecutive 256 B vectors: NHD -> entry-major (all heads of an entry are 8 KiB contiguous for
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict_
     for (int j = 0; j < kEstIter; ++j) {
         ok[j] = ent[j] < n_out;
         const half_t* p = data + page[j] * ms.page + (size_t)head[j] * ms.head + (size_t)(ecl[j] % S) * ms.entry + col * kVec;
-        mx[j] = ld8(p);
-        mn[j] = ld8(p + ms.v_off);
+        mx[j] = ld8_stream(p);
+        mn[j] = ld8_stream(p + ms.v_off);
         if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)head[j] * D + col * kVec));
     }
     if (!QPRE) {

@@ -245,14 +245,14 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                 left[T + t] = len1 - t * R;
                 // rows past the page's length exist in the pool (the page is allocated) but hold
                 // stale bytes; they are fetched only for the sequence's last page and masked in fold
-                k[t] = ld8(b0 + lane_off + t * step);
-                v[t] = ld8(b0 + lane_off + t * step + p.st.v_off);
+                k[t] = ld8_stream(b0 + lane_off + t * step);
+                v[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
             }
             if (has1) {  // wave-uniform
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    k[T + t] = ld8(b1 + lane_off + t * step);
-                    v[T + t] = ld8(b1 + lane_off + t * step + p.st.v_off);
+                    k[T + t] = ld8_stream(b1 + lane_off + t * step);
+                    v[T + t] = ld8_stream(b1 + lane_off + t * step + p.st.v_off);
                 }
                 fold_groups<D, 2 * T>(st, qv, k, v, left, row);
             } else {
