@@ -4,9 +4,9 @@
 // Reference behaviour restated (not translated): MaxPossibleSampleWithPagedKVCacheKernel,
 // kernels/include/decode/decode_attn.cuh:245-401, arithmetic compute_max_possible :137-168.
 // The reference launches one block per kv head (grid (1, H), :1131) which starves a 256-CU
-// part; here the (entry, head) rows are tiled in memory order: one workgroup = 64 rows
-// (2 entries x 32 heads at cfg 3 -> 1024 workgroups), each streaming 2 x 16 KiB contiguous
-// with all of its loads in flight at once (8 x 16 B per lane), no LDS.
+// part; here the (entry, head) rows are tiled: one workgroup = 8 entries x 8 heads = 64 rows
+// (1024 workgroups at cfg 3), each streaming 32 KiB with all of its loads in flight at once
+// (8 x 16 B per lane); LDS holds the tile's query vectors and the score transpose.
 //
 // Bit-exactness: per lane 8 consecutive features are accumulated left to right in fp32 (as the
 // reference kernel does, decode_attn.cuh:152-156); the 16 lanes of a row are then reduced with the
@@ -18,14 +18,9 @@
 
 namespace quest {
 
-#ifndef QUEST_EST_ITER
-#define QUEST_EST_ITER 4
-#endif
-constexpr int kEstIter = QUEST_EST_ITER;  // load instructions per tensor per wave, all in flight together
+constexpr int kEstIter = 4;   // load instructions per tensor per wave, all in flight together
+constexpr int kEstWaves = 4;  // waves per workgroup
 
-// Work is the flat list of (entry, kv head) rows in MEMORY order, so consecutive rows are
-// consecutive 256 B vectors: NHD -> entry-major (all heads of an entry are 8 KiB contiguous for
-// H=32), HND -> (page, head, slot).  A wave takes kEstIter*R consecutive rows, a workgroup 4 waves.
 struct AppendTail {  // optional decode-append riding in the same launch (blocks >= est_blocks)
     quest_paged_kv_t kv;
     const uint16_t* key;
@@ -34,127 +29,179 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
     uint32_t enabled;
     const quest_step_state_t* state;  // optional device-resident lengths / last-page ids (graph replay)
     uint32_t o_stride;                // row stride of o (== n_out unless state-driven)
+    uint32_t tile_heads;              // kv heads per workgroup tile (power of two dividing num_heads, <= 8)
 };
 
+// Workgroup tile = EW entries x HW kv heads = 64 rows (D = 128): HW = tile_heads (8 for 8 or 32 kv heads), so
+// a tile reads HW*256 B contiguous per entry (NHD) or EW*256 B contiguous per head (HND) for max and for
+// min, and produces EW consecutive scores for each of its HW*G query heads.  Row order inside the tile
+// follows memory: NHD head-fastest, HND entry-fastest.
+//
+//   1. the tile's query vectors are requested first and parked in LDS split as q+ = max(q,0) and
+//      q- = min(q,0) (exact in fp16), so max(q*Kmax, q*Kmin) becomes two FMAs per feature (one product is
+//      an exact zero; fp16 x fp16 is exact in fp32 -> bit-identical to `acc += max(q*Kmax, q*Kmin)`,
+//      decode_attn.cuh:152-156) with both FMA operands taken as fp16 by v_fma_mix_f32;
+//   2. page-table entries, then all 2*kEstIter metadata loads of the wave (streaming, nt) are issued;
+//   3. scores are transposed through LDS and leave as EW-long contiguous runs per query head (the 2-byte
+//      scattered stores of the first version cost 0.7 us at MHA and 1.5 us at GQA-4 in write amplification).
 template <int D, int G, bool HND>
-__global__ __launch_bounds__(256) void estimate_kernel(const half_t* __restrict__ q, half_t* __restrict__ o,
-                                                       quest_paged_kv_t meta, uint32_t n_out, AppendTail tail) {
+__global__ __launch_bounds__(kEstWaves* kWave) void estimate_kernel(const half_t* __restrict__ q, half_t* __restrict__ o,
+                                                                    quest_paged_kv_t meta, uint32_t n_out,
+                                                                    AppendTail tail) {
+    constexpr int LPR = D / kVec;   // lanes per row
+    constexpr int R = kWave / LPR;  // rows per load instruction
+    constexpr int ROWS = kEstWaves * kEstIter * R;
     // n_out as passed bounds every address (state-driven launches pass the largest n_out the graph will
-    // see; page tables and pools cover it).  The live n_out is read from the state AFTER the page-table
-    // loads are issued, so that scalar load overlaps them instead of preceding them.
+    // see; page tables and pools cover it); the live n_out comes from the state further down.
     const uint32_t n_cap = n_out;
-    if (tail.state && tail.enabled && blockIdx.x >= tail.est_blocks) {
-        const quest_step_state_t st = *tail.state;
-        meta.last_page_len = (uint32_t)st.meta_last_page_len;
-        meta.last_page_idx = st.meta_last_page_idx;
-        tail.kv.last_page_len = (uint32_t)st.kv_last_page_len;
-        tail.kv.last_page_idx = st.kv_last_page_idx;
-    }
     if (tail.enabled && blockIdx.x >= tail.est_blocks) {
+        if (tail.state) {
+            const quest_step_state_t st = *tail.state;
+            meta.last_page_len = (uint32_t)st.meta_last_page_len;
+            meta.last_page_idx = st.meta_last_page_idx;
+            tail.kv.last_page_len = (uint32_t)st.kv_last_page_len;
+            tail.kv.last_page_idx = st.kv_last_page_idx;
+        }
         // The appended token only touches the CURRENT page's KV entry and metadata entry (index n_out),
         // which the estimate excludes (e < n_out), so the two halves of the launch share no byte.
         append_decode_body(tail.kv, meta, tail.key, tail.value, (blockIdx.x - tail.est_blocks) * 256 + threadIdx.x);
         return;
     }
-    constexpr int LPR = D / kVec;   // lanes per row
-    constexpr int R = kWave / LPR;  // rows per load instruction
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char est_smem[];
+    const uint32_t HW = tail.tile_heads, EW = ROWS / HW;
+    half_t* qp_s = reinterpret_cast<half_t*>(est_smem);          // [HW*G][D]  max(q, 0)
+    half_t* qn_s = qp_s + (size_t)HW * G * D;                     // [HW*G][D]  min(q, 0)
+    half_t* out_s = qn_s + (size_t)HW * G * D;                    // [HW*G][EW] scores
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t Hkv = meta.num_heads, S = meta.page_size;
+    const uint32_t head_tiles = Hkv / HW;
+    const uint32_t et = blockIdx.x / head_tiles, ht = blockIdx.x % head_tiles;
+    const uint32_t e0 = et * EW, h0 = ht * HW;
     const PoolStrides ms = pool_strides(meta);
     const half_t* data = reinterpret_cast<const half_t*>(meta.data);
     const int32_t* idx = meta.indices;  // batch_size == 1: indptr[0] == 0 (estimate.cu:14)
-    const uint32_t row0 = (blockIdx.x * 4 + wave) * (kEstIter * R) + row;
-    half8 mx[kEstIter], mn[kEstIter];
-    // MHA: q is requested together with the metadata (one extra 16 B load per row).  GQA: a row needs the
-    // G query vectors of its kv head; all Hq vectors (8 KiB for 32 x 128) are staged in LDS once per
-    // workgroup -- issued after the metadata loads so both are in flight together -- and read per (row, g).
-    constexpr int QPRE = (G == 1) ? 1 : 0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char est_smem[];
-    half_t* q_s = reinterpret_cast<half_t*>(est_smem);
-    float8 qv[kEstIter][QPRE ? 1 : 1];
-    uint32_t ent[kEstIter], head[kEstIter];
-    bool ok[kEstIter];
+
+    // (1) query vectors of this tile: HW*G contiguous heads starting at h0*G
+    constexpr int QV_PER_THREAD = 2;  // covers HW*G*D/8 <= 512 16-byte vectors
+    half8 qreg[QV_PER_THREAD];
+    const uint32_t q_vecs = HW * G * LPR;
+#pragma unroll
+    for (int t = 0; t < QV_PER_THREAD; ++t) {
+        const uint32_t vi = threadIdx.x + t * (kEstWaves * kWave);
+        qreg[t] = ld8(q + (size_t)h0 * G * D + (size_t)(vi < q_vecs ? vi : 0) * kVec);
+    }
+
+    // (2) rows of this wave: page-table entries first, then the metadata itself
+    uint32_t el[kEstIter], hl[kEstIter];
     size_t page[kEstIter];
     uint32_t ecl[kEstIter];
 #pragma unroll
     for (int j = 0; j < kEstIter; ++j) {
-        const uint32_t r = row0 + j * R;
-        uint32_t e, hk;
-        if (HND) {
-            const uint32_t per_page = Hkv * S;
-            const uint32_t pg = r / per_page, rem = r % per_page;
-            hk = rem / S;
-            e = pg * S + rem % S;
-        } else {
-            e = r / Hkv;
-            hk = r % Hkv;
-        }
-        ent[j] = e;
-        head[j] = hk;
-        // Loads are unconditional from a clamped entry: a predicated load compiles to branch + load +
-        // wait and serialises the kEstIter round trips.  Clamped rows re-read the last entry (tail only).
+        const uint32_t r = (wave * kEstIter + j) * R + row;  // row inside the tile
+        el[j] = HND ? r % EW : r / HW;
+        hl[j] = HND ? r / EW : r % HW;
+        const uint32_t e = e0 + el[j];
+        // Loads are unconditional from a clamped entry: a predicated load compiles to branch + load + wait
+        // and serialises the round trips.  Clamped rows re-read the last entry (tail tiles only).
         ecl[j] = e < n_cap ? e : n_cap - 1;
         page[j] = (size_t)idx[ecl[j] / S];
     }
-    if (tail.state) {  // live length (<= n_cap); whole workgroups past it have nothing to do
+    if (tail.state) {  // live length (<= n_cap); whole tiles past it have nothing to do
         n_out = (uint32_t)(tail.state->n_pages - 1);
-        const uint32_t first = blockIdx.x * 4 * (kEstIter * R);
-        const uint32_t first_entry = HND ? (first / (Hkv * S)) * S : first / Hkv;
-        if (first_entry >= n_out) return;
+        if (e0 >= n_out) return;
     }
+    half8 mx[kEstIter], mn[kEstIter];
 #pragma unroll
     for (int j = 0; j < kEstIter; ++j) {
-        ok[j] = ent[j] < n_out;
-        const half_t* p = data + page[j] * ms.page + (size_t)head[j] * ms.head + (size_t)(ecl[j] % S) * ms.entry + col * kVec;
+        const half_t* p = data + page[j] * ms.page + (size_t)(h0 + hl[j]) * ms.head + (size_t)(ecl[j] % S) * ms.entry +
+                          col * kVec;
         mx[j] = ld8_stream(p);
         mn[j] = ld8_stream(p + ms.v_off);
-        if (QPRE) qv[j][0] = to_f32(ld8(q + (size_t)head[j] * D + col * kVec));
-    }
-    if (!QPRE) {
-        const uint32_t total = Hkv * G * D;
-        for (uint32_t i = threadIdx.x * kVec; i < total; i += 256 * kVec) st8(q_s + i, ld8(q + i));
-        __syncthreads();
     }
 
+    // q -> LDS (these loads are older than the metadata loads, so this does not wait for them)
+#pragma unroll
+    for (int t = 0; t < QV_PER_THREAD; ++t) {
+        const uint32_t vi = threadIdx.x + t * (kEstWaves * kWave);
+        if (vi < q_vecs) {
+            half8 pos, neg;
+#pragma unroll
+            for (int i = 0; i < kVec; ++i) {
+                const half_t x = qreg[t][i];
+                pos[i] = x > (half_t)0 ? x : (half_t)0;
+                neg[i] = x < (half_t)0 ? x : (half_t)0;
+            }
+            st8(qp_s + (size_t)vi * kVec, pos);
+            st8(qn_s + (size_t)vi * kVec, neg);
+        }
+    }
+    __syncthreads();
+
+    // (3) scores
 #pragma unroll
     for (int j = 0; j < kEstIter; ++j) {
         const float8 a = to_f32(mx[j]), b = to_f32(mn[j]);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float8 qg;
-            if (QPRE) qg = qv[j][0];
-            else qg = to_f32(ld8(q_s + ((size_t)head[j] * G + g) * D + col * kVec));
+            const uint32_t qh = hl[j] * G + g;  // query head inside the tile
+            const float8 qp = to_f32(ld8(qp_s + (size_t)qh * D + col * kVec));
+            const float8 qn = to_f32(ld8(qn_s + (size_t)qh * D + col * kVec));
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < kVec; ++i) acc += __builtin_fmaxf(qg[i] * a[i], qg[i] * b[i]);
+            for (int i = 0; i < kVec; ++i) {
+                acc = __builtin_fmaf(qp[i], a[i], acc);
+                acc = __builtin_fmaf(qn[i], b[i], acc);
+            }
             acc = row_allreduce_sum_fast<LPR>(acc);
-            if (ok[j] && col == 0) o[((size_t)head[j] * G + g) * tail.o_stride + ent[j]] = (half_t)acc;
+            if (col == 0) out_s[qh * EW + el[j]] = (half_t)acc;
         }
     }
+    __syncthreads();
+    const uint32_t n_scores = HW * G * EW;
+    for (uint32_t t = threadIdx.x; t < n_scores; t += kEstWaves * kWave) {
+        const uint32_t qh = t / EW, e = e0 + t % EW;
+#ifdef QUEST_EST_NOSTORE
+        if (e < n_out && out_s[t] == (half_t)12345.f)
+#else
+        if (e < n_out)
+#endif
+            o[((size_t)h0 * G + qh) * tail.o_stride + e] = out_s[t];
+    }
+}
+
+// kv heads per tile: the largest power of two <= 8 that divides num_heads and whose query vectors
+// (hw * G * D/8 sixteen-byte vectors) fit the two-per-thread staging pass
+static uint32_t pick_tile_heads(uint32_t num_heads, uint32_t G, uint32_t lpr) {
+    for (uint32_t hw = 8; hw > 1; hw >>= 1)
+        if (num_heads % hw == 0 && hw * G * lpr <= 2u * kEstWaves * kWave) return hw;
+    return 1;
 }
 
 template <int D, int G>
 static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, AppendTail tail,
                            hipStream_t s) {
     constexpr int R = kWave / (D / kVec);
+    constexpr uint32_t ROWS = kEstWaves * kEstIter * R;
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
     if (!tail.state) tail.o_stride = n_out;
-    const uint64_t entries = hnd ? (uint64_t)((n_out + meta.page_size - 1) / meta.page_size) * meta.page_size : n_out;
-    const uint64_t rows = entries * meta.num_heads;
-    const uint32_t rows_per_block = 4 * kEstIter * R;
-    tail.est_blocks = (uint32_t)((rows + rows_per_block - 1) / rows_per_block);
+    const uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec), ew = ROWS / hw;
+    tail.tile_heads = hw;
+    tail.est_blocks = ((n_out + ew - 1) / ew) * (meta.num_heads / hw);
     uint32_t blocks = tail.est_blocks;
     if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + 255) / 256;
     if (blocks == 0) return 0;
     dim3 grid(blocks);
-    const size_t lds = G == 1 ? 0 : (size_t)meta.num_heads * G * D * sizeof(half_t);  // staged q (GQA only)
-    if (lds > 64 * 1024) return QUEST_EUNSUPPORTED;
+    const size_t lds = (size_t)hw * G * (2 * D + ew) * sizeof(half_t);
+    if (hw * G * (D / kVec) > 2 * kEstWaves * kWave) return QUEST_EUNSUPPORTED;  // q staging capacity
     if (hnd)
-        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(256), lds, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
+        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q,
+                           (half_t*)o, meta, n_out, tail);
     else
-        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(256), lds, s, (const half_t*)q, (half_t*)o, meta, n_out, tail);
+        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q,
+                           (half_t*)o, meta, n_out, tail);
     QUEST_LAUNCH_CHECK();
     return 0;
 }
