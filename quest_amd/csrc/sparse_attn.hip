@@ -26,7 +26,6 @@
 
 namespace quest {
 
-constexpr int kDecWaves = 4;  // default waves per workgroup (NW template parameter)
 constexpr float kNegFloor = -1.0e30f;  // finite "-inf": exp2(floor - floor) stays finite, weights it carries are 0
 
 struct DecodeParams {
@@ -129,8 +128,8 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const uint32_t slot_begin = chunk * p.pages_per_chunk;
     const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
 
-    float8 qv = to_f32(ld8(p.q + (size_t)hq * D + col * kVec));
-    qv *= p.scale_log2;
+    // q is requested now but first used after the top-k front end, so its latency hides under the selection
+    const half8 q_raw = ld8(p.q + (size_t)hq * D + col * kVec);
 
     const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
     const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
@@ -218,6 +217,8 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                 }
         }
     }
+    float8 qv = to_f32(q_raw);
+    qv *= p.scale_log2;
     // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
     auto slot_page = [&](uint32_t slot) -> int32_t {
         if (slot >= p.n_sel) return p.last_page_idx;
@@ -362,6 +363,36 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
     for (int j = 0; j < kPre; ++j) {
         const uint32_t c = g + j * kMergeGroups, cc = c < n_chunks ? c : n_chunks - 1;  // clamped: no branch
         pre[j] = w[(size_t)cc * ws_stride + f];
+    }
+    if (n_chunks <= (uint32_t)kWave && n_chunks <= (uint32_t)(kPre * kMergeGroups)) {
+        // Common case (<= 32 chunks): every wave derives the chunk weights by itself -- lane c holds chunk
+        // c's (m, d) -- so the only workgroup barrier is the final cross-group sum.
+        const uint32_t lane = tid & 63, lc = lane < n_chunks ? lane : n_chunks - 1;
+        const float m_c = w[(size_t)lc * ws_stride + D], d_c = w[(size_t)lc * ws_stride + D + 1];
+        float Mw = lane < n_chunks ? m_c : kNegFloor;
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) Mw = __builtin_fmaxf(Mw, __shfl_xor(Mw, off, kWave));
+        const float e_c = lane < n_chunks ? __builtin_amdgcn_exp2f(m_c - Mw) : 0.f;
+        float dn = e_c * d_c;
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) dn += __shfl_xor(dn, off, kWave);
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const uint32_t c = g + j * kMergeGroups;  // wave-uniform (a wave lies inside one group: D >= 64)
+            const float wc = __shfl(e_c, (int)(c < n_chunks ? c : 0), kWave);
+            if (c < n_chunks) a += wc * pre[j];
+        }
+        s_red[g][f] = a;
+        __syncthreads();
+        if (g == 0) {
+            float tot = s_red[0][f];
+#pragma unroll
+            for (int j = 1; j < kMergeGroups; ++j) tot += s_red[j][f];
+            o[(size_t)hq * D + f] = (half_t)(tot / dn);
+            if (lse && f == 0) lse[hq] = (Mw + __builtin_amdgcn_logf(dn)) * 0.6931471805599453f;
+        }
+        return;
     }
     // pass 1: chunk maxima -> M, weights, denominator
     float M = kNegFloor;
@@ -555,9 +586,9 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         if (h->pages_per_chunk > (uint32_t)kFusedMaxPpc) return QUEST_EUNSUPPORTED;
         // beyond 4096 pages the per-workgroup selection (>= 32 keys per thread, repeated by every
         // workgroup of the head) costs more than the stand-alone top-k launch it replaces (measured at
-        // 8191 pages: 33.9 vs 30.1 us) -> tell the caller to take the two-launch path.  State-driven
+        // 8191 pages: 33.7 vs 28.2 us) -> tell the caller to take the two-launch path.  State-driven
         // launches pass a capacity, not a length (the work follows the live length), so they are exempt.
-        if (!state && n_scores > 16u * kDecWaves * kWave) return QUEST_EUNSUPPORTED;
+        if (!state && n_scores > 8u * 8u * kWave) return QUEST_EUNSUPPORTED;
     } else if (h->n_sel > 0 && (!kv.indices || kv.page_budget < h->n_sel)) {
         return QUEST_EINVAL;
     }
