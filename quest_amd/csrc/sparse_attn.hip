@@ -52,6 +52,8 @@ struct DecodeParams {
     int32_t* sel_idx_out;    // optional [Hq][n_sel]
     uint32_t ws_stride;  // floats per partial record (>= D + 2, multiple of 32 -> records own whole 128 B lines)
     uint32_t score_stride;  // row stride of `scores`
+    uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
+    uint32_t ids_lds_offset;
     const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
 };
 
@@ -171,7 +173,6 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     }
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
-        constexpr bool PRE = FC <= 16;  // page ids of the owned columns fetched with the scores
         if (p.state) {  // live lengths (the column ownership below depends on the live row length)
             const quest_step_state_t st = *p.state;
             p.n_scores = (uint32_t)(st.n_pages - 1);
@@ -179,23 +180,41 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             p.last_page_idx = st.kv_last_page_idx;
         }
         const uint32_t n = p.n_scores;
-        const uint32_t cpt = topk_cols_per_thread<NW * kWave>(n);  // <= FC (FC is sized for n_cap >= n)
+        constexpr int NT = NW * kWave;
+        const uint32_t cpt = topk_cols_per_thread<NT>(n);  // <= FC (FC is sized for n_cap >= n)
         const uint32_t c0 = threadIdx.x * cpt;
         const uint16_t* srow = p.scores + (size_t)hq * p.score_stride;
         const int32_t* table = p.indices;
-        uint32_t key[FC];
-        int32_t pid[PRE ? FC : 1];
+        // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
+        extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
+        uint16_t* keys_s = reinterpret_cast<uint16_t*>(fe_dyn);
+        const bool stage_ids = p.stage_ids != 0;
+        int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
+        uint16_t kraw[FC];
+        int32_t iraw[FC];
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
-            // clamped, UNCONDITIONAL loads (any guard here becomes a branch with a wait per load); slots
-            // i >= cpt re-read the row's last column and are ignored by the in-range tests below
-            const uint32_t cc = c0 + i < n ? c0 + i : n - 1;
-            key[i] = half_key(srow[cc]);
-            if (PRE) pid[i] = table[cc];
+            const uint32_t e = threadIdx.x + i * NT, ec = e < n ? e : n - 1;  // clamped, unconditional
+            kraw[i] = srow[ec];
+            iraw[i] = stage_ids ? table[ec] : 0;
         }
-        topk_clear<NW * kWave>(sm);  // overlaps the score / page-id loads above
+        topk_clear<NT>(sm);  // overlaps the score / page-id loads above
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const uint32_t e = threadIdx.x + i * NT;
+            if (e < n) {
+                keys_s[e] = (uint16_t)half_key(kraw[i]);
+                if (stage_ids) ids_s[e] = iraw[i];
+            }
+        }
         __syncthreads();
-        TopkCursor cur = topk_select<NW * kWave, FC>(sm, key, n, p.n_sel, cpt);
+        uint32_t key[FC];
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const uint32_t c = c0 + i;
+            key[i] = keys_s[c < n ? c : n - 1];
+        }
+        TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt);
         uint32_t my_slot[FC];
         bool mine[FC];
 #pragma unroll
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             uint32_t slot;
             mine[i] = topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot) && slot >= slot_begin && slot < slot_end;
             my_slot[i] = slot;
-            if (mine[i]) s_sel[slot - slot_begin] = PRE ? pid[i] : table[c0 + i];
+            if (mine[i]) s_sel[slot - slot_begin] = stage_ids ? ids_s[c0 + i] : table[c0 + i];
         }
         __syncthreads();
         // optional copy of the selection for callers that inspect it: issued after the barrier so no
@@ -542,12 +561,13 @@ template <int D, int FC>
 static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t waves,
                             hipStream_t s) {
     dim3 grid(h->n_chunks, num_qo_heads);
+    const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)p.n_scores * 4 : 0) : 0;
     if (p.page_size == 16 && waves == 8)
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), 0, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), lds, s, p);
     else if (p.page_size == 16)
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 4>), grid, dim3(4 * kWave), 0, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 4>), grid, dim3(4 * kWave), lds, s, p);
     else
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), 0, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), lds, s, p);
     QUEST_LAUNCH_CHECK();
     if (h->n_chunks > 1) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D * kMergeGroups), 0, s,
@@ -619,6 +639,8 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.sel_idx_out = topk_idx_out;
     p.ws_stride = h->ws_stride;
     p.score_stride = score_stride ? score_stride : n_scores;
+    p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
+    p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
     p.state = state;
     // fc < 0: single-wave selection with -fc columns per lane (rows <= 4096); fc > 0: block selection
     int fc = 0;

@@ -18,15 +18,25 @@ namespace quest {
 
 constexpr int kTkThreads = 1024;
 
-// C = columns per thread (compile-time bound, n <= C * 1024).  Thread t owns the contiguous columns
-// [t*C, t*C+C): their keys and page ids stay in registers for the whole kernel, so the only global
-// traffic is one round of loads at the top and the k output stores at the bottom.
+// C = columns per thread (compile-time bound, n <= C * 1024).
+//
+// Loads are COALESCED (element t + i*1024 for thread t) and parked in LDS as 16-bit keys (+ the page ids
+// when they fit); every thread then reads back the contiguous columns [t*cpt, t*cpt+cpt) it owns for the
+// selection.  (Loading the owned columns directly is a 16 B-strided 2-byte gather per instruction: at
+// 8191 columns that alone cost ~6 us of address-unit time.)
+constexpr uint32_t kTkStageIdsMax = 8192;  // page ids are staged in LDS up to this row length (32 KiB)
+
 template <int C>
 __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __restrict__ vals,
                                                           const int32_t* __restrict__ in_idx,
                                                           uint16_t* __restrict__ out_val,
                                                           int32_t* __restrict__ out_idx, uint32_t n, uint32_t k) {
     __shared__ TopkSmem<kTkThreads> sm;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tk_dyn[];
+    uint16_t* keys_s = reinterpret_cast<uint16_t*>(tk_dyn);
+    const bool stage_ids = n <= kTkStageIdsMax;
+    int32_t* ids_s = reinterpret_cast<int32_t*>(tk_dyn + (((size_t)n * 2 + 15) & ~(size_t)15));
+
     const uint32_t tid = threadIdx.x;
     const size_t row = blockIdx.x;
     const uint16_t* v = vals + row * n;
@@ -34,18 +44,30 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
     const uint32_t cpt = topk_cols_per_thread<kTkThreads>(n);
     const uint32_t c0 = tid * cpt;
 
-    uint32_t key[C];
-    int32_t pid[C];
+    uint16_t kraw[C];
+    int32_t iraw[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        // unconditional loads from a clamped column (a predicated load becomes branch + load + wait,
-        // which serialises the round trips); out-of-range columns are masked later
-        const uint32_t c = c0 + i, cc = c < n ? c : n - 1;
-        key[i] = half_key(v[cc]);
-        pid[i] = ii[cc];
+        const uint32_t e = tid + i * kTkThreads, ec = e < n ? e : n - 1;  // clamped, unconditional
+        kraw[i] = v[ec];
+        iraw[i] = stage_ids ? ii[ec] : 0;
     }
     topk_clear<kTkThreads>(sm);  // overlaps the loads above
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const uint32_t e = tid + i * kTkThreads;
+        if (e < n) {
+            keys_s[e] = (uint16_t)half_key(kraw[i]);
+            if (stage_ids) ids_s[e] = iraw[i];
+        }
+    }
     __syncthreads();
+    uint32_t key[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const uint32_t c = c0 + i;
+        key[i] = keys_s[c < n ? c : n - 1];
+    }
     TopkCursor cur = topk_select<kTkThreads, C>(sm, key, n, k, cpt);
     uint16_t* ov = out_val + row * k;
     int32_t* oi = out_idx + row * k;
@@ -54,7 +76,7 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
         uint32_t slot;
         if (topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot)) {
             ov[slot] = key_to_half_bits(key[i]);
-            oi[slot] = pid[i];
+            oi[slot] = stage_ids ? ids_s[c0 + i] : ii[c0 + i];
         }
     }
 }
@@ -109,8 +131,9 @@ extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* 
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* ev = (const uint16_t*)estimated_value;
     uint16_t* dv = (uint16_t*)d_out;
-#define QUEST_TOPK_LAUNCH(CC)                                                                              \
-    hipLaunchKernelGGL((topk_kernel<CC>), dim3(num_heads), dim3(kTkThreads), 0, s, ev, estimated_indices, dv, \
+    const size_t tk_lds = (((size_t)num_pages * 2 + 15) & ~(size_t)15) + (num_pages <= kTkStageIdsMax ? (size_t)num_pages * 4 : 0);
+#define QUEST_TOPK_LAUNCH(CC)                                                                                   \
+    hipLaunchKernelGGL((topk_kernel<CC>), dim3(num_heads), dim3(kTkThreads), tk_lds, s, ev, estimated_indices, dv, \
                        indices_out, num_pages, page_budget)
 #define QUEST_TOPK_WAVE(CC)                                                                                 \
     hipLaunchKernelGGL((topk_wave_kernel<CC>), dim3(num_heads), dim3(kWave), 0, s, ev, estimated_indices, dv, \
