@@ -52,6 +52,7 @@ def main():
     a0 = ap.parse_args()
     sys.argv = [sys.argv[0]]
     a = bench.parse()
+    a.mode = "graph-static"  # per-op timing uses the by-value (reference-signature) entry points
     a.layers, a.layout, a.seqlen, a.token_budget, a.heads, a.kv_heads = (a0.layers, a0.layout, a0.seqlen,
                                                                         a0.token_budget, a0.heads, a0.kv_heads)
     dev = torch.device("cuda", 0)
