@@ -533,3 +533,34 @@ def test_quest_attention_module_decode_matches_unfused():
         outs.append(out.float().cpu())
     assert outs[0].shape == (1, 1, 1024)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_llama_model_decode_runs_with_layer_skip():
+    """quest_amd.models.llama: quest_init / forward / quest_clear surface of the reference's model fork; the
+    first two layers decode dense, the rest sparse, and the result equals the op-by-op (unfused) model."""
+    from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
+
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
+                      num_attention_heads=4, num_key_value_heads=2)
+    logits = []
+    for fused in (True, False):
+        torch.manual_seed(7)
+        with torch.device(dev):
+            m = LlamaForCausalLM(cfg, fused=fused).half()
+        for p_ in m.parameters():
+            p_.data.normal_(0, 0.05)
+        m.quest_init(16, 1024, token_budget=64)
+        ids = torch.arange(200, device=dev)[None] % 512
+        with torch.inference_mode():
+            m(input_ids=ids)                               # prefill 200 tokens (13 pages > 4-page budget)
+            out = None
+            for t in range(20):                            # decode across a page boundary
+                out = m(input_ids=torch.tensor([[(7 * t) % 512]], device=dev))
+        ctl = m.model.iController
+        assert ctl.kv_cache.seqlen == 220 and ctl.inference_page_budget == 4
+        logits.append(out.float().cpu())
+        m.quest_clear()
+        assert ctl.kv_cache.seqlen == 0
+    assert logits[0].shape == (1, 1, 512) and torch.isfinite(logits[0]).all()
+    assert torch.equal(logits[0], logits[1])
