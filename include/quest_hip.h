@@ -140,6 +140,15 @@ int quest_decode_forward(quest_decode_handler_t* h, const void* q, void* o, ques
                          uint32_t num_qo_heads, float* lse, quest_stream_t stream);
 
 /*
+ * forward for the case where every query head attends the SAME page list (what the reference passes as
+ * kv_indices_without_last.repeat(num_heads, 1) when the budget covers the cache, controller.py:106,
+ * QuestAttention.py:125-132): paged_kv.indices = ONE row [n_selected_pages].  With GQA the K/V tiles of
+ * a kv head are then fetched once for its whole query group.  page_size 16, head_dim 64/128.
+ */
+int quest_decode_forward_shared(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                uint32_t num_qo_heads, float* lse, quest_stream_t stream);
+
+/*
  * Fused form of decode_topk + decode_sparse_attn (QuestAttention.py:144-157): the top-k selection of
  * quest_topk_filtering runs at the head of the attention kernel (every workgroup of a head recomputes
  * it from the head's score row -- a 4 KiB L2-resident read -- so no second launch and no cross-workgroup

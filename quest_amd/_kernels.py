@@ -345,6 +345,25 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         check(lib.quest_decode_forward(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), None, _stream(q)),
               "BatchDecodeWithPagedKVCache")
 
+    def forward_shared(self, q, o, paged_kv_data, page_list, paged_kv_last_page_len: int,
+                       paged_kv_last_page_idx: int) -> bool:
+        """EXTENSION: forward when all query heads share ONE page list ``[n_selected]`` (full-KV decode).  With
+        GQA each K/V tile is fetched once per kv head.  False (nothing launched) if the shape is outside the
+        shared kernel's set (page_size 16, head_dim 64/128)."""
+        _check_input(q, "q")
+        _check_input(o, "o")
+        _check_input(paged_kv_data, "paged_kv_data")
+        _check_input(page_list, "page_list")
+        _check_dim(1, page_list, "page_list")
+        _check_eq(page_list.dtype, torch.int32, "page_list.scalar_type(), torch::kInt32")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, page_list, None, paged_kv_last_page_len, paged_kv_last_page_idx, self._layout)
+        code = lib.quest_decode_forward_shared(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), None, _stream(q))
+        if code == -2:
+            return False
+        check(code, "BatchDecodeWithPagedKVCache")
+        return True
+
     def forward_fused_topk(self, q, o, paged_kv_data, page_table, scores, topk_val_out, topk_idx_out,
                            paged_kv_last_page_len: int, paged_kv_last_page_idx: int) -> bool:
         """EXTENSION: topk_filtering + forward in one launch.  ``page_table`` is the sequence's page table

@@ -46,6 +46,7 @@ SIGNATURES = {
     "quest_decode_begin_forward": (ctypes.c_int, [c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp]),
     "quest_decode_end_forward": (ctypes.c_int, [c_vp]),
     "quest_decode_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp]),
+    "quest_decode_forward_shared": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp]),
     "quest_decode_forward_fused_topk": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_vp, c_vp,
                                                         c_vp, c_vp]),
     "quest_step_state_advance": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_vp]),

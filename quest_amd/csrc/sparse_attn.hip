@@ -358,6 +358,128 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Group-shared variant: all GS query heads of a kv head attend the SAME page list (full-KV decode: the
+// model's dense first layers, contexts shorter than the budget).  One workgroup per (chunk, kv head)
+// fetches each K/V tile once and folds it into GS online-softmax states, instead of once per query head
+// as the per-head-list kernel above would (4x the traffic at Llama-3 GQA).  Same work split, same partial
+// records, same merge kernel.
+template <int D, int GS, int NW>
+__global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(DecodeParams p) {
+    constexpr int LPR = D / kVec, R = kWave / LPR, S_T = 16, T = (S_T + R - 1) / R;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = lane / LPR, col = lane % LPR;
+    const uint32_t chunk = blockIdx.x, hk = blockIdx.y;
+    const uint32_t n_slots = p.n_sel + 1;
+    const uint32_t slot_begin = chunk * p.pages_per_chunk;
+    const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
+
+    float8 qv[GS];
+#pragma unroll
+    for (int g = 0; g < GS; ++g) {
+        qv[g] = to_f32(ld8(p.q + ((size_t)hk * GS + g) * D + col * kVec));
+        qv[g] *= p.scale_log2;
+    }
+    const half_t* head_base = p.kv + (size_t)hk * p.st.head;
+    const uint32_t lane_off = row * p.st.entry + col * kVec;
+    const uint32_t step = R * p.st.entry;
+    RowState<D> st[GS];
+
+    for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += NW) {
+        const int32_t pg = __builtin_amdgcn_readfirstlane(s0 < p.n_sel ? p.indices[s0] : p.last_page_idx);
+        const int len = s0 < p.n_sel ? S_T : (int)p.last_page_len;
+        const half_t* b0 = head_base + (size_t)pg * p.st.page;
+        half8 k[T], v[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            k[t] = ld8_stream(b0 + lane_off + t * step);
+            v[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
+        }
+        float8 kf[T], vf[T];
+        bool valid[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            valid[t] = row < len - t * R;
+            kf[t] = to_f32(k[t]);
+            vf[t] = valid[t] ? to_f32(v[t]) : (float8)(0.f);  // stale rows past the page length: select
+        }
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            float sc[T];
+            float m_new = st[g].m;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < kVec; ++i) dot = __builtin_fmaf(qv[g][i], kf[t][i], dot);
+                dot = row_allreduce_sum_fast<LPR>(dot);
+                sc[t] = valid[t] ? dot : kNegFloor;
+                m_new = __builtin_fmaxf(m_new, sc[t]);
+            }
+            const float scale = __builtin_amdgcn_exp2f(st[g].m - m_new);
+            st[g].d *= scale;
+            st[g].acc *= scale;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float pr = valid[t] ? __builtin_amdgcn_exp2f(sc[t] - m_new) : 0.f;
+                st[g].d += pr;
+#pragma unroll
+                for (int i = 0; i < kVec; ++i) st[g].acc[i] = __builtin_fmaf(pr, vf[t][i], st[g].acc[i]);
+            }
+            st[g].m = m_new;
+        }
+    }
+
+    __shared__ float s_acc[NW][GS][D];
+    __shared__ float s_md[NW][GS][2];
+#pragma unroll
+    for (int g = 0; g < GS; ++g) {
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1) {  // rows of the wave -> one state
+            const float m_o = __shfl_xor(st[g].m, off, kWave), d_o = __shfl_xor(st[g].d, off, kWave);
+            const float m_n = __builtin_fmaxf(st[g].m, m_o);
+            const float a = __builtin_amdgcn_exp2f(st[g].m - m_n), b = __builtin_amdgcn_exp2f(m_o - m_n);
+            st[g].d = st[g].d * a + d_o * b;
+#pragma unroll
+            for (int i = 0; i < kVec; ++i) st[g].acc[i] = st[g].acc[i] * a + __shfl_xor(st[g].acc[i], off, kWave) * b;
+            st[g].m = m_n;
+        }
+        if (row == 0) {
+#pragma unroll
+            for (int i = 0; i < kVec; ++i) s_acc[wave][g][col * kVec + i] = st[g].acc[i];
+            if (col == 0) {
+                s_md[wave][g][0] = st[g].m;
+                s_md[wave][g][1] = st[g].d;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < (uint32_t)(GS * D); t += NW * kWave) {
+        const uint32_t g = t / D, f = t % D, hq = hk * GS + g;
+        float M = s_md[0][g][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) M = __builtin_fmaxf(M, s_md[w][g][0]);
+        float acc = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float e = __builtin_amdgcn_exp2f(s_md[w][g][0] - M);
+            acc += e * s_acc[w][g][f];
+            den += e * s_md[w][g][1];
+        }
+        if (p.n_chunks == 1) {
+            p.o[(size_t)hq * D + f] = (half_t)(acc / den);
+            if (p.lse && f == 0) p.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
+        } else {
+            float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
+            w[f] = acc;
+            if (f == 0) {
+                w[D] = M;
+                w[D + 1] = den;
+            }
+        }
+    }
+}
+
 // Merge the per-chunk partial states of a head, normalise, cast to fp16 (the job of flashinfer's
 // VariableLengthMergeStates).  kMergeGroups thread groups each take every kMergeGroups-th chunk with
 // all of their loads independent (unrolled), then combine through LDS: two memory round trips total.
@@ -475,6 +597,7 @@ struct quest_decode_handler {
     size_t ws_bytes = 0;
     uint32_t ws_stride = 0;
     uint32_t dec_waves = 4;
+    uint32_t shared_ppc = 0, shared_chunks = 0;  // plan of the group-shared kernel (grid.y = kv heads)
 };
 
 // Workgroups the planner aims for: the kernel is built for 2 workgroups (8 waves) per CU, so 512
@@ -529,9 +652,20 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     if ((n_slots + ppc - 1) / ppc > kMaxChunks) ppc = (n_slots + kMaxChunks - 1) / kMaxChunks;
     h->pages_per_chunk = ppc;
     h->n_chunks = (n_slots + ppc - 1) / ppc;
+    {   // the group-shared kernel runs one workgroup per (chunk, KV head): plan it for the same 512 workgroups
+        uint32_t chunks = kTargetWorkgroups / num_kv_heads;
+        if (chunks < 1) chunks = 1;
+        if (chunks > n_slots) chunks = n_slots;
+        if (chunks > kMaxChunks) chunks = kMaxChunks;
+        uint32_t sp = h->forced_ppc ? h->forced_ppc : (n_slots + chunks - 1) / chunks;
+        if ((n_slots + sp - 1) / sp > kMaxChunks) sp = (n_slots + kMaxChunks - 1) / kMaxChunks;
+        h->shared_ppc = sp;
+        h->shared_chunks = (n_slots + sp - 1) / sp;
+    }
     h->ws_stride = (head_dim + 2 + 31) / 32 * 32;
-    const size_t need = (size_t)num_qo_heads * h->n_chunks * h->ws_stride * sizeof(float);
-    if (h->n_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
+    const uint32_t max_chunks = h->n_chunks > h->shared_chunks ? h->n_chunks : h->shared_chunks;
+    const size_t need = (size_t)num_qo_heads * max_chunks * h->ws_stride * sizeof(float);
+    if (max_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
         if (h->ws) (void)hipFree(h->ws);
         h->ws = nullptr;
         h->ws_bytes = 0;
@@ -664,6 +798,58 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
 extern "C" int quest_decode_forward(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
                                     uint32_t num_qo_heads, float* lse, quest_stream_t stream) {
     return decode_entry(h, q, o, kv, num_qo_heads, nullptr, 0, nullptr, nullptr, lse, (hipStream_t)stream);
+}
+
+template <int D>
+static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t gs,
+                         hipStream_t s) {
+    dim3 grid(p.n_chunks, num_qo_heads / gs), block(4 * kWave);
+    switch (gs) {
+        case 1: hipLaunchKernelGGL((shared_decode_kernel<D, 1, 4>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((shared_decode_kernel<D, 2, 4>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((shared_decode_kernel<D, 4, 4>), grid, block, 0, s, p); break;
+        case 8: hipLaunchKernelGGL((shared_decode_kernel<D, 8, 4>), grid, block, 0, s, p); break;
+        default: return QUEST_EUNSUPPORTED;
+    }
+    QUEST_LAUNCH_CHECK();
+    if (p.n_chunks > 1) {
+        hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D * kMergeGroups), 0, s,
+                           (const float*)p.ws, p.o, p.lse, p.n_chunks, p.ws_stride);
+        QUEST_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int quest_decode_forward_shared(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
+                                           uint32_t num_qo_heads, float* lse, quest_stream_t stream) {
+    if (!h) return QUEST_EINVAL;
+    if (!h->started) return QUEST_ESTATE;
+    if (!q || !o || !kv.data || (h->n_sel > 0 && !kv.indices)) return QUEST_EINVAL;
+    if (kv.layout != h->layout || kv.head_dim != h->head_dim || kv.page_size != h->page_size ||
+        kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
+        return QUEST_EINVAL;
+    if (kv.last_page_len == 0 || kv.last_page_len > kv.page_size) return QUEST_EINVAL;
+    if (kv.page_size != 16 || (kv.head_dim != 64 && kv.head_dim != 128)) return QUEST_EUNSUPPORTED;
+    DecodeParams p{};
+    p.q = (const half_t*)q;
+    p.o = (half_t*)o;
+    p.lse = lse;
+    p.kv = (const half_t*)kv.data;
+    p.indices = kv.indices;
+    p.ws = h->ws;
+    p.st = pool_strides(kv);
+    p.n_sel = h->n_sel;
+    p.last_page_len = kv.last_page_len;
+    p.last_page_idx = kv.last_page_idx;
+    p.page_size = kv.page_size;
+    p.group = num_qo_heads / kv.num_heads;
+    p.pages_per_chunk = h->shared_ppc;
+    p.n_chunks = h->shared_chunks;
+    p.scale_log2 = (float)(1.4426950408889634 / sqrt((double)kv.head_dim));
+    p.ws_stride = h->ws_stride;
+    hipStream_t s = (hipStream_t)stream;
+    return kv.head_dim == 64 ? launch_shared<64>(h, p, num_qo_heads, p.group, s)
+                             : launch_shared<128>(h, p, num_qo_heads, p.group, s);
 }
 
 extern "C" int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,

@@ -99,6 +99,15 @@ def decode_sparse_attn(q: torch.Tensor, iController: InferenceController, layer_
     """Attention of q ``[1, Hq, D]`` over the pages in ``topk_indices`` ``[Hq, budget - 1]`` plus the
     current page."""
     o = torch.empty_like(q)
+    if topk_indices is iController.kv_indices_without_last and iController.kv_indices_with_last is not None:
+        # full-KV decode: every head attends the same pages (the tensor is the page table repeated per head,
+        # controller.py:106) -> one shared list, K/V fetched once per kv head (matters with GQA)
+        n_sel = topk_indices.size(1)
+        if iController._decode_handler.forward_shared(q, o, iController.kv_cache.buf_layer(layer_idx),
+                                                      iController.kv_indices_with_last[:n_sel],
+                                                      iController.kv_cache.last_page_len,
+                                                      iController.kv_last_page_idx):
+            return o
     iController._decode_handler.forward(q, o, iController.kv_cache.buf_layer(layer_idx), topk_indices,
                                         iController.kv_indptr_for_approx_decode, iController.kv_cache.last_page_len,
                                         iController.kv_last_page_idx, rope_scale, rope_theta)

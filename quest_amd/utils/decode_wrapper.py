@@ -33,6 +33,11 @@ class BatchDecodeWithPagedKVCacheWrapper:
                               paged_kv_last_page_idx, 1.0 if rope_scale is None else rope_scale,
                               1e4 if rope_theta is None else rope_theta)
 
+    def forward_shared(self, q, o, paged_kv_data, page_list, paged_kv_last_page_len: int,
+                       paged_kv_last_page_idx: int) -> bool:
+        return self._wrapper.forward_shared(q, o, paged_kv_data, page_list, paged_kv_last_page_len,
+                                            paged_kv_last_page_idx)
+
     def forward_fused_topk(self, q, o, paged_kv_data, page_table, scores, topk_val_out, topk_idx_out,
                            paged_kv_last_page_len: int, paged_kv_last_page_idx: int) -> bool:
         return self._wrapper.forward_fused_topk(q, o, paged_kv_data, page_table, scores, topk_val_out, topk_idx_out,

@@ -564,3 +564,21 @@ def test_llama_model_decode_runs_with_layer_skip():
         assert ctl.kv_cache.seqlen == 0
     assert logits[0].shape == (1, 1, 512) and torch.isfinite(logits[0]).all()
     assert torch.equal(logits[0], logits[1])
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,L,layout", [(8, 2, 128, 300, 0), (32, 8, 128, 2500, 1), (8, 1, 64, 777, 0),
+                                                (4, 4, 128, 100, 0), (8, 2, 256, 200, 0), (16, 2, 128, 5000, 0)])
+def test_dense_decode_shared_lists_gqa(Hq, Hkv, D, L, layout):
+    """Budget >= pages: all heads attend every page.  quest_amd routes this through the group-shared
+    kernel (K/V read once per kv head); D=256 exercises the fallback to per-head lists."""
+    qu = _qu()
+    q, k, v = inputs(600 + Hq + D + L, L, Hq, Hkv, D)
+    ctl = make_controller(L, Hq, Hkv, D, PAGE, 1 << 20, layout=layout, shuffle_seed=L)
+    fill(ctl, k, v)
+    assert not ctl.need_estimate()
+    o = qu.decode_sparse_attn(cuda(q), ctl, 0, ctl.kv_indices_without_last)
+    ctl.end_forward()
+    kv_o, _ = oracle_pools(ctl, k, v)
+    table = np.array(ctl.kv_cache.indicies, np.int32)
+    eo, _ = oracle.sparse_attn(q, kv_o, np.tile(table[:-1], (Hq, 1)), len(table) - 1, int(table[-1]), kv_o.last_page_len)
+    _close(o.cpu().numpy(), eo, tol=2e-3)
