@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const uint32_t chunk = blockIdx.x, hq = blockIdx.y, hk = hq / p.group;
     // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
     // row length comes from the state
-    if (FC <= 0 && p.state) {  // variants without the block-wide front end: plain up-front read
+    if (FC == 0 && p.state) {  // no front end (not reachable through the C ABI today): plain up-front read
         const quest_step_state_t st = *p.state;
         p.n_scores = (uint32_t)(st.n_pages - 1);
         p.last_page_len = (uint32_t)st.kv_last_page_len;
@@ -138,39 +138,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const int32_t* idx_row = p.indices + (size_t)hq * p.idx_stride;  // uniform
     RowState<D> st;
 
-    __shared__ int32_t s_sel[FC != 0 ? kFusedMaxPpc : 1];
-    if constexpr (FC < 0) {
-        // rows up to 64*(-FC) columns: wave 0 alone selects (no barriers inside), the other waves go
-        // straight to the one barrier below
-        constexpr int C = -FC;
-        __shared__ TopkWaveSmem wsm;
-        if (wave == 0) {
-            const uint32_t n = p.n_scores;
-            const uint16_t* srow = p.scores + (size_t)hq * p.score_stride;
-            const int32_t* table = p.indices;
-            uint32_t key[C];
-            int32_t pid[C];
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                const uint32_t c = i * kWave + lane, cc = c < n ? c : n - 1;  // clamped, unconditional loads
-                key[i] = half_key(srow[cc]);
-                pid[i] = table[cc];
-            }
-            const TopkWaveResult r = topk_select_wave<C>(wsm, key, n, p.n_sel, lane);
-            TopkWaveCursor cur;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                uint32_t slot;
-                if (topk_wave_take(cur, r, key[i], (uint32_t)(i * kWave + lane) < n, lane, slot) && slot >= slot_begin &&
-                    slot < slot_end) {
-                    s_sel[slot - slot_begin] = pid[i];
-                    if (p.sel_idx_out) p.sel_idx_out[(size_t)hq * p.n_sel + slot] = pid[i];
-                    if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + slot] = key_to_half_bits(key[i]);
-                }
-            }
-        }
-        __syncthreads();
-    }
+    __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
         if (p.state) {  // live lengths (the column ownership below depends on the live row length)
@@ -241,7 +209,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
     auto slot_page = [&](uint32_t slot) -> int32_t {
         if (slot >= p.n_sel) return p.last_page_idx;
-        if constexpr (FC != 0) return s_sel[slot - slot_begin];
+        if constexpr (FC > 0) return s_sel[slot - slot_begin];
         else return idx_row[slot];
     };
 
@@ -776,7 +744,7 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
     p.state = state;
-    // fc < 0: single-wave selection with -fc columns per lane (rows <= 4096); fc > 0: block selection
+    // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor
     int fc = 0;
     uint32_t waves = h->dec_waves;
     if (fused) {

@@ -81,39 +81,6 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
     }
 }
 
-// Rows up to 64*C columns: one 64-thread workgroup (a single wave) per row, no barriers.
-template <int C>
-__global__ __launch_bounds__(kWave) void topk_wave_kernel(const uint16_t* __restrict__ vals,
-                                                          const int32_t* __restrict__ in_idx,
-                                                          uint16_t* __restrict__ out_val, int32_t* __restrict__ out_idx,
-                                                          uint32_t n, uint32_t k) {
-    __shared__ TopkWaveSmem sm;
-    const int lane = threadIdx.x;
-    const size_t row = blockIdx.x;
-    const uint16_t* v = vals + row * n;
-    const int32_t* ii = in_idx + row * n;
-    uint32_t key[C];
-    int32_t pid[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const uint32_t c = i * kWave + lane, cc = c < n ? c : n - 1;  // clamped, unconditional (see above)
-        key[i] = half_key(v[cc]);
-        pid[i] = ii[cc];
-    }
-    const TopkWaveResult r = topk_select_wave<C>(sm, key, n, k, lane);
-    TopkWaveCursor cur;
-    uint16_t* ov = out_val + row * k;
-    int32_t* oi = out_idx + row * k;
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        uint32_t slot;
-        if (topk_wave_take(cur, r, key[i], (uint32_t)(i * kWave + lane) < n, lane, slot)) {
-            ov[slot] = key_to_half_bits(key[i]);
-            oi[slot] = pid[i];
-        }
-    }
-}
-
 }  // namespace quest
 
 using namespace quest;
@@ -135,19 +102,14 @@ extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* 
 #define QUEST_TOPK_LAUNCH(CC)                                                                                   \
     hipLaunchKernelGGL((topk_kernel<CC>), dim3(num_heads), dim3(kTkThreads), tk_lds, s, ev, estimated_indices, dv, \
                        indices_out, num_pages, page_budget)
-#define QUEST_TOPK_WAVE(CC)                                                                                 \
-    hipLaunchKernelGGL((topk_wave_kernel<CC>), dim3(num_heads), dim3(kWave), 0, s, ev, estimated_indices, dv, \
-                       indices_out, num_pages, page_budget)
-    // (a single-wave variant, topk_wave_kernel, exists for rows <= 4096 but measured 2x slower on
-    // MI355X: one wave issues ~1 instruction / 4-5 cycles, so ~3.5k instructions cost > 8 us)
-    if (num_pages <= 64) QUEST_TOPK_WAVE(16);
-    else if (num_pages <= 1 * kTkThreads) QUEST_TOPK_LAUNCH(1);
+    // (a single-wave selection variant was built and measured 2x slower on MI355X: one wave issues ~1
+    // instruction per 4-5 cycles, so its ~3.5k instructions cost > 8 us; removed)
+    if (num_pages <= 1 * kTkThreads) QUEST_TOPK_LAUNCH(1);
     else if (num_pages <= 2 * kTkThreads) QUEST_TOPK_LAUNCH(2);
     else if (num_pages <= 4 * kTkThreads) QUEST_TOPK_LAUNCH(4);
     else if (num_pages <= 8 * kTkThreads) QUEST_TOPK_LAUNCH(8);
     else QUEST_TOPK_LAUNCH(16);
 #undef QUEST_TOPK_LAUNCH
-#undef QUEST_TOPK_WAVE
     QUEST_LAUNCH_CHECK();
     return 0;
 }

@@ -151,115 +151,4 @@ __device__ __forceinline__ uint16_t key_to_half_bits(uint32_t key) {
     return (key & 0x8000u) ? (uint16_t)(key & 0x7fffu) : (uint16_t)~key;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Single-wave variant (rows up to 64*C columns): the same selection, but one wavefront does it all,
-// so there is no workgroup barrier anywhere -- phases are ordered by the wave's own program order.
-// Lane l owns columns i*64 + l (i = 0..C-1): global loads are fully coalesced and a column's output
-// slot comes from ballots (ascending column order = i-major, then lane).
-struct TopkWaveSmem {
-    uint32_t hist1[kBins1];
-    uint32_t hist2[kBins2];
-};
-
-__device__ __forceinline__ void wave_lds_fence() {
-    // LDS operations of one wave execute in program order; this only stops the compiler from
-    // reordering them across phases.
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, int lane) {
-    (void)lane;
-    return wave_scan_incl_dpp(x);
-}
-
-struct TopkWaveResult {
-    uint32_t T, need;
-};
-
-// All 64 lanes of ONE wave must call this (other waves of the workgroup must not touch `sm`).
-template <int C>
-__device__ __forceinline__ TopkWaveResult topk_select_wave(TopkWaveSmem& sm, const uint32_t (&key)[C], uint32_t n,
-                                                           uint32_t k, int lane) {
-    constexpr int BPL = kBins1 / kWave;  // 32 histogram bins per lane
-    static_assert(BPL == 32, "transposed histogram indexing assumes 32 bins per lane");
-#pragma unroll
-    for (int j = 0; j < BPL; ++j) sm.hist1[j * kWave + lane] = 0;
-    if (lane < kBins2) sm.hist2[lane] = 0;
-    wave_lds_fence();
-#pragma unroll
-    // hist1 is indexed by the REVERSED bin rb = kBins1-1-bin (so ascending rb = descending score) and
-    // stored transposed, word (rb % 32) * 64 + rb / 32: lane l then owns rb = 32l .. 32l+31 and reads
-    // them as hist1[j*64 + l] -- consecutive lanes on consecutive banks, no conflicts.
-    for (int i = 0; i < C; ++i)
-        if ((uint32_t)(i * kWave + lane) < n) {
-            const uint32_t rb = kBins1 - 1 - (key[i] >> kLowBits);
-            atomicAdd(&sm.hist1[((rb & (BPL - 1)) << 6) | (rb >> 5)], 1u);
-        }
-    wave_lds_fence();
-
-    // suffix scan from the top: lane l owns reversed bins BPL*l .. BPL*l+BPL-1
-    uint32_t thr_bin = 0, above = 0;
-    {
-        uint32_t h[BPL], tot = 0;
-#pragma unroll
-        for (int j = 0; j < BPL; ++j) {
-            h[j] = sm.hist1[j * kWave + lane];
-            tot += h[j];
-        }
-        uint32_t run = wave_scan_incl(tot, lane) - tot;
-        uint32_t found_bin = 0, found_above = 0;
-        bool found = false;
-#pragma unroll
-        for (int j = 0; j < BPL; ++j) {
-            if (run < k && k <= run + h[j]) {
-                found = true;
-                found_bin = kBins1 - 1 - (BPL * lane + j);
-                found_above = run;
-            }
-            run += h[j];
-        }
-        const unsigned long long m = __ballot(found);  // exactly one lane when k <= n
-        const int src = m ? __builtin_ctzll(m) : 0;
-        thr_bin = __shfl(found_bin, src, kWave);
-        above = __shfl(found_above, src, kWave);
-    }
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-        if ((uint32_t)(i * kWave + lane) < n && (key[i] >> kLowBits) == thr_bin)
-            atomicAdd(&sm.hist2[key[i] & (kBins2 - 1)], 1u);
-    wave_lds_fence();
-    TopkWaveResult r;
-    {
-        const uint32_t cnt = lane < kBins2 ? sm.hist2[kBins2 - 1 - lane] : 0u;
-        const uint32_t incl = wave_scan_incl(cnt, lane);
-        const uint32_t excl = incl - cnt;
-        const bool found = lane < kBins2 && above + excl < k && k <= above + incl;
-        const unsigned long long m = __ballot(found);
-        const int src = m ? __builtin_ctzll(m) : 0;
-        r.T = (thr_bin << kLowBits) | (uint32_t)(kBins2 - 1 - src);
-        r.need = k - (above + __shfl(excl, src, kWave));
-    }
-    return r;
-}
-
-// Ranking cursor for the wave variant: call once per i (ascending), every lane of the wave.
-struct TopkWaveCursor {
-    uint32_t pos_base = 0, eq_base = 0;
-};
-
-__device__ __forceinline__ bool topk_wave_take(TopkWaveCursor& cur, const TopkWaveResult& r, uint32_t key, bool in_range,
-                                               int lane, uint32_t& slot) {
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const bool is_eq = in_range && key == r.T;
-    const unsigned long long eq_mask = __ballot(is_eq);
-    const uint32_t eq_rank = cur.eq_base + (uint32_t)__builtin_popcountll(eq_mask & lt);
-    const bool take = in_range && (key > r.T || (is_eq && eq_rank < r.need));
-    const unsigned long long t_mask = __ballot(take);
-    slot = cur.pos_base + (uint32_t)__builtin_popcountll(t_mask & lt);
-    cur.pos_base += (uint32_t)__builtin_popcountll(t_mask);
-    cur.eq_base += (uint32_t)__builtin_popcountll(eq_mask);
-    return take;
-}
-
 }  // namespace quest
