@@ -200,6 +200,17 @@ int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q
                                         uint32_t max_n_scores, const quest_step_state_t* state, float* lse,
                                         quest_stream_t stream);
 
+/* quest_append_kv_cache_decode with lengths / last-page ids from `state` (dense layers of a replayed step). */
+int quest_append_kv_cache_decode_dyn(const void* k, const void* v, quest_paged_kv_t kv, quest_paged_kv_t metadata,
+                                     const quest_step_state_t* state, quest_stream_t stream);
+
+/* quest_decode_forward_shared over ALL pages of the sequence (state->n_pages - 1 listed pages + the current
+ * one): paged_kv.indices = the full page table.  Plan with begin_forward(n_selected_pages = pool capacity - 1);
+ * workgroups past the live length contribute empty partial states. */
+int quest_decode_forward_shared_dyn(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                    uint32_t num_qo_heads, const quest_step_state_t* state, float* lse,
+                                    quest_stream_t stream);
+
 /* quest_apply_rope_in_place for one decode token with past_kv_len = state->seq_len - 1. */
 int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_heads, uint32_t num_kv_heads, uint32_t head_dim,
                                   float rope_scale, float rope_theta, const quest_step_state_t* state,

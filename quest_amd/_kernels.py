@@ -251,6 +251,19 @@ def append_estimate_dyn(k, v, kv_data, kv_table, q, o, metadata_data, meta_table
           "append_estimate_dyn")
 
 
+def append_kv_cache_decode_dyn(k, v, kv_data, kv_table, metadata_data, meta_table, state, layout: int) -> None:
+    """append_kv_cache_decode with lengths / last-page ids from ``state``."""
+    for t, n in ((k, "k"), (v, "v"), (kv_data, "kv_data"), (kv_table, "kv_table"), (metadata_data, "metadata_data"),
+                 (meta_table, "meta_table"), (state, "state")):
+        _check_input(t, n)
+    _check_eq(k.size(0), 1, "k.size(0), 1")
+    _check_half(k, "Append_kv_cache_decode")
+    kv = _paged(kv_data, kv_table, None, 1, 0, layout)
+    meta = _paged(metadata_data, meta_table, None, 1, 0, layout)
+    check(lib.quest_append_kv_cache_decode_dyn(k.data_ptr(), v.data_ptr(), kv, meta, state.data_ptr(), _stream(k)),
+          "Append_kv_cache_decode")
+
+
 def apply_rope_in_place_dyn(q, k, rope_scale: float, rope_theta: float, state) -> None:
     _check_input(q, "q")
     _check_input(k, "k")
@@ -392,6 +405,15 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
             return False
         check(code, "BatchDecodeWithPagedKVCache")
         return True
+
+    def forward_shared_dyn(self, q, o, paged_kv_data, page_table, state) -> None:
+        """forward_shared over all pages of the sequence, live length from ``state`` (graph replay)."""
+        for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (page_table, "page_table"), (state, "state")):
+            _check_input(t, n)
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, page_table, None, 1, 0, self._layout)
+        check(lib.quest_decode_forward_shared_dyn(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), state.data_ptr(),
+                                                  None, _stream(q)), "BatchDecodeWithPagedKVCache")
 
     def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
         """forward_fused_topk whose row length and current page come from ``state`` (graph replay)."""

@@ -14,7 +14,15 @@ namespace quest {
 
 __global__ __launch_bounds__(256) void append_decode_kernel(quest_paged_kv_t kv, quest_paged_kv_t meta,
                                                             const uint16_t* __restrict__ key,
-                                                            const uint16_t* __restrict__ value) {
+                                                            const uint16_t* __restrict__ value,
+                                                            const quest_step_state_t* state) {
+    if (state) {  // state-driven launch: lengths / last-page ids from device memory
+        const quest_step_state_t st = *state;
+        kv.last_page_len = (uint32_t)st.kv_last_page_len;
+        kv.last_page_idx = st.kv_last_page_idx;
+        meta.last_page_len = (uint32_t)st.meta_last_page_len;
+        meta.last_page_idx = st.meta_last_page_idx;
+    }
     append_decode_body(kv, meta, key, value, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
@@ -122,7 +130,23 @@ extern "C" int quest_append_kv_cache_decode(const void* k, const void* v, quest_
     const uint32_t threads = kv.num_heads * (kv.head_dim / kVec);
     const uint32_t block = 256, grid = (threads + block - 1) / block;
     hipLaunchKernelGGL(append_decode_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, kv, metadata,
-                       (const uint16_t*)k, (const uint16_t*)v);
+                       (const uint16_t*)k, (const uint16_t*)v, (const quest_step_state_t*)nullptr);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int quest_append_kv_cache_decode_dyn(const void* k, const void* v, quest_paged_kv_t kv,
+                                                quest_paged_kv_t metadata, const quest_step_state_t* state,
+                                                quest_stream_t stream) {
+    if (!k || !v || !state) return QUEST_EINVAL;
+    kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
+    const uint32_t threads = kv.num_heads * (kv.head_dim / kVec);
+    const uint32_t block = 256, grid = (threads + block - 1) / block;
+    hipLaunchKernelGGL(append_decode_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, kv, metadata,
+                       (const uint16_t*)k, (const uint16_t*)v, state);
     QUEST_LAUNCH_CHECK();
     return 0;
 }

@@ -338,8 +338,15 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hk = blockIdx.y;
+    if (p.state) {  // state-driven launch: the plan (chunks) was made for the pool capacity; workgroups whose
+                    // chunk lies past the live page list write an empty partial (weight 0 in the merge)
+        const quest_step_state_t st = *p.state;
+        p.n_sel = (uint32_t)(st.n_pages - 1);
+        p.last_page_len = (uint32_t)st.kv_last_page_len;
+        p.last_page_idx = st.kv_last_page_idx;
+    }
     const uint32_t n_slots = p.n_sel + 1;
-    const uint32_t slot_begin = chunk * p.pages_per_chunk;
+    const uint32_t slot_begin = min(n_slots, chunk * p.pages_per_chunk);
     const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
 
     float8 qv[GS];
@@ -788,9 +795,10 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, u
     return 0;
 }
 
-extern "C" int quest_decode_forward_shared(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
-                                           uint32_t num_qo_heads, float* lse, quest_stream_t stream) {
+static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv, uint32_t num_qo_heads,
+                        float* lse, const quest_step_state_t* state, quest_stream_t stream) {
     if (!h) return QUEST_EINVAL;
+    if (state) kv.last_page_len = 1;  // placeholder; read from `state` in the kernel
     if (!h->started) return QUEST_ESTATE;
     if (!q || !o || !kv.data || (h->n_sel > 0 && !kv.indices)) return QUEST_EINVAL;
     if (kv.layout != h->layout || kv.head_dim != h->head_dim || kv.page_size != h->page_size ||
@@ -815,9 +823,22 @@ extern "C" int quest_decode_forward_shared(quest_decode_handler_t* h, const void
     p.n_chunks = h->shared_chunks;
     p.scale_log2 = (float)(1.4426950408889634 / sqrt((double)kv.head_dim));
     p.ws_stride = h->ws_stride;
+    p.state = state;
     hipStream_t s = (hipStream_t)stream;
     return kv.head_dim == 64 ? launch_shared<64>(h, p, num_qo_heads, p.group, s)
                              : launch_shared<128>(h, p, num_qo_heads, p.group, s);
+}
+
+extern "C" int quest_decode_forward_shared(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
+                                           uint32_t num_qo_heads, float* lse, quest_stream_t stream) {
+    return shared_entry(h, q, o, kv, num_qo_heads, lse, nullptr, stream);
+}
+
+extern "C" int quest_decode_forward_shared_dyn(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
+                                               uint32_t num_qo_heads, const quest_step_state_t* state, float* lse,
+                                               quest_stream_t stream) {
+    if (!state) return QUEST_EINVAL;
+    return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream);
 }
 
 extern "C" int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,

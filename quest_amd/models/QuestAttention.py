@@ -117,3 +117,23 @@ class QuestAttention(nn.Module):
         out = self.o_proj(attn.reshape(bsz, q_len, self.hidden_size))
         nvtx.range_pop()
         return out, None, past_key_value
+
+    def forward_dyn(self, hidden_states: torch.Tensor, iController: qutils.InferenceController, scores: torch.Tensor,
+                    dense: bool) -> torch.Tensor:
+        """Decode-token forward whose every length comes from the controller's device-resident step state
+        (``enable_device_state`` + ``begin_graph_decode(dense_layers=True)``), so a whole model step can be
+        captured in one hipGraph and replayed as the sequence grows.  ``dense``: full-KV layer (the model's
+        first layers) vs Quest sparse layer.  EXTENSION of the reference module."""
+        bsz, q_len, _ = hidden_states.size()
+        assert bsz == 1 and q_len == 1
+        q = self.q_proj(hidden_states).view(1, self.num_heads, self.head_dim)
+        k = self.k_proj(hidden_states).view(1, self.num_key_value_heads, self.head_dim)
+        v = self.v_proj(hidden_states).view(1, self.num_key_value_heads, self.head_dim)
+        if dense:
+            attn = qutils.decode_layer_dense_dyn(q, k, v, iController, self.layer_idx, self.rope_scale, self.rope_theta,
+                                                 apply_rope=True)
+        else:
+            attn = qutils.decode_layer_dyn(q, k, v, iController, self.layer_idx, scores, self.rope_scale,
+                                           self.rope_theta, apply_rope=True)
+        return self.o_proj(attn.reshape(1, 1, self.hidden_size))
+

@@ -73,6 +73,11 @@ class LlamaDecoderLayer(nn.Module):
         hidden_states = hidden_states + h
         return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
 
+    def forward_dyn(self, hidden_states: torch.Tensor, iController, scores, dense: bool) -> torch.Tensor:
+        h = self.self_attn.forward_dyn(self.input_layernorm(hidden_states), iController, scores, dense)
+        hidden_states = hidden_states + h
+        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+
 
 class LlamaModel(nn.Module):
     def __init__(self, config: LlamaConfig, fused: bool = True):
@@ -104,6 +109,16 @@ class LlamaModel(nn.Module):
         return self.norm(h)
 
 
+    def forward_decode_dyn(self, h: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
+        """One decode token with no host-side planning: the device-side state advance replaces
+        prepare_metadata / begin_forward / end_forward (capturable, replayable)."""
+        ctl = self.iController
+        qutils.step_advance_dyn(ctl)
+        for idx, layer in enumerate(self.layers):
+            h = layer.forward_dyn(h, ctl, scores, dense=idx < self._quest_skip_layer)
+        return self.norm(h)
+
+
 class LlamaForCausalLM(nn.Module):
     def __init__(self, config: LlamaConfig, fused: bool = True):
         super().__init__()
@@ -132,3 +147,49 @@ class LlamaForCausalLM(nn.Module):
     def forward(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None):
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds)
         return self.lm_head(h[:, -1:, :])  # decode only needs the last position
+
+    # ------------------------------------------------------------------ one hipGraph per generated token
+    def capture_decode_graph(self) -> None:
+        """Capture ONE decode step (all layers + lm_head) and keep it for ``decode_graph_step``.  Call after
+        the prompt has been processed (the cache must already hold at least `page budget` pages).  The
+        graph reads its input from ``self.graph_input`` ``[1, 1, hidden]`` and leaves the logits in
+        ``self.graph_logits``; sequence lengths live on the device (EXTENSION)."""
+        m, ctl = self.model, self.model.iController
+        dev = next(self.parameters()).device
+        ctl.set_page_budget(m._quest_page_budget)
+        ctl.enable_device_state()
+        ctl.begin_graph_decode(dense_layers=m._quest_skip_layer > 0)
+        self.graph_input = torch.zeros(1, 1, self.config.hidden_size, dtype=self.lm_head.weight.dtype, device=dev)
+        self._graph_scores = torch.empty(self.config.num_attention_heads, ctl.max_pages, dtype=torch.float16, device=dev)
+
+        def step():
+            return self.lm_head(m.forward_decode_dyn(self.graph_input, self._graph_scores))
+
+        # Warm-up (allocator, rocBLAS workspaces) runs a real step on a dummy input: it advances the device
+        # state and folds the dummy key into the current page's (max, min) metadata entry.  K/V bytes it wrote
+        # are overwritten by the first real token, but the metadata fold is not idempotent -> snapshot the
+        # current metadata page of every layer and restore it, then rewind the state.
+        meta_page = ctl.metadata_cache.indicies[-1]
+        saved = ctl.metadata_cache.pool.buf[:, meta_page].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.inference_mode():
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ctl.metadata_cache.pool.buf[:, meta_page].copy_(saved)
+        ctl.sync_device_state()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.inference_mode(), torch.cuda.graph(self._graph):
+            self.graph_logits = step()
+
+    def decode_graph_step(self, inputs_embeds: Optional[torch.Tensor] = None,
+                          input_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Generate one token's logits by replaying the captured step; returns ``self.graph_logits``."""
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        self.graph_input.copy_(inputs_embeds.view(1, 1, -1))
+        self._graph.replay()
+        self.model.iController.prepare_metadata(1)  # host mirror of the device-side reservation
+        return self.graph_logits
+

@@ -33,6 +33,7 @@ __all__ = [
     # state-driven forms for hipGraph replay across tokens
     "step_advance_dyn",
     "decode_layer_dyn",
+    "decode_layer_dense_dyn",
 ]
 
 
@@ -179,4 +180,22 @@ def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iControl
     o = torch.empty_like(q)
     ctl._decode_handler.forward_fused_topk_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, scores,
                                                ctl.step_state, max_n)
+    return o
+
+
+def decode_layer_dense_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
+                           layer_idx: int, rope_scale: Optional[float] = None, rope_theta: Optional[float] = None,
+                           apply_rope: bool = False) -> torch.Tensor:
+    """One FULL-KV layer of a decode token, every length read from the device-resident state:
+    [RoPE] -> append -> attention over all pages (group-shared kernel) (+merge).  Needs
+    ``begin_graph_decode(dense_layers=True)``."""
+    ctl = iController
+    if apply_rope:
+        scale, theta = _rope_defaults(rope_scale, rope_theta)
+        _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
+    _kernels.append_kv_cache_decode_dyn(k, v, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full,
+                                        ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, ctl.step_state,
+                                        ctl.layout)
+    o = torch.empty_like(q)
+    ctl._dense_handler.forward_shared_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, ctl.step_state)
     return o

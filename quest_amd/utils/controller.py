@@ -141,14 +141,21 @@ class InferenceController:
         self.step_state = torch.zeros(8, dtype=torch.int32, device=self.device)
         self.sync_device_state()
 
-    def begin_graph_decode(self) -> None:
+    def begin_graph_decode(self, dense_layers: bool = False) -> None:
         """Plan the sparse decode for the configured budget once, for a graph that will be replayed over
-        many tokens (the plan depends only on the budget, which is constant once pages >= budget)."""
+        many tokens (the plan depends only on the budget, which is constant once pages >= budget).  With
+        ``dense_layers`` a second handler is planned for full-KV layers (the model's first layers,
+        llama.py:428-430) over the pool's capacity."""
         budget = self._page_budget
         assert len(self.kv_cache.indicies) >= budget, "graph decode needs the sparse regime (pages >= budget)"
         self.inference_page_budget = budget
         self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
                                            self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
+        if dense_layers:
+            if getattr(self, "_dense_handler", None) is None:
+                self._dense_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout=TensorLayout.FORMAT2STR[self.layout])
+            self._dense_handler.begin_forward(torch.tensor([0, self.max_pages - 1], dtype=torch.int32), self.num_heads,
+                                              self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
 
     def sync_device_state(self) -> None:
         kv, meta = self.kv_cache, self.metadata_cache

@@ -43,6 +43,9 @@ class BatchDecodeWithPagedKVCacheWrapper:
         return self._wrapper.forward_fused_topk(q, o, paged_kv_data, page_table, scores, topk_val_out, topk_idx_out,
                                                 paged_kv_last_page_len, paged_kv_last_page_idx)
 
+    def forward_shared_dyn(self, q, o, paged_kv_data, page_table, state) -> None:
+        self._wrapper.forward_shared_dyn(q, o, paged_kv_data, page_table, state)
+
     def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
         self._wrapper.forward_fused_topk_dyn(q, o, paged_kv_data, page_table, scores, state, max_n_scores)
 

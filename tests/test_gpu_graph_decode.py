@@ -96,3 +96,48 @@ def test_graph_replay_matches_eager_over_growing_sequence(Hq, Hkv, layout, L0, s
     for l in range(layers):
         ia = torch.tensor(ea.kv_cache.indicies[:-1], device=dev)
         assert torch.equal(ea.kv_cache.buf_layer(l)[ia], gr.kv_cache.buf_layer(l)[ia])
+
+
+def test_model_generation_graph_replay_equals_eager():
+    """A whole Llama-architecture model (2 dense layers + sparse layers, GQA) generating greedily: one
+    captured hipGraph replayed per token must produce exactly the logits of the eager, host-planned path."""
+    from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
+
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
+                      num_attention_heads=4, num_key_value_heads=2)
+    prompt = (torch.arange(300, device=dev)[None] * 7) % 256
+    n_new = 40  # crosses two page boundaries and (at 320 tokens = 20 pages -> 21) a metadata-page boundary
+
+    def build():
+        torch.manual_seed(11)
+        with torch.device(dev):
+            m = LlamaForCausalLM(cfg).half()
+        for p_ in m.parameters():
+            p_.data.normal_(0, 0.05)
+        m.quest_init(16, 512, token_budget=96)
+        with torch.inference_mode():
+            first = m(input_ids=prompt)
+        return m, first
+
+    eager, first_e = build()
+    toks_e, logits_e = [], []
+    tok = first_e.argmax(-1)
+    with torch.inference_mode():
+        for _ in range(n_new):
+            toks_e.append(int(tok))
+            out = eager(input_ids=tok.view(1, 1))
+            logits_e.append(out.float().clone())
+            tok = out.argmax(-1)
+
+    graph, first_g = build()
+    assert torch.equal(first_e, first_g)
+    graph.capture_decode_graph()
+    tok = first_g.argmax(-1)
+    with torch.inference_mode():
+        for t in range(n_new):
+            assert int(tok) == toks_e[t]
+            out = graph.decode_graph_step(input_ids=tok.view(1, 1))
+            assert torch.equal(out.float(), logits_e[t]), f"token {t}"
+            tok = out.argmax(-1)
+    assert graph.model.iController.kv_cache.seqlen == 300 + n_new
