@@ -20,10 +20,19 @@ from ._lib import PagedKV, check, lib
 
 _NHD, _HND = 0, 1
 
+# The reference compiles its argument validation in or out with -DBSK_TORCH_CHECK
+# (quest/ops/CMakeLists.txt:40); here QUEST_TORCH_CHECK=0 turns the same checks off at import time
+# (eager decode is host-bound: the checks are ~30 % of an op call's Python time).
+import os as _os
+
+_CHECKS_ON = _os.environ.get("QUEST_TORCH_CHECK", "1") != "0"
+
 
 # ---------------------------------------------------------------- validation (CHECK_* macros)
 
 def _check_input(x: torch.Tensor, name: str) -> None:
+    if not _CHECKS_ON:
+        return
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if not x.is_cuda:
@@ -33,17 +42,17 @@ def _check_input(x: torch.Tensor, name: str) -> None:
 
 
 def _check_dim(d: int, x: torch.Tensor, name: str) -> None:
-    if x.dim() != d:
+    if _CHECKS_ON and x.dim() != d:
         raise RuntimeError(f"{name} must be a {d}D tensor")
 
 
 def _check_eq(a, b, what: str) -> None:
-    if a != b:
+    if _CHECKS_ON and a != b:
         raise RuntimeError(f"CHECK_EQ({what}) failed. {a} vs {b}")
 
 
 def _check_ge(a, b, what: str) -> None:
-    if not a >= b:
+    if _CHECKS_ON and not a >= b:
         raise RuntimeError(f"CHECK_GE({what}) failed. {a} vs {b}")
 
 

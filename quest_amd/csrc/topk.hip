@@ -69,15 +69,25 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
         key[i] = keys_s[c < n ? c : n - 1];
     }
     TopkCursor cur = topk_select<kTkThreads, C>(sm, key, n, k, cpt);
-    uint16_t* ov = out_val + row * k;
-    int32_t* oi = out_idx + row * k;
+    // Selected (value, id) pairs are compacted in LDS by output slot (k <= n), then written out by the
+    // first k threads: coalesced stores instead of a divergent scatter of 2- and 4-byte writes.
+    uint16_t* selv_s = keys_s;  // the key array is dead after the reads above ...
+    __syncthreads();            // ... once every thread has read its keys
+    int32_t* seli_s = reinterpret_cast<int32_t*>(tk_dyn + (((size_t)n * 2 + 15) & ~(size_t)15) + (stage_ids ? (size_t)n * 4 : 0));
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         uint32_t slot;
         if (topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot)) {
-            ov[slot] = key_to_half_bits(key[i]);
-            oi[slot] = stage_ids ? ids_s[c0 + i] : ii[c0 + i];
+            selv_s[slot] = key_to_half_bits(key[i]);
+            seli_s[slot] = stage_ids ? ids_s[c0 + i] : ii[c0 + i];
         }
+    }
+    __syncthreads();
+    uint16_t* ov = out_val + row * k;
+    int32_t* oi = out_idx + row * k;
+    for (uint32_t t = tid; t < k; t += kTkThreads) {
+        ov[t] = selv_s[t];
+        oi[t] = seli_s[t];
     }
 }
 
@@ -98,7 +108,8 @@ extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* 
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* ev = (const uint16_t*)estimated_value;
     uint16_t* dv = (uint16_t*)d_out;
-    const size_t tk_lds = (((size_t)num_pages * 2 + 15) & ~(size_t)15) + (num_pages <= kTkStageIdsMax ? (size_t)num_pages * 4 : 0);
+    const size_t tk_lds = (((size_t)num_pages * 2 + 15) & ~(size_t)15) + (num_pages <= kTkStageIdsMax ? (size_t)num_pages * 4 : 0) +
+                          (size_t)page_budget * 4;  // keys, staged ids, compacted selected ids
 #define QUEST_TOPK_LAUNCH(CC)                                                                                   \
     hipLaunchKernelGGL((topk_kernel<CC>), dim3(num_heads), dim3(kTkThreads), tk_lds, s, ev, estimated_indices, dv, \
                        indices_out, num_pages, page_budget)

@@ -24,11 +24,12 @@ template <int NT>
 struct TopkSmem {
     uint32_t hist1[kBins1];
     uint32_t hist2[kBins2];
-    uint32_t wave_tot[NT / kWave];
-    uint32_t misc[4];  // thr_bin, above, T, need_eq
+    uint32_t wave_tot[2][NT / kWave];  // one row per block scan, so a scan needs a single barrier
+    uint32_t misc[4];                  // thr_bin, above, T, need_eq
 };
 
-// Inclusive block scan of one uint32 per thread.
+// Inclusive block scan of one uint32 per thread; `wave_tot` must not be reused by a later scan of the
+// same kernel (each call site gets its own row), which is what lets it run with ONE barrier.
 template <int NT>
 __device__ __forceinline__ uint32_t block_scan_incl(uint32_t x, uint32_t* wave_tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -38,7 +39,6 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t x, uint32_t* wave_t
     uint32_t base = 0;
 #pragma unroll
     for (int w = 0; w < NT / kWave; ++w) base += (w < wave) ? wave_tot[w] : 0u;
-    __syncthreads();  // wave_tot is reused by the next scan
     return x + base;
 }
 
@@ -85,7 +85,7 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
             h[j] = sm.hist1[kBins1 - 1 - (BPT * tid + j)];
             tot += h[j];
         }
-        const uint32_t incl = block_scan_incl<NT>(tot, sm.wave_tot);
+        const uint32_t incl = block_scan_incl<NT>(tot, sm.wave_tot[0]);
         uint32_t run = incl - tot;
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
         eq += in && key[i] == cur.T;
     }
     const uint32_t packed = gt | (eq << 16);  // both totals < 65536 (n <= 16384)
-    const uint32_t before = block_scan_incl<NT>(packed, sm.wave_tot) - packed;
+    const uint32_t before = block_scan_incl<NT>(packed, sm.wave_tot[1]) - packed;
     cur.eq_rank = before >> 16;
     cur.pos = (before & 0xffffu) + (cur.eq_rank < cur.need ? cur.eq_rank : cur.need);
     return cur;
