@@ -216,23 +216,6 @@ int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_heads, uint3
                                   float rope_scale, float rope_theta, const quest_step_state_t* state,
                                   quest_stream_t stream);
 
-/*
- * The whole chain of one layer for one decode token -- append, estimate, top-k, sparse attention, merge
- * (QuestAttention.py:106-157) -- as ONE persistent launch whose workgroups pull interleaved work items
- * from a queue (csrc/layer_fused.hip).  Same results as the separate ops.  kv.indices = the sequence's page
- * table [n_pages]; n_selected_pages = page budget - 1 <= n_pages - 1.  QUEST_EUNSUPPORTED outside this
- * version's shape set (head_dim 128, page 16, kv heads % 8 == 0, query group 1 or 4, <= 4097 pages).
- * One workspace must not be used by two launches in flight.
- */
-typedef struct quest_layer_ws quest_layer_ws_t;
-int quest_layer_ws_create(quest_layer_ws_t** out);
-void quest_layer_ws_destroy(quest_layer_ws_t* w);
-/* time-out flag of the launches so far (0 = all in-kernel hand-offs completed); synchronises the device */
-int quest_layer_ws_error(quest_layer_ws_t* w, uint32_t* flag);
-int quest_decode_layer_fused(quest_layer_ws_t* w, const void* k, const void* v, const void* q, void* o,
-                             quest_paged_kv_t kv, quest_paged_kv_t metadata, uint32_t num_qo_heads,
-                             uint32_t n_pages, uint32_t n_selected_pages, quest_stream_t stream);
-
 /* Introspection of the current plan (for benches/tests): pages per workgroup, workgroups per head. */
 int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_chunk,
                            uint32_t* chunks_per_head);

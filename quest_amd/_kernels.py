@@ -314,45 +314,6 @@ def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, c
     return o.transpose(0, 1).contiguous()
 
 
-class LayerFusedWorkspace:
-    """EXTENSION: workspace of the one-launch-per-layer decode (csrc/layer_fused.hip)."""
-
-    def __init__(self):
-        h = ctypes.c_void_p()
-        check(lib.quest_layer_ws_create(ctypes.byref(h)), "layer_ws_create")
-        self._h = h
-        self._destroy = lib.quest_layer_ws_destroy
-
-    def __del__(self):
-        h, self._h = getattr(self, "_h", None), None
-        if h:
-            self._destroy(h)
-
-    def error_flag(self) -> int:
-        f = ctypes.c_uint32()
-        check(lib.quest_layer_ws_error(self._h, ctypes.byref(f)), "layer_ws_error")
-        return f.value
-
-    def decode_layer(self, k, v, q, o, kv_data, page_table, kv_last_page_len: int, kv_last_page_idx: int,
-                     metadata_data, meta_table, meta_last_page_len: int, meta_last_page_idx: int, n_selected: int,
-                     layout: int) -> bool:
-        """append + estimate + top-k + sparse attention + merge of one layer in one launch.  False (nothing
-        launched) when the shape is outside the fused kernel's set."""
-        for t, n in ((k, "k"), (v, "v"), (q, "q"), (o, "o"), (kv_data, "kv_data"), (page_table, "page_table"),
-                     (metadata_data, "metadata_data"), (meta_table, "meta_table")):
-            _check_input(t, n)
-        _check_eq(k.size(0), 1, "k.size(0), 1")
-        _check_half(q, "decode_layer_fused")
-        kv = _paged(kv_data, page_table, None, kv_last_page_len, kv_last_page_idx, layout)
-        meta = _paged(metadata_data, meta_table, None, meta_last_page_len, meta_last_page_idx, layout)
-        code = lib.quest_decode_layer_fused(self._h, k.data_ptr(), v.data_ptr(), q.data_ptr(), o.data_ptr(), kv, meta,
-                                            q.size(1), page_table.size(0), int(n_selected), _stream(q))
-        if code == -2:
-            return False
-        check(code, "decode_layer_fused")
-        return True
-
-
 # ---------------------------------------------------------------- handler class
 
 class BatchDecodeWithPagedKVCachePyTorchWrapper:

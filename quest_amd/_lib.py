@@ -57,11 +57,6 @@ SIGNATURES = {
     "quest_append_kv_cache_decode_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp, c_vp]),
     "quest_decode_forward_shared_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp, c_vp]),
     "quest_apply_rope_in_place_dyn": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, c_vp]),
-    "quest_layer_ws_create": (ctypes.c_int, [ctypes.POINTER(c_vp)]),
-    "quest_layer_ws_destroy": (None, [c_vp]),
-    "quest_layer_ws_error": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32)]),
-    "quest_decode_layer_fused": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, PagedKV, PagedKV, c_u32, c_u32, c_u32,
-                                                 c_vp]),
     "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),
     "quest_apply_rope_in_place": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp]),

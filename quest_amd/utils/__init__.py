@@ -34,8 +34,6 @@ __all__ = [
     "step_advance_dyn",
     "decode_layer_dyn",
     "decode_layer_dense_dyn",
-    # one persistent launch per layer
-    "decode_layer_fused",
 ]
 
 
@@ -202,22 +200,3 @@ def decode_layer_dense_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iC
     ctl._dense_handler.forward_shared_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, ctl.step_state)
     return o
 
-
-def decode_layer_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
-                       layer_idx: int) -> torch.Tensor:
-    """``append_kv`` + ``decode_estimate`` + ``decode_topk`` + ``decode_sparse_attn`` of one layer as ONE
-    persistent launch (csrc/layer_fused.hip); falls back to the two fused launches when the shape is outside
-    that kernel's set.  Call between ``begin_forward(1)`` and ``end_forward()`` in the sparse regime."""
-    ctl = iController
-    ws = getattr(ctl, "_layer_ws", None)
-    if ws is None:
-        ws = ctl._layer_ws = _kernels.LayerFusedWorkspace()
-    o = torch.empty_like(q)
-    ok = ws.decode_layer(k, v, q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_indices_with_last,
-                         ctl.kv_cache.last_page_len, ctl.kv_last_page_idx, ctl.metadata_cache.buf_layer(layer_idx),
-                         ctl.metadata_indices, ctl.metadata_cache.last_page_len, ctl.metadata_last_page_idx,
-                         ctl.inference_page_budget - 1, ctl.layout)
-    if ok:
-        return o
-    est = decode_append_estimate(q, k, v, ctl, layer_idx)
-    return decode_topk_sparse_attn(q, est, ctl, layer_idx, write_topk=False)

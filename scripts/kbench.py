@@ -99,8 +99,6 @@ def main():
 
             t_fc = graph_time(fchain, L)
             print(f"fused chain: {t_fc:7.2f} us  {bpl['chain'] / t_fc / 1e3:7.1f} GB/s")
-            t_lf = graph_time(lambda l: qu.decode_layer_fused(w.q[l], w.k1[l], w.v1[l], ctl, l), L)
-            print(f"one-launch layer: {t_lf:7.2f} us  {bpl['chain'] / t_lf / 1e3:7.1f} GB/s  err={ctl._layer_ws.error_flag()}")
         ctl.end_forward()
     if a0.dense:
         ctl._decode_handler.set_pages_per_chunk(0)

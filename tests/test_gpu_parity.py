@@ -582,53 +582,3 @@ def test_dense_decode_shared_lists_gqa(Hq, Hkv, D, L, layout):
     table = np.array(ctl.kv_cache.indicies, np.int32)
     eo, _ = oracle.sparse_attn(q, kv_o, np.tile(table[:-1], (Hq, 1)), len(table) - 1, int(table[-1]), kv_o.last_page_len)
     _close(o.cpu().numpy(), eo, tol=2e-3)
-
-
-# ---------------------------------------------------------------------------- one launch per layer
-
-@pytest.mark.parametrize("Hq,Hkv,L,B,layout", [(32, 32, 4099, 64, 0), (32, 8, 2500, 40, 1), (8, 8, 1541, 16, 0),
-                                               (32, 32, 32768 + 5, 128, 0), (16, 16, 40000, 300, 1), (32, 8, 613, 5, 0)])
-def test_layer_fused_equals_separate_ops(Hq, Hkv, L, B, layout):
-    """The persistent one-launch layer (queue of append / estimate-tile / attention items with in-kernel
-    hand-offs) must reproduce the separate ops: pools bit for bit, attention output to fp32-merge rounding,
-    and no hand-off may time out.  Repeated launches reuse the self-cleaning sync words."""
-    from _harness import gather_entries
-    qu = _qu()
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device=dev).manual_seed(Hq + L)
-    k = torch.randn(L, Hkv, 128, generator=g, device=dev, dtype=torch.float16)
-    v = torch.randn(L, Hkv, 128, generator=g, device=dev, dtype=torch.float16)
-    res = []
-    for fused in (False, True):
-        ctl = make_controller(L, Hq, Hkv, 128, PAGE, B, layout=layout, shuffle_seed=17, max_seq_len=L + 64)
-        ctl.prepare_metadata(L - 1)
-        ctl.begin_forward(L - 1)
-        qu.append_kv(k[:-1], v[:-1], ctl, 0)
-        ctl.end_forward()
-        ctl.prepare_metadata(1)
-        ctl.begin_forward(1)
-        assert ctl.need_estimate()
-        outs = []
-        for rep in range(3):  # same token re-decoded: launches must be repeatable
-            q = torch.randn(1, Hq, 128, generator=torch.Generator(device=dev).manual_seed(rep), device=dev,
-                            dtype=torch.float16)
-            if fused:
-                o = qu.decode_layer_fused(q, k[-1:], v[-1:], ctl, 0)
-            else:
-                est = qu.decode_append_estimate(q, k[-1:], v[-1:], ctl, 0)
-                o = qu.decode_topk_sparse_attn(q, est, ctl, 0, write_topk=False)
-            outs.append(o.float().cpu())
-        if fused:
-            assert getattr(ctl, "_layer_ws", None) is not None, "fused kernel did not take this shape"
-            assert ctl._layer_ws.error_flag() == 0, "an in-kernel hand-off timed out"
-        ctl.end_forward()
-        n_pages = len(ctl.kv_cache.indicies)
-        kvp = ctl.kv_cache.buf_layer(0)[ctl.kv_indices_with_last.long()].cpu().numpy()
-        mp = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()].cpu().numpy()
-        res.append((outs, gather_entries(kvp, np.arange(kvp.shape[0]), L, layout),
-                    gather_entries(mp, np.arange(mp.shape[0]), n_pages, layout)))
-    (oa, kva, ma), (ob, kvb, mb) = res
-    for x, y in zip(kva + ma, kvb + mb):
-        assert np.array_equal(U16(x), U16(y)), "pools / metadata differ"
-    for x, y in zip(oa, ob):
-        torch.testing.assert_close(x, y, rtol=2e-3, atol=2e-3)
