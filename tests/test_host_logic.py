@@ -211,3 +211,24 @@ def test_reference_python_stack_runs_on_our_kernels_module():
         for k in [k for k in sys.modules if k == "quest" or k.startswith("quest.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_bench_byte_accounting_matches_survey():
+    """bench.py's algorithmic bytes per layer-step are SURVEY.md 8(d)'s (the reference benches' accounting)."""
+    import argparse
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    MiB = 1 << 20
+    a = argparse.Namespace(page_size=16, head_dim=128, heads=32, kv_heads=32, seqlen=32768, token_budget=2048)
+    b = bench.bytes_per_layer(a)
+    assert abs(b["estimate"] / MiB - 32.13) < 0.05      # 32 MiB metadata + q + table + 128 KiB scores
+    assert abs(b["attn"] / MiB - 32.03) < 0.02          # 128 pages x 16 x 2 x 32 heads x 256 B (+ idx, q, o)
+    assert abs(b["dense"] / MiB - 512.3) < 0.1
+    assert abs(b["chain"] / MiB - 64.65) < 0.1          # the "~64.6 MiB" of BASELINE.md section 3
+    g = argparse.Namespace(page_size=16, head_dim=128, heads=32, kv_heads=8, seqlen=131072, token_budget=4096)
+    bg = bench.bytes_per_layer(g)
+    assert abs(bg["estimate"] / MiB - 32.5) < 0.1 and abs(bg["attn"] / MiB - 64.05) < 0.05
+    assert abs(bg["dense"] / MiB - 512) < 2             # GQA: every kv head read once
