@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--seqs-per-gpu", type=int, default=1,
                     help="independent sequences per GPU (BASELINE configs[4] uses 8); each runs its chain on its "
                          "own HIP stream inside the step graph so their latency phases overlap")
+    ap.add_argument("--no-multi-seq", action="store_true",
+                    help="skip the side measurement with 8 sequences per GPU (BASELINE configs[4]'s per-GPU load)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--cpu-sample-s", type=float, default=12.0)
@@ -188,6 +190,55 @@ def time_kernel_loop(fn, layers, reps):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (reps * layers)  # us
+
+
+def multi_seq_side_measurement(a, dev, bpl, dense_us, n_seqs=8, layers=8):
+    """Side figure (not `value`): the same chain with 8 independent sequences on one GPU -- the per-GPU load
+    of BASELINE configs[4] -- each on its own stream inside one step graph, so the fixed latencies of one
+    sequence's kernels overlap the data movement of another's.  8 layers per sequence keep it short."""
+    import copy
+
+    b = copy.copy(a)
+    b.layers, b.mode, b.steps, b.warmup = layers, "graph-static", 30, 5
+    ws = [Workload(b, dev, 100 + i) for i in range(n_seqs)]
+    streams = [torch.cuda.Stream() for _ in ws]
+
+    def step_all():
+        cur = torch.cuda.current_stream()
+        for st, wl in zip(streams, ws):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                wl.step()
+        for st in streams:
+            cur.wait_stream(st)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step_all()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step_all()
+    for _ in range(b.warmup):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(b.steps):
+        g.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    us = el * 1e6 / b.steps / layers / n_seqs
+    res = {"sequences": n_seqs, "layers_per_sequence": layers, "us_per_sequence_layer": us,
+           "chain_frac_of_hbm_peak": bpl["chain"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           # a step of the full model yields n_seqs tokens in us * model_layers * n_seqs microseconds
+           "tokens_per_s_scaled_to_model_layers": 1.0 / (us * 1e-6 * a.layers)}
+    if dense_us is not None:
+        res["speedup_vs_dense"] = dense_us / us
+    del ws, g
+    torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(a, budget_s):
@@ -377,6 +428,8 @@ def main():
             out["dense_full_kv_us"] = dense_us
             out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
             out["speedup_vs_dense"] = dense_us / (ms_per_step * 1e3 / a.layers / len(ws))
+        if world == 1 and len(ws) == 1 and not a.no_multi_seq:
+            out["eight_sequences_per_gpu"] = multi_seq_side_measurement(a, dev, bpl, dense_us)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, a.cpu_sample_s)
         else:
