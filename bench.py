@@ -277,8 +277,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("QUEST_BENCH_REHEARSE") == "1":
+            # rehearsal of the N > 1 control flow on a ONE-GPU box: all ranks share cuda:0, gloo collectives
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
     if not torch.cuda.is_available():
