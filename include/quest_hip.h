@@ -178,12 +178,15 @@ typedef struct quest_step_state {
     int32_t n_meta_pages;
     int32_t meta_last_page_len;
     int32_t meta_last_page_idx;
-    int32_t reserved;
+    int32_t reserved;           /* set to 1 by quest_step_state_advance when the pool is exhausted */
 } quest_step_state_t;
 
-/* Reserve room for one more token: the device-side prepare_metadata(1) (controller.py:72-76). */
+/* Reserve room for one more token: the device-side prepare_metadata(1) (controller.py:72-76).  The tables
+ * hold max_kv_pages / max_meta_pages entries (the pools' capacities); when the next token would not fit the
+ * state is left unchanged and `reserved` is set, so a replayed graph can never index past a table. */
 int quest_step_state_advance(quest_step_state_t* state, const int32_t* kv_table, const int32_t* meta_table,
-                             uint32_t page_size, quest_stream_t stream);
+                             uint32_t page_size, uint32_t max_kv_pages, uint32_t max_meta_pages,
+                             quest_stream_t stream);
 
 /* quest_append_estimate with lengths / last-page ids / n_out (= state->n_pages - 1) taken from `state`.
  * o is [num_qo_heads][o_stride] with o_stride >= max_n_out, the largest n_out the graph will ever see

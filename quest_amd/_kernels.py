@@ -236,7 +236,7 @@ def step_state_advance(state, kv_table, meta_table, page_size: int) -> None:
         _check_eq(t.dtype, torch.int32, f"{n}.scalar_type(), torch::kInt32")
     _check_eq(state.numel(), STEP_STATE_INTS, "state.numel(), 8")
     check(lib.quest_step_state_advance(state.data_ptr(), kv_table.data_ptr(), meta_table.data_ptr(), int(page_size),
-                                       _stream(state)), "step_state_advance")
+                                       kv_table.numel(), meta_table.numel(), _stream(state)), "step_state_advance")
 
 
 def append_estimate_dyn(k, v, kv_data, kv_table, q, o, metadata_data, meta_table, state, max_n_out: int,

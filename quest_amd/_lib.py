@@ -49,7 +49,7 @@ SIGNATURES = {
     "quest_decode_forward_shared": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp]),
     "quest_decode_forward_fused_topk": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_vp, c_vp,
                                                         c_vp, c_vp]),
-    "quest_step_state_advance": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_vp]),
+    "quest_step_state_advance": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
     "quest_append_estimate_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, c_u32, PagedKV, c_vp,
                                                   c_vp]),
     "quest_decode_forward_fused_topk_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32, c_vp,

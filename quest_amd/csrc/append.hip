@@ -86,10 +86,19 @@ __global__ __launch_bounds__(256) void append_prefill_kernel(quest_paged_kv_t kv
 }
 
 __global__ void step_state_advance_kernel(quest_step_state_t* st, const int32_t* __restrict__ kv_table,
-                                          const int32_t* __restrict__ meta_table, uint32_t S) {
+                                          const int32_t* __restrict__ meta_table, uint32_t S, uint32_t max_kv_pages,
+                                          uint32_t max_meta_pages) {
     // prepare_metadata(1) of quest/utils/controller.py:72-76 + kv_cache.py:115-126, on the device
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     quest_step_state_t s = *st;
+    if (s.kv_last_page_len == (int32_t)S &&
+        ((uint32_t)s.n_pages >= max_kv_pages ||
+         (s.meta_last_page_len == (int32_t)S && (uint32_t)s.n_meta_pages >= max_meta_pages))) {
+        // pool exhausted: stay on the last token (memory-safe; the host mirror raises "KvPool exhausted"
+        // right after the replay) and flag it
+        st->reserved = 1;
+        return;
+    }
     s.seq_len += 1;
     if (s.kv_last_page_len == (int32_t)S) {  // the token opens a new KV page ...
         s.n_pages += 1;
@@ -175,10 +184,11 @@ extern "C" int quest_append_kv_cache_prefill(const void* k, const void* v, uint3
 }
 
 extern "C" int quest_step_state_advance(quest_step_state_t* state, const int32_t* kv_table, const int32_t* meta_table,
-                                        uint32_t page_size, quest_stream_t stream) {
-    if (!state || !kv_table || !meta_table || page_size == 0) return QUEST_EINVAL;
+                                        uint32_t page_size, uint32_t max_kv_pages, uint32_t max_meta_pages,
+                                        quest_stream_t stream) {
+    if (!state || !kv_table || !meta_table || page_size == 0 || max_kv_pages == 0 || max_meta_pages == 0) return QUEST_EINVAL;
     hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, kv_table, meta_table,
-                       page_size);
+                       page_size, max_kv_pages, max_meta_pages);
     QUEST_LAUNCH_CHECK();
     return 0;
 }

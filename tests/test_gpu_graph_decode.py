@@ -141,3 +141,29 @@ def test_model_generation_graph_replay_equals_eager():
             assert torch.equal(out.float(), logits_e[t]), f"token {t}"
             tok = out.argmax(-1)
     assert graph.model.iController.kv_cache.seqlen == 300 + n_new
+
+
+def test_state_advance_stops_at_pool_capacity():
+    """A replayed graph must never index past the page tables: at capacity the device state stays put and
+    flags it (the host mirror raises 'KvPool exhausted')."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    ctl = qu.InferenceController(1, 2, 128, PAGE, 3, 64, torch.float16, dev)  # 4 pages of capacity
+    k = torch.zeros(60, 2, 128, dtype=torch.float16, device=dev)
+    ctl.prepare_metadata(60)
+    ctl.begin_forward(60)
+    qu.append_kv(k, k, ctl, 0)
+    ctl.end_forward()
+    ctl.enable_device_state()
+    for _ in range(4):
+        qu.step_advance_dyn(ctl)
+    st = ctl.step_state.cpu().tolist()
+    assert st[0] == 64 and st[1] == 4 and st[2] == 16 and st[7] == 0
+    qu.step_advance_dyn(ctl)  # would need a 5th page
+    st = ctl.step_state.cpu().tolist()
+    assert st[0] == 64 and st[1] == 4 and st[7] == 1
+    for _ in range(4):
+        ctl.prepare_metadata(1)
+    with pytest.raises(RuntimeError, match="KvPool exhausted"):
+        ctl.prepare_metadata(1)
