@@ -219,6 +219,51 @@ int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_heads, uint3
                                   float rope_scale, float rope_theta, const quest_step_state_t* state,
                                   quest_stream_t stream);
 
+/*
+ * Batched state-driven step (SURVEY.md 8f-3 second half: the reference fixes `constexpr batch_size = 1`,
+ * approx_attn.cu:113 / estimate.cu:14; BASELINE config 5 decodes 8 sequences per GPU).  One launch serves
+ * n_seqs independent sequences (grid.z / grid.y = sequence), no data is shared between them:
+ *   - ONE KV pool and ONE metadata pool hold every sequence's pages (`data` of the views below);
+ *   - page tables are rows of one int32 matrix: sequence i's table = indices + i * *_table_stride,
+ *     materialised up to its capacity like the single-sequence tables above;
+ *   - `state` is an array of n_seqs step states; q / o / k / v are [n_seqs][heads][dim], scores
+ *     [n_seqs][num_qo_heads][score_stride], lse [n_seqs][num_qo_heads].
+ * Results per sequence are bit-identical to the single-sequence *_dyn entry points.
+ */
+typedef struct quest_batch {
+    uint32_t n_seqs;
+    uint32_t kv_table_stride;   /* int32 entries between consecutive sequences' KV page tables */
+    uint32_t meta_table_stride; /* ... metadata page tables */
+    uint32_t reserved;
+} quest_batch_t;
+
+/* quest_step_state_advance for every sequence of the batch (tables: [n_seqs][*_table_stride], each row
+ * valid up to max_kv_pages / max_meta_pages entries). */
+int quest_step_state_advance_batched(quest_step_state_t* state, const int32_t* kv_tables, const int32_t* meta_tables,
+                                     uint32_t page_size, uint32_t max_kv_pages, uint32_t max_meta_pages,
+                                     quest_batch_t batch, quest_stream_t stream);
+int quest_append_estimate_batched(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                  uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                                  quest_paged_kv_t metadata, const quest_step_state_t* state, quest_batch_t batch,
+                                  quest_stream_t stream);
+/* The handler must have been planned for the batch: quest_decode_set_batch(h, n_seqs) before begin_forward. */
+int quest_decode_forward_fused_topk_batched(quest_decode_handler_t* h, const void* q, void* o,
+                                            quest_paged_kv_t paged_kv, uint32_t num_qo_heads, const void* scores,
+                                            uint32_t score_stride, uint32_t max_n_scores,
+                                            const quest_step_state_t* state, quest_batch_t batch, float* lse,
+                                            quest_stream_t stream);
+int quest_append_kv_cache_decode_batched(const void* k, const void* v, quest_paged_kv_t kv, quest_paged_kv_t metadata,
+                                         const quest_step_state_t* state, quest_batch_t batch, quest_stream_t stream);
+int quest_decode_forward_shared_batched(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                        uint32_t num_qo_heads, const quest_step_state_t* state, quest_batch_t batch,
+                                        float* lse, quest_stream_t stream);
+/* q: [n_seqs][num_qo_heads][dim], k: [n_seqs][num_kv_heads][dim]; row i sits at position state[i].seq_len - 1. */
+int quest_apply_rope_in_place_batched(void* q, void* k, uint32_t num_qo_heads, uint32_t num_kv_heads,
+                                      uint32_t head_dim, float rope_scale, float rope_theta,
+                                      const quest_step_state_t* state, quest_batch_t batch, quest_stream_t stream);
+/* Sequences per launch the next begin_forward plans (workspace, work split) for; default 1. */
+int quest_decode_set_batch(quest_decode_handler_t* h, uint32_t n_seqs);
+
 /* Introspection of the current plan (for benches/tests): pages per workgroup, workgroups per head. */
 int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_chunk,
                            uint32_t* chunks_per_head);

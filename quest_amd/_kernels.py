@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import PagedKV, check, lib
+from ._lib import Batch, PagedKV, check, lib
 
 _NHD, _HND = 0, 1
 
@@ -284,6 +284,79 @@ def apply_rope_in_place_dyn(q, k, rope_scale: float, rope_theta: float, state) -
           "apply_rope_in_place_dyn")
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Batched state-driven step (EXTENSION; SURVEY 8f-3, BASELINE config 5): n sequences per launch.  The pools
+# are shared, page tables are rows of ``[n, stride]`` int32 matrices, ``state`` is ``[n, 8]`` int32,
+# q/k/v/o are ``[n, heads, dim]``, scores ``[n, Hq, stride]``.
+def _batch(state, kv_tables, meta_tables) -> Batch:
+    _check_dim(2, state, "state")
+    n = state.size(0)
+    for t, name in ((kv_tables, "kv_tables"), (meta_tables, "meta_tables")):
+        if t is not None:
+            _check_input(t, name)
+            _check_dim(2, t, name)
+            _check_eq(t.size(0), n, f"{name}.size(0), n_seqs")
+            if t.dtype != torch.int32:
+                raise RuntimeError(f"{name} must be an int32 tensor")
+    return Batch(n, 0 if kv_tables is None else kv_tables.size(1), 0 if meta_tables is None else meta_tables.size(1), 0)
+
+
+def step_state_advance_batched(state, kv_tables, meta_tables, page_size: int) -> None:
+    _check_input(state, "state")
+    b = _batch(state, kv_tables, meta_tables)
+    check(lib.quest_step_state_advance_batched(state.data_ptr(), kv_tables.data_ptr(), meta_tables.data_ptr(),
+                                               int(page_size), kv_tables.size(1), meta_tables.size(1), b,
+                                               _stream(state)), "step_state_advance_batched")
+
+
+def append_estimate_batched(k, v, kv_data, kv_tables, q, o, metadata_data, meta_tables, state, max_n_out: int,
+                            layout: int) -> None:
+    for t, n in ((k, "k"), (v, "v"), (kv_data, "kv_data"), (q, "q"), (o, "o"), (metadata_data, "metadata_data"),
+                 (state, "state")):
+        _check_input(t, n)
+    b = _batch(state, kv_tables, meta_tables)
+    _check_dim(3, k, "k")
+    _check_dim(3, q, "q")
+    _check_dim(3, o, "o")
+    _check_eq(k.size(0), b.n_seqs, "k.size(0), n_seqs")
+    _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+    _check_eq(o.size(0), b.n_seqs, "o.size(0), n_seqs")
+    _check_eq(o.size(1), q.size(1), "o.size(1), num_heads")
+    _check_ge(o.size(2), max_n_out, "o.size(2), max_n_out")
+    _check_half(k, "Append_kv_cache_decode")
+    _check_half(q, "Estimate_attn_score")
+    kv = _paged(kv_data, kv_tables, None, 1, 0, layout)
+    meta = _paged(metadata_data, meta_tables, None, 1, 0, layout)
+    check(lib.quest_append_estimate_batched(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1),
+                                            o.size(2), int(max_n_out), meta, state.data_ptr(), b, _stream(k)),
+          "append_estimate_batched")
+
+
+def append_kv_cache_decode_batched(k, v, kv_data, kv_tables, metadata_data, meta_tables, state, layout: int) -> None:
+    for t, n in ((k, "k"), (v, "v"), (kv_data, "kv_data"), (metadata_data, "metadata_data"), (state, "state")):
+        _check_input(t, n)
+    b = _batch(state, kv_tables, meta_tables)
+    _check_eq(k.size(0), b.n_seqs, "k.size(0), n_seqs")
+    _check_half(k, "Append_kv_cache_decode")
+    kv = _paged(kv_data, kv_tables, None, 1, 0, layout)
+    meta = _paged(metadata_data, meta_tables, None, 1, 0, layout)
+    check(lib.quest_append_kv_cache_decode_batched(k.data_ptr(), v.data_ptr(), kv, meta, state.data_ptr(), b,
+                                                   _stream(k)), "Append_kv_cache_decode")
+
+
+def apply_rope_in_place_batched(q, k, rope_scale: float, rope_theta: float, state) -> None:
+    _check_input(q, "q")
+    _check_input(k, "k")
+    _check_input(state, "state")
+    b = _batch(state, None, None)
+    _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+    _check_eq(k.size(0), b.n_seqs, "k.size(0), n_seqs")
+    _check_half(q, "apply_rope_in_place")
+    check(lib.quest_apply_rope_in_place_batched(q.data_ptr(), k.data_ptr(), q.size(1), k.size(1), q.size(2),
+                                                float(rope_scale), float(rope_theta), state.data_ptr(), b,
+                                                _stream(q)), "apply_rope_in_place_batched")
+
+
 def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, causal: bool, layout: int,
                                 allow_fp16_qk_reduction: bool, rope_scale: float, rope_theta: float):
     """batch_prefill.cu:27-117 -- NOT on the sparse-decode path; torch SDPA over the gathered pages."""
@@ -437,6 +510,40 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         check(lib.quest_decode_forward_fused_topk_dyn(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1),
                                                       scores.data_ptr(), scores.size(1), int(max_n_scores),
                                                       state.data_ptr(), None, _stream(q)),
+              "BatchDecodeWithPagedKVCache")
+
+    def set_batch(self, n_seqs: int) -> None:
+        """Sequences per launch the NEXT begin_forward plans for (workspace, work split)."""
+        check(lib.quest_decode_set_batch(self._h, int(n_seqs)), "set_batch")
+
+    def forward_fused_topk_batched(self, q, o, paged_kv_data, kv_tables, scores, state, max_n_scores: int) -> None:
+        """forward_fused_topk_dyn for ``n`` sequences in one launch: q/o ``[n, Hq, D]``, scores ``[n, Hq, stride]``."""
+        for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (scores, "scores"), (state, "state")):
+            _check_input(t, n)
+        b = _batch(state, kv_tables, None)
+        _check_dim(3, q, "q")
+        _check_dim(3, scores, "scores")
+        _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+        _check_eq(scores.size(0), b.n_seqs, "scores.size(0), n_seqs")
+        _check_eq(scores.size(1), q.size(1), "scores.size(1), num_qo_heads")
+        _check_ge(scores.size(2), max_n_scores, "scores.size(2), max_n_scores")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, kv_tables, None, 1, 0, self._layout)
+        check(lib.quest_decode_forward_fused_topk_batched(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1),
+                                                          scores.data_ptr(), scores.size(2), int(max_n_scores),
+                                                          state.data_ptr(), b, None, _stream(q)),
+              "BatchDecodeWithPagedKVCache")
+
+    def forward_shared_batched(self, q, o, paged_kv_data, kv_tables, state) -> None:
+        for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (state, "state")):
+            _check_input(t, n)
+        b = _batch(state, kv_tables, None)
+        _check_dim(3, q, "q")
+        _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, kv_tables, None, 1, 0, self._layout)
+        check(lib.quest_decode_forward_shared_batched(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1),
+                                                      state.data_ptr(), b, None, _stream(q)),
               "BatchDecodeWithPagedKVCache")
 
     # introspection used by the bench / tuning sweeps (not part of the reference surface)

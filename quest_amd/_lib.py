@@ -32,6 +32,12 @@ class PagedKV(ctypes.Structure):
     ]
 
 
+class Batch(ctypes.Structure):
+    """quest_batch_t (include/quest_hip.h)."""
+
+    _fields_ = [("n_seqs", c_u32), ("kv_table_stride", c_u32), ("meta_table_stride", c_u32), ("reserved", c_u32)]
+
+
 # name -> (restype, argtypes); must list every function include/quest_hip.h declares
 SIGNATURES = {
     "quest_error_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -57,6 +63,16 @@ SIGNATURES = {
     "quest_append_kv_cache_decode_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp, c_vp]),
     "quest_decode_forward_shared_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp, c_vp]),
     "quest_apply_rope_in_place_dyn": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, c_vp]),
+    "quest_step_state_advance_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, Batch, c_vp]),
+    "quest_append_estimate_batched": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, c_u32, PagedKV,
+                                                      c_vp, Batch, c_vp]),
+    "quest_decode_forward_fused_topk_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32,
+                                                                c_vp, Batch, c_vp, c_vp]),
+    "quest_append_kv_cache_decode_batched": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp, Batch, c_vp]),
+    "quest_decode_forward_shared_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, Batch, c_vp, c_vp]),
+    "quest_apply_rope_in_place_batched": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, Batch,
+                                                          c_vp]),
+    "quest_decode_set_batch": (ctypes.c_int, [c_vp, c_u32]),
     "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),
     "quest_apply_rope_in_place": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp]),

@@ -16,8 +16,10 @@ __global__ __launch_bounds__(256) void append_decode_kernel(quest_paged_kv_t kv,
                                                             const uint16_t* __restrict__ key,
                                                             const uint16_t* __restrict__ value,
                                                             const quest_step_state_t* state) {
-    if (state) {  // state-driven launch: lengths / last-page ids from device memory
-        const quest_step_state_t st = *state;
+    if (state) {  // state-driven launch: lengths / last-page ids from device memory; blockIdx.y = sequence
+        const quest_step_state_t st = state[blockIdx.y];
+        key += (size_t)blockIdx.y * kv.num_heads * kv.head_dim;
+        value += (size_t)blockIdx.y * kv.num_heads * kv.head_dim;
         kv.last_page_len = (uint32_t)st.kv_last_page_len;
         kv.last_page_idx = st.kv_last_page_idx;
         meta.last_page_len = (uint32_t)st.meta_last_page_len;
@@ -87,9 +89,14 @@ __global__ __launch_bounds__(256) void append_prefill_kernel(quest_paged_kv_t kv
 
 __global__ void step_state_advance_kernel(quest_step_state_t* st, const int32_t* __restrict__ kv_table,
                                           const int32_t* __restrict__ meta_table, uint32_t S, uint32_t max_kv_pages,
-                                          uint32_t max_meta_pages) {
-    // prepare_metadata(1) of quest/utils/controller.py:72-76 + kv_cache.py:115-126, on the device
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                                          uint32_t max_meta_pages, quest_batch_t batch) {
+    // prepare_metadata(1) of quest/utils/controller.py:72-76 + kv_cache.py:115-126, on the device;
+    // one thread per sequence
+    const uint32_t seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= batch.n_seqs) return;
+    st += seq;
+    kv_table += (size_t)seq * batch.kv_table_stride;
+    meta_table += (size_t)seq * batch.meta_table_stride;
     quest_step_state_t s = *st;
     if (s.kv_last_page_len == (int32_t)S &&
         ((uint32_t)s.n_pages >= max_kv_pages ||
@@ -187,8 +194,38 @@ extern "C" int quest_step_state_advance(quest_step_state_t* state, const int32_t
                                         uint32_t page_size, uint32_t max_kv_pages, uint32_t max_meta_pages,
                                         quest_stream_t stream) {
     if (!state || !kv_table || !meta_table || page_size == 0 || max_kv_pages == 0 || max_meta_pages == 0) return QUEST_EINVAL;
+    const quest_batch_t one = {1, 0, 0, 0};
     hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, kv_table, meta_table,
-                       page_size, max_kv_pages, max_meta_pages);
+                       page_size, max_kv_pages, max_meta_pages, one);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int quest_step_state_advance_batched(quest_step_state_t* state, const int32_t* kv_tables,
+                                                const int32_t* meta_tables, uint32_t page_size, uint32_t max_kv_pages,
+                                                uint32_t max_meta_pages, quest_batch_t batch, quest_stream_t stream) {
+    if (!state || !kv_tables || !meta_tables || page_size == 0 || max_kv_pages == 0 || max_meta_pages == 0)
+        return QUEST_EINVAL;
+    if (batch.n_seqs == 0 || batch.kv_table_stride < max_kv_pages || batch.meta_table_stride < max_meta_pages)
+        return QUEST_EINVAL;
+    hipLaunchKernelGGL(step_state_advance_kernel, dim3((batch.n_seqs + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       state, kv_tables, meta_tables, page_size, max_kv_pages, max_meta_pages, batch);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int quest_append_kv_cache_decode_batched(const void* k, const void* v, quest_paged_kv_t kv,
+                                                    quest_paged_kv_t metadata, const quest_step_state_t* state,
+                                                    quest_batch_t batch, quest_stream_t stream) {
+    if (!k || !v || !state || batch.n_seqs == 0) return QUEST_EINVAL;
+    kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
+    const uint32_t threads = kv.num_heads * (kv.head_dim / kVec);
+    const uint32_t block = 256, grid = (threads + block - 1) / block;
+    hipLaunchKernelGGL(append_decode_kernel, dim3(grid, batch.n_seqs), dim3(block), 0, (hipStream_t)stream, kv, metadata,
+                       (const uint16_t*)k, (const uint16_t*)v, state);
     QUEST_LAUNCH_CHECK();
     return 0;
 }

@@ -30,6 +30,7 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
     const quest_step_state_t* state;  // optional device-resident lengths / last-page ids (graph replay)
     uint32_t o_stride;                // row stride of o (== n_out unless state-driven)
     uint32_t tile_heads;              // kv heads per workgroup tile (power of two dividing num_heads, <= 8)
+    uint32_t meta_table_stride;       // batched launches (blockIdx.y = sequence): entries between page tables
 };
 
 // Workgroup tile = EW entries x HW kv heads = 64 rows (D = 128): HW = tile_heads (8 for 8 or 32 kv heads), so
@@ -54,6 +55,15 @@ __global__ __launch_bounds__(kEstWaves* kWave) void estimate_kernel(const half_t
     // n_out as passed bounds every address (state-driven launches pass the largest n_out the graph will
     // see; page tables and pools cover it); the live n_out comes from the state further down.
     const uint32_t n_cap = n_out;
+    if (tail.state) {  // state-driven launches may be batched: blockIdx.y = sequence (0 for a single one)
+        const uint32_t seq = blockIdx.y;
+        tail.state += seq;
+        q += (size_t)seq * meta.num_heads * G * D;
+        o += (size_t)seq * meta.num_heads * G * tail.o_stride;
+        meta.indices += (size_t)seq * tail.meta_table_stride;
+        tail.key += (size_t)seq * meta.num_heads * D;
+        tail.value += (size_t)seq * meta.num_heads * D;
+    }
     if (tail.enabled && blockIdx.x >= tail.est_blocks) {
         if (tail.state) {
             const quest_step_state_t st = *tail.state;
@@ -182,7 +192,7 @@ static uint32_t pick_tile_heads(uint32_t num_heads, uint32_t G, uint32_t lpr) {
 
 template <int D, int G>
 static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, AppendTail tail,
-                           hipStream_t s) {
+                           hipStream_t s, uint32_t n_seqs) {
     constexpr int R = kWave / (D / kVec);
     constexpr uint32_t ROWS = kEstWaves * kEstIter * R;
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
@@ -193,7 +203,7 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     uint32_t blocks = tail.est_blocks;
     if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + 255) / 256;
     if (blocks == 0) return 0;
-    dim3 grid(blocks);
+    dim3 grid(blocks, n_seqs);
     const size_t lds = (size_t)hw * G * (2 * D + ew) * sizeof(half_t);
     if (hw * G * (D / kVec) > 2 * kEstWaves * kWave) return QUEST_EUNSUPPORTED;  // q staging capacity
     if (hnd)
@@ -208,12 +218,12 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
 
 template <int D>
 static int dispatch_group(uint32_t G, const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta,
-                          const AppendTail& tail, hipStream_t s) {
+                          const AppendTail& tail, hipStream_t s, uint32_t n_seqs) {
     switch (G) {
-        case 1: return launch_estimate<D, 1>(q, o, n_out, meta, tail, s);
-        case 2: return launch_estimate<D, 2>(q, o, n_out, meta, tail, s);
-        case 4: return launch_estimate<D, 4>(q, o, n_out, meta, tail, s);
-        case 8: return launch_estimate<D, 8>(q, o, n_out, meta, tail, s);
+        case 1: return launch_estimate<D, 1>(q, o, n_out, meta, tail, s, n_seqs);
+        case 2: return launch_estimate<D, 2>(q, o, n_out, meta, tail, s, n_seqs);
+        case 4: return launch_estimate<D, 4>(q, o, n_out, meta, tail, s, n_seqs);
+        case 8: return launch_estimate<D, 8>(q, o, n_out, meta, tail, s, n_seqs);
         default: return QUEST_EUNSUPPORTED;
     }
 }
@@ -227,7 +237,7 @@ int check_pool(const quest_paged_kv_t& p);  // append.hip
 }
 
 static int estimate_entry(const void* q, void* o, uint32_t num_qo_heads, uint32_t n_out, const quest_paged_kv_t& metadata,
-                          const AppendTail& tail, hipStream_t s) {
+                          const AppendTail& tail, hipStream_t s, uint32_t n_seqs = 1) {
     if (!q || !metadata.data || !metadata.indices) return QUEST_EINVAL;
     if (metadata.layout > QUEST_LAYOUT_HND || metadata.num_heads == 0 || metadata.page_size == 0) return QUEST_EINVAL;
     if (num_qo_heads == 0 || num_qo_heads % metadata.num_heads != 0) return QUEST_EINVAL;
@@ -235,9 +245,9 @@ static int estimate_entry(const void* q, void* o, uint32_t num_qo_heads, uint32_
     if (n_out == 0 && !tail.enabled) return 0;  // nothing to score (single page)
     const uint32_t G = num_qo_heads / metadata.num_heads;
     switch (metadata.head_dim) {
-        case 64: return dispatch_group<64>(G, q, o, n_out, metadata, tail, s);
-        case 128: return dispatch_group<128>(G, q, o, n_out, metadata, tail, s);
-        case 256: return dispatch_group<256>(G, q, o, n_out, metadata, tail, s);
+        case 64: return dispatch_group<64>(G, q, o, n_out, metadata, tail, s, n_seqs);
+        case 128: return dispatch_group<128>(G, q, o, n_out, metadata, tail, s, n_seqs);
+        case 256: return dispatch_group<256>(G, q, o, n_out, metadata, tail, s, n_seqs);
         default: return QUEST_EUNSUPPORTED;
     }
 }
@@ -248,11 +258,11 @@ extern "C" int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo
     return estimate_entry(q, o, num_qo_heads, n_out, metadata, tail, (hipStream_t)stream);
 }
 
-extern "C" int quest_append_estimate_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
-                                         uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
-                                         quest_paged_kv_t metadata, const quest_step_state_t* state,
-                                         quest_stream_t stream) {
-    if (!k || !v || !state || max_n_out == 0 || o_stride < max_n_out) return QUEST_EINVAL;
+static int append_estimate_state(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                 uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                                 quest_paged_kv_t metadata, const quest_step_state_t* state, quest_batch_t batch,
+                                 quest_stream_t stream) {
+    if (!k || !v || !state || max_n_out == 0 || o_stride < max_n_out || batch.n_seqs == 0) return QUEST_EINVAL;
     kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
     if (int e = check_pool(kv)) return e;
     if (int e = check_pool(metadata)) return e;
@@ -264,7 +274,25 @@ extern "C" int quest_append_estimate_dyn(const void* k, const void* v, quest_pag
     tail.enabled = 1;
     tail.state = state;
     tail.o_stride = o_stride;
-    return estimate_entry(q, o, num_qo_heads, max_n_out, metadata, tail, (hipStream_t)stream);
+    tail.meta_table_stride = batch.meta_table_stride;
+    return estimate_entry(q, o, num_qo_heads, max_n_out, metadata, tail, (hipStream_t)stream, batch.n_seqs);
+}
+
+extern "C" int quest_append_estimate_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                         uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                                         quest_paged_kv_t metadata, const quest_step_state_t* state,
+                                         quest_stream_t stream) {
+    const quest_batch_t one = {1, 0, 0, 0};
+    return append_estimate_state(k, v, kv, q, o, num_qo_heads, o_stride, max_n_out, metadata, state, one, stream);
+}
+
+extern "C" int quest_append_estimate_batched(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                             uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                                             quest_paged_kv_t metadata, const quest_step_state_t* state,
+                                             quest_batch_t batch, quest_stream_t stream) {
+    // every sequence's metadata table must cover the entries the grid is sized for
+    if (batch.n_seqs > 1 && (uint64_t)batch.meta_table_stride * metadata.page_size < max_n_out) return QUEST_EINVAL;
+    return append_estimate_state(k, v, kv, q, o, num_qo_heads, o_stride, max_n_out, metadata, state, batch, stream);
 }
 
 extern "C" int quest_append_estimate(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,

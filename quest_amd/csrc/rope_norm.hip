@@ -14,7 +14,7 @@ template <int D>
 __global__ __launch_bounds__(256) void rope_kernel(half_t* __restrict__ q, half_t* __restrict__ k, uint32_t n,
                                                    uint32_t past_len, uint32_t hq, uint32_t hk, float rcp_scale,
                                                    float log2_rcp_theta, const quest_step_state_t* state) {
-    if (state) past_len = (uint32_t)(state->seq_len - 1);  // decode token of a state-driven step
+    // state-driven: row i is the decode token of sequence i (one row for a single sequence)
     constexpr int LPR = D / kVec;
     constexpr int RPB = 256 / LPR;  // vectors per block
     const uint32_t vec = blockIdx.x * RPB + threadIdx.x / LPR;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void rope_kernel(half_t* __restrict__ q, half_
     half_t* x = (h < hq) ? q + ((size_t)tok * hq + h) * D : k + ((size_t)tok * hk + (h - hq)) * D;
     x += col * kVec;
     const float8 self = to_f32(ld8(x));
-    const float pos = (float)(past_len + tok);
+    const float pos = state ? (float)(state[tok].seq_len - 1) : (float)(past_len + tok);
     float8 out;
 #pragma unroll
     for (int i = 0; i < kVec; ++i) {
@@ -116,6 +116,14 @@ extern "C" int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_h
                                              const quest_step_state_t* state, quest_stream_t stream) {
     if (!state) return QUEST_EINVAL;
     return rope_entry(q, k, 1, 0, num_qo_heads, num_kv_heads, head_dim, rope_scale, rope_theta, state, stream);
+}
+
+extern "C" int quest_apply_rope_in_place_batched(void* q, void* k, uint32_t num_qo_heads, uint32_t num_kv_heads,
+                                                 uint32_t head_dim, float rope_scale, float rope_theta,
+                                                 const quest_step_state_t* state, quest_batch_t batch,
+                                                 quest_stream_t stream) {
+    if (!state || batch.n_seqs == 0) return QUEST_EINVAL;
+    return rope_entry(q, k, batch.n_seqs, 0, num_qo_heads, num_kv_heads, head_dim, rope_scale, rope_theta, state, stream);
 }
 
 extern "C" int quest_rms_norm_forward(const void* input, const void* weight, void* output, uint32_t rows, uint32_t cols,

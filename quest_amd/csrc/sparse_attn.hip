@@ -55,7 +55,34 @@ struct DecodeParams {
     uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
     uint32_t ids_lds_offset;
     const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
+    uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
 };
+
+// Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
+// batched tensor ([n_seqs][Hq][...]), the pools are shared.  A single-sequence launch has blockIdx.z == 0.
+// (Returned as a fresh set of pointers: rewriting the by-value kernel argument in place trips an
+// address-space inference bug in this compiler.)
+struct SeqView {
+    const half_t* q;
+    half_t* o;
+    float* lse;
+    const int32_t* indices;
+    const uint16_t* scores;
+    float* ws;
+    const quest_step_state_t* state;
+};
+__device__ __forceinline__ SeqView select_sequence(const DecodeParams& p, uint32_t num_qo_heads, uint32_t head_dim) {
+    const size_t seq = blockIdx.z, row = seq * num_qo_heads;
+    SeqView v;
+    v.q = p.q + row * head_dim;
+    v.o = p.o + row * head_dim;
+    v.lse = p.lse + row;  // only dereferenced when p.lse != nullptr
+    v.indices = p.indices + seq * p.table_stride;
+    v.scores = p.scores + row * p.score_stride;
+    v.ws = p.ws + row * p.n_chunks * p.ws_stride;
+    v.state = p.state + seq;  // only dereferenced when p.state != nullptr
+    return v;
+}
 
 constexpr int kFusedMaxPpc = 64;  // pages per workgroup the fused front end can stage in LDS
 
@@ -118,10 +145,11 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hq = blockIdx.y, hk = hq / p.group;
+    const SeqView sv = select_sequence(p, gridDim.y, D);
     // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
     // row length comes from the state
     if (FC == 0 && p.state) {  // no front end (not reachable through the C ABI today): plain up-front read
-        const quest_step_state_t st = *p.state;
+        const quest_step_state_t st = *sv.state;
         p.n_scores = (uint32_t)(st.n_pages - 1);
         p.last_page_len = (uint32_t)st.kv_last_page_len;
         p.last_page_idx = st.kv_last_page_idx;
@@ -131,18 +159,18 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
 
     // q is requested now but first used after the top-k front end, so its latency hides under the selection
-    const half8 q_raw = ld8(p.q + (size_t)hq * D + col * kVec);
+    const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);
 
     const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
     const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
-    const int32_t* idx_row = p.indices + (size_t)hq * p.idx_stride;  // uniform
+    const int32_t* idx_row = sv.indices + (size_t)hq * p.idx_stride;  // uniform
     RowState<D> st;
 
     __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
         if (p.state) {  // live lengths (the column ownership below depends on the live row length)
-            const quest_step_state_t st = *p.state;
+            const quest_step_state_t st = *sv.state;
             p.n_scores = (uint32_t)(st.n_pages - 1);
             p.last_page_len = (uint32_t)st.kv_last_page_len;
             p.last_page_idx = st.kv_last_page_idx;
@@ -151,8 +179,8 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         constexpr int NT = NW * kWave;
         const uint32_t cpt = topk_cols_per_thread<NT>(n);  // <= FC (FC is sized for n_cap >= n)
         const uint32_t c0 = threadIdx.x * cpt;
-        const uint16_t* srow = p.scores + (size_t)hq * p.score_stride;
-        const int32_t* table = p.indices;
+        const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
+        const int32_t* table = sv.indices;
         // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         uint16_t* keys_s = reinterpret_cast<uint16_t*>(fe_dyn);
@@ -190,7 +218,18 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             uint32_t slot;
             mine[i] = topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot) && slot >= slot_begin && slot < slot_end;
             my_slot[i] = slot;
-            if (mine[i]) s_sel[slot - slot_begin] = stage_ids ? ids_s[c0 + i] : table[c0 + i];
+            if (mine[i]) {
+                // two separate loads: a select between an LDS and a global ADDRESS becomes one flat load
+                // whose address-space cast this compiler miscompiles (illegal v_cmp on src_shared_base)
+                int32_t pg;
+                if (stage_ids) {
+                    pg = ids_s[c0 + i];
+                } else {
+                    pg = table[c0 + i];
+                    asm volatile("" : "+v"(pg));
+                }
+                s_sel[slot - slot_begin] = pg;
+            }
         }
         __syncthreads();
         // optional copy of the selection for callers that inspect it: issued after the barrier so no
@@ -313,10 +352,10 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             den += e * s_md[w][1];
         }
         if (p.n_chunks == 1) {
-            p.o[(size_t)hq * D + f] = (half_t)(acc / den);
-            if (p.lse && f == 0) p.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
+            sv.o[(size_t)hq * D + f] = (half_t)(acc / den);
+            if (p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
         } else {
-            float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
+            float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
             w[f] = acc;
             if (f == 0) {
                 w[D] = M;
@@ -338,9 +377,10 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hk = blockIdx.y;
+    const SeqView sv = select_sequence(p, gridDim.y * GS, D);
     if (p.state) {  // state-driven launch: the plan (chunks) was made for the pool capacity; workgroups whose
                     // chunk lies past the live page list write an empty partial (weight 0 in the merge)
-        const quest_step_state_t st = *p.state;
+        const quest_step_state_t st = *sv.state;
         p.n_sel = (uint32_t)(st.n_pages - 1);
         p.last_page_len = (uint32_t)st.kv_last_page_len;
         p.last_page_idx = st.kv_last_page_idx;
@@ -352,7 +392,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
     float8 qv[GS];
 #pragma unroll
     for (int g = 0; g < GS; ++g) {
-        qv[g] = to_f32(ld8(p.q + ((size_t)hk * GS + g) * D + col * kVec));
+        qv[g] = to_f32(ld8(sv.q + ((size_t)hk * GS + g) * D + col * kVec));
         qv[g] *= p.scale_log2;
     }
     const half_t* head_base = p.kv + (size_t)hk * p.st.head;
@@ -361,7 +401,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
     RowState<D> st[GS];
 
     for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += NW) {
-        const int32_t pg = __builtin_amdgcn_readfirstlane(s0 < p.n_sel ? p.indices[s0] : p.last_page_idx);
+        const int32_t pg = __builtin_amdgcn_readfirstlane(s0 < p.n_sel ? sv.indices[s0] : p.last_page_idx);
         const int len = s0 < p.n_sel ? S_T : (int)p.last_page_len;
         const half_t* b0 = head_base + (size_t)pg * p.st.page;
         half8 k[T], v[T];
@@ -442,10 +482,10 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
             den += e * s_md[w][g][1];
         }
         if (p.n_chunks == 1) {
-            p.o[(size_t)hq * D + f] = (half_t)(acc / den);
-            if (p.lse && f == 0) p.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
+            sv.o[(size_t)hq * D + f] = (half_t)(acc / den);
+            if (p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
         } else {
-            float* w = p.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
+            float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
             w[f] = acc;
             if (f == 0) {
                 w[D] = M;
@@ -573,12 +613,14 @@ struct quest_decode_handler {
     uint32_t ws_stride = 0;
     uint32_t dec_waves = 4;
     uint32_t shared_ppc = 0, shared_chunks = 0;  // plan of the group-shared kernel (grid.y = kv heads)
+    uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
 };
 
 // Workgroups the planner aims for: the kernel is built for 2 workgroups (8 waves) per CU, so 512
 // workgroups are one fully resident round on 256 CUs, each wave with 16 x 1 KiB loads in flight.
 static constexpr uint32_t kTargetWorkgroups = 512;
 static constexpr uint32_t kMaxChunks = 1024;  // merge kernel's LDS weight table
+static constexpr uint32_t kBatchRounds = 2;   // batched launches: resident rounds of workgroups aimed for
 
 extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout) {
     if (!out || layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
@@ -602,6 +644,12 @@ extern "C" int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint3
     return 0;
 }
 
+extern "C" int quest_decode_set_batch(quest_decode_handler_t* h, uint32_t n_seqs) {
+    if (!h || n_seqs == 0 || n_seqs > 65535u) return QUEST_EINVAL;  // grid.z limit
+    h->batch = n_seqs;
+    return 0;
+}
+
 extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_selected_pages, uint32_t num_qo_heads,
                                           uint32_t num_kv_heads, uint32_t head_dim, uint32_t page_size,
                                           quest_stream_t stream) {
@@ -619,16 +667,19 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     if (h->forced_ppc) {
         ppc = h->forced_ppc;
     } else {
-        uint32_t chunks = kTargetWorkgroups / num_qo_heads;
+        // a batch brings its own parallelism: the same number of workgroups is spread over the sequences
+        // (fewer, longer chunks per head -> fewer partials and fewer repeats of the fused selection)
+        uint32_t chunks = kTargetWorkgroups * (h->batch > 1 ? kBatchRounds : 1u) / (num_qo_heads * h->batch);
         if (chunks < 1) chunks = 1;
         if (chunks > n_slots) chunks = n_slots;
         ppc = (n_slots + chunks - 1) / chunks;
+        if (h->batch > 1 && ppc > (uint32_t)kFusedMaxPpc) ppc = kFusedMaxPpc;  // keep the fused front end usable
     }
     if ((n_slots + ppc - 1) / ppc > kMaxChunks) ppc = (n_slots + kMaxChunks - 1) / kMaxChunks;
     h->pages_per_chunk = ppc;
     h->n_chunks = (n_slots + ppc - 1) / ppc;
     {   // the group-shared kernel runs one workgroup per (chunk, KV head): plan it for the same 512 workgroups
-        uint32_t chunks = kTargetWorkgroups / num_kv_heads;
+        uint32_t chunks = kTargetWorkgroups * (h->batch > 1 ? kBatchRounds : 1u) / (num_kv_heads * h->batch);
         if (chunks < 1) chunks = 1;
         if (chunks > n_slots) chunks = n_slots;
         if (chunks > kMaxChunks) chunks = kMaxChunks;
@@ -639,7 +690,7 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     }
     h->ws_stride = (head_dim + 2 + 31) / 32 * 32;
     const uint32_t max_chunks = h->n_chunks > h->shared_chunks ? h->n_chunks : h->shared_chunks;
-    const size_t need = (size_t)num_qo_heads * max_chunks * h->ws_stride * sizeof(float);
+    const size_t need = (size_t)h->batch * num_qo_heads * max_chunks * h->ws_stride * sizeof(float);
     if (max_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
         if (h->ws) (void)hipFree(h->ws);
         h->ws = nullptr;
@@ -668,8 +719,8 @@ extern "C" int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t*
 
 template <int D, int FC>
 static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t waves,
-                            hipStream_t s) {
-    dim3 grid(h->n_chunks, num_qo_heads);
+                            hipStream_t s, uint32_t n_seqs) {
+    dim3 grid(h->n_chunks, num_qo_heads, n_seqs);
     const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)p.n_scores * 4 : 0) : 0;
     if (p.page_size == 16 && waves == 8)
         hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), lds, s, p);
@@ -678,8 +729,8 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     else
         hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), lds, s, p);
     QUEST_LAUNCH_CHECK();
-    if (h->n_chunks > 1) {
-        hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D * kMergeGroups), 0, s,
+    if (h->n_chunks > 1) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
+        hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, p.lse, h->n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
     }
@@ -689,13 +740,13 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
 // fc: fused top-k front end variant (0 = page ids come from an index tensor)
 template <int D>
 static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, int fc,
-                         uint32_t waves, hipStream_t s) {
+                         uint32_t waves, hipStream_t s, uint32_t n_seqs) {
     switch (fc) {
-        case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, waves, s);
-        case 8: return launch_decode_fc<D, 8>(h, p, num_qo_heads, waves, s);
-        case 16: return launch_decode_fc<D, 16>(h, p, num_qo_heads, waves, s);
-        case 32: return launch_decode_fc<D, 32>(h, p, num_qo_heads, waves, s);
-        case 64: return launch_decode_fc<D, 64>(h, p, num_qo_heads, waves, s);
+        case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, waves, s, n_seqs);
+        case 8: return launch_decode_fc<D, 8>(h, p, num_qo_heads, waves, s, n_seqs);
+        case 16: return launch_decode_fc<D, 16>(h, p, num_qo_heads, waves, s, n_seqs);
+        case 32: return launch_decode_fc<D, 32>(h, p, num_qo_heads, waves, s, n_seqs);
+        case 64: return launch_decode_fc<D, 64>(h, p, num_qo_heads, waves, s, n_seqs);
         default: return QUEST_EUNSUPPORTED;
     }
 }
@@ -703,10 +754,11 @@ static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, u
 static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
                         uint32_t num_qo_heads, const void* scores, uint32_t n_scores, void* topk_val_out,
                         int32_t* topk_idx_out, float* lse, hipStream_t s, uint32_t score_stride = 0,
-                        const quest_step_state_t* state = nullptr) {
+                        const quest_step_state_t* state = nullptr, quest_batch_t batch = {1, 0, 0, 0}) {
     if (state) kv.last_page_len = 1;  // placeholder; the kernel reads the real one from `state`
-    if (!h) return QUEST_EINVAL;
+    if (!h || batch.n_seqs == 0) return QUEST_EINVAL;
     if (!h->started) return QUEST_ESTATE;
+    if (batch.n_seqs > h->batch) return QUEST_ESTATE;  // workspace / plan were made for fewer sequences
     if (!q || !o || !kv.data) return QUEST_EINVAL;
     const bool fused = scores != nullptr;
     if (fused) {
@@ -751,6 +803,7 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
     p.state = state;
+    p.table_stride = batch.kv_table_stride;
     // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor
     int fc = 0;
     uint32_t waves = h->dec_waves;
@@ -763,9 +816,9 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
     }
     switch (kv.head_dim) {
-        case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s);
-        case 128: return launch_decode<128>(h, p, num_qo_heads, fc, waves, s);
-        case 256: return launch_decode<256>(h, p, num_qo_heads, fc, waves, s);
+        case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
+        case 128: return launch_decode<128>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
+        case 256: return launch_decode<256>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
         default: return QUEST_EUNSUPPORTED;
     }
 }
@@ -777,8 +830,8 @@ extern "C" int quest_decode_forward(quest_decode_handler_t* h, const void* q, vo
 
 template <int D>
 static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t gs,
-                         hipStream_t s) {
-    dim3 grid(p.n_chunks, num_qo_heads / gs), block(4 * kWave);
+                         hipStream_t s, uint32_t n_seqs) {
+    dim3 grid(p.n_chunks, num_qo_heads / gs, n_seqs), block(4 * kWave);
     switch (gs) {
         case 1: hipLaunchKernelGGL((shared_decode_kernel<D, 1, 4>), grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL((shared_decode_kernel<D, 2, 4>), grid, block, 0, s, p); break;
@@ -788,7 +841,7 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, u
     }
     QUEST_LAUNCH_CHECK();
     if (p.n_chunks > 1) {
-        hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads), dim3(D * kMergeGroups), 0, s,
+        hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, p.lse, p.n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
     }
@@ -796,10 +849,12 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, u
 }
 
 static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv, uint32_t num_qo_heads,
-                        float* lse, const quest_step_state_t* state, quest_stream_t stream) {
-    if (!h) return QUEST_EINVAL;
+                        float* lse, const quest_step_state_t* state, quest_stream_t stream,
+                        quest_batch_t batch = {1, 0, 0, 0}) {
+    if (!h || batch.n_seqs == 0) return QUEST_EINVAL;
     if (state) kv.last_page_len = 1;  // placeholder; read from `state` in the kernel
     if (!h->started) return QUEST_ESTATE;
+    if (batch.n_seqs > h->batch) return QUEST_ESTATE;
     if (!q || !o || !kv.data || (h->n_sel > 0 && !kv.indices)) return QUEST_EINVAL;
     if (kv.layout != h->layout || kv.head_dim != h->head_dim || kv.page_size != h->page_size ||
         kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
@@ -824,9 +879,10 @@ static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.scale_log2 = (float)(1.4426950408889634 / sqrt((double)kv.head_dim));
     p.ws_stride = h->ws_stride;
     p.state = state;
+    p.table_stride = batch.kv_table_stride;
     hipStream_t s = (hipStream_t)stream;
-    return kv.head_dim == 64 ? launch_shared<64>(h, p, num_qo_heads, p.group, s)
-                             : launch_shared<128>(h, p, num_qo_heads, p.group, s);
+    return kv.head_dim == 64 ? launch_shared<64>(h, p, num_qo_heads, p.group, s, batch.n_seqs)
+                             : launch_shared<128>(h, p, num_qo_heads, p.group, s, batch.n_seqs);
 }
 
 extern "C" int quest_decode_forward_shared(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
@@ -858,6 +914,26 @@ extern "C" int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, co
     // dispatch (keys per thread) is chosen for the longest row the graph will see
     return decode_entry(h, q, o, kv, num_qo_heads, scores, max_n_scores, nullptr, nullptr, lse, (hipStream_t)stream,
                         score_stride, state);
+}
+
+extern "C" int quest_decode_forward_fused_topk_batched(quest_decode_handler_t* h, const void* q, void* o,
+                                                       quest_paged_kv_t kv, uint32_t num_qo_heads, const void* scores,
+                                                       uint32_t score_stride, uint32_t max_n_scores,
+                                                       const quest_step_state_t* state, quest_batch_t batch, float* lse,
+                                                       quest_stream_t stream) {
+    if (!scores || !state || score_stride < max_n_scores) return QUEST_EINVAL;
+    if (batch.n_seqs > 1 && batch.kv_table_stride < max_n_scores + 1) return QUEST_EINVAL;
+    return decode_entry(h, q, o, kv, num_qo_heads, scores, max_n_scores, nullptr, nullptr, lse, (hipStream_t)stream,
+                        score_stride, state, batch);
+}
+
+extern "C" int quest_decode_forward_shared_batched(quest_decode_handler_t* h, const void* q, void* o,
+                                                   quest_paged_kv_t kv, uint32_t num_qo_heads,
+                                                   const quest_step_state_t* state, quest_batch_t batch, float* lse,
+                                                   quest_stream_t stream) {
+    if (!state) return QUEST_EINVAL;
+    if (h && batch.n_seqs > 1 && batch.kv_table_stride < h->n_sel + 1) return QUEST_EINVAL;
+    return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream, batch);
 }
 
 extern "C" const char* quest_error_string(int code) {

@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from .. import _kernels
-from .controller import InferenceController
+from .controller import BatchedInferenceController, InferenceController
 from .decode_wrapper import BatchDecodeWithPagedKVCacheWrapper
 from .kv_cache import KvCache
 from .utils import TensorLayout
@@ -34,6 +34,11 @@ __all__ = [
     "step_advance_dyn",
     "decode_layer_dyn",
     "decode_layer_dense_dyn",
+    # batched state-driven forms: n sequences per launch
+    "BatchedInferenceController",
+    "step_advance_batched",
+    "decode_layer_batched",
+    "decode_layer_dense_batched",
 ]
 
 
@@ -200,3 +205,45 @@ def decode_layer_dense_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iC
     ctl._dense_handler.forward_shared_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, ctl.step_state)
     return o
 
+
+
+# --------------------------------------------------------------------------------------------------
+# Batched state-driven step: the same three launches per layer serve every sequence of a
+# ``BatchedInferenceController`` (grid.z = sequence).  q/k/v are ``[n_seqs, heads, dim]``.
+
+def step_advance_batched(bController: BatchedInferenceController) -> None:
+    _kernels.step_state_advance_batched(bController.step_states, bController.kv_tables, bController.meta_tables,
+                                        bController.page_size)
+
+
+def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bController: BatchedInferenceController,
+                         layer_idx: int, scores: torch.Tensor, rope_scale: Optional[float] = None,
+                         rope_theta: Optional[float] = None, apply_rope: bool = False,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``decode_layer_dyn`` for every sequence at once; ``scores`` is ``[n_seqs, Hq, >= max_pages]`` fp16."""
+    b = bController
+    if apply_rope:
+        scale, theta = _rope_defaults(rope_scale, rope_theta)
+        _kernels.apply_rope_in_place_batched(q, k, scale, theta, b.step_states)
+    max_n = b.max_pages - 1
+    _kernels.append_estimate_batched(k, v, b.kv_layer(layer_idx), b.kv_tables, q, scores, b.metadata_layer(layer_idx),
+                                     b.meta_tables, b.step_states, max_n, b.layout)
+    o = torch.empty_like(q) if out is None else out
+    b._decode_handler.forward_fused_topk_batched(q, o, b.kv_layer(layer_idx), b.kv_tables, scores, b.step_states, max_n)
+    return o
+
+
+def decode_layer_dense_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                               bController: BatchedInferenceController, layer_idx: int,
+                               rope_scale: Optional[float] = None, rope_theta: Optional[float] = None,
+                               apply_rope: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``decode_layer_dense_dyn`` for every sequence at once (needs ``begin_graph_decode(dense_layers=True)``)."""
+    b = bController
+    if apply_rope:
+        scale, theta = _rope_defaults(rope_scale, rope_theta)
+        _kernels.apply_rope_in_place_batched(q, k, scale, theta, b.step_states)
+    _kernels.append_kv_cache_decode_batched(k, v, b.kv_layer(layer_idx), b.kv_tables, b.metadata_layer(layer_idx),
+                                            b.meta_tables, b.step_states, b.layout)
+    o = torch.empty_like(q) if out is None else out
+    b._dense_handler.forward_shared_batched(q, o, b.kv_layer(layer_idx), b.kv_tables, b.step_states)
+    return o

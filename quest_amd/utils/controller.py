@@ -28,7 +28,7 @@ class InferenceController:
                  page_budget,  # pages, including the last (current) page
                  max_seq_len,  # capacity of the KV / metadata pools, in tokens
                  dtype, device, num_kv_heads: Optional[int] = None, layout: int = TensorLayout.NHD,
-                 shuffle_seed: Optional[int] = None):
+                 shuffle_seed: Optional[int] = None, kv_pool=None, metadata_pool=None):
         self.num_heads = num_heads
         self.num_kv_heads = num_heads if num_kv_heads is None else num_kv_heads
         if self.num_heads % self.num_kv_heads != 0:
@@ -41,10 +41,11 @@ class InferenceController:
 
         max_kv_pages = (max_seq_len + page_size - 1) // page_size
         self.kv_cache = KvCache(num_layers, self.num_kv_heads, head_dim, max_seq_len, page_size, dtype, device,
-                                self.layout, shuffle_seed)
+                                self.layout, shuffle_seed, pool=kv_pool)
         # one metadata entry (max in the K slot, min in the V slot) per KV page: controller.py:29-37
         self.metadata_cache = KvCache(num_layers, self.num_kv_heads, head_dim, max_kv_pages, page_size, dtype, device,
-                                      self.layout, None if shuffle_seed is None else shuffle_seed + 1)
+                                      self.layout, None if shuffle_seed is None else shuffle_seed + 1,
+                                      pool=metadata_pool)
 
         self._page_budget = page_budget
         self._decode_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout=TensorLayout.FORMAT2STR[self.layout])
@@ -173,3 +174,86 @@ class InferenceController:
         self.metadata_cache.release()
         self._without_last_pages = -1
         self.inference_page_budget = None
+
+
+class BatchedInferenceController:
+    """``n_seqs`` independent sequences decoded with ONE launch per op (EXTENSION; SURVEY 8f-3: the reference
+    fixes ``batch_size = 1``, approx_attn.cu:113; BASELINE config 5 decodes 8 sequences per GPU).
+
+    All sequences share one KV pool and one metadata pool (each reserves its ``max_seq_len`` worth of pages up
+    front); ``self.seqs[i]`` is an ordinary ``InferenceController`` over those pools, so prefill and the eager
+    single-sequence ops work on each sequence exactly as before.  After prefill, ``enable_device_state()``
+    stacks the page tables / step states and the ``*_batched`` wrappers of ``quest_amd.utils`` run every
+    sequence of a decode step in one grid (grid.z = sequence); results per sequence are bit-identical to the
+    single-sequence path."""
+
+    def __init__(self, n_seqs, num_layers, num_heads, head_dim, page_size, page_budget, max_seq_len, dtype, device,
+                 num_kv_heads: Optional[int] = None, layout: int = TensorLayout.NHD,
+                 shuffle_seed: Optional[int] = None):
+        from .kv_cache import KvPool
+
+        if n_seqs <= 0:
+            raise ValueError("n_seqs must be positive")
+        self.n_seqs = n_seqs
+        self.num_heads = num_heads
+        self.num_kv_heads = num_heads if num_kv_heads is None else num_kv_heads
+        self.head_dim, self.page_size, self.device, self.dtype = head_dim, page_size, device, dtype
+        self.layout = TensorLayout.parse(layout)
+        self._page_budget = page_budget
+        pages = (max_seq_len + page_size - 1) // page_size
+        meta_pages = (pages + page_size - 1) // page_size
+        self.kv_pool = KvPool(num_layers, self.num_kv_heads, head_dim, n_seqs * pages, page_size, dtype, device,
+                              self.layout, shuffle_seed)
+        self.metadata_pool = KvPool(num_layers, self.num_kv_heads, head_dim, n_seqs * meta_pages, page_size, dtype,
+                                    device, self.layout, None if shuffle_seed is None else shuffle_seed + 1)
+        self.seqs = [InferenceController(num_layers, num_heads, head_dim, page_size, page_budget, max_seq_len, dtype,
+                                         device, num_kv_heads=num_kv_heads, layout=layout, kv_pool=self.kv_pool,
+                                         metadata_pool=self.metadata_pool) for _ in range(n_seqs)]
+        self._decode_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout=TensorLayout.FORMAT2STR[self.layout])
+        self._dense_handler = None
+
+    def kv_layer(self, layer_idx: int) -> torch.Tensor:
+        return self.kv_pool.buf[layer_idx]
+
+    def metadata_layer(self, layer_idx: int) -> torch.Tensor:
+        return self.metadata_pool.buf[layer_idx]
+
+    def prepare_metadata(self, seq_len: int = 1) -> None:
+        """Host mirror of the device-side reservation (``step_advance_batched``) for every sequence."""
+        for c in self.seqs:
+            c.prepare_metadata(seq_len)
+
+    def enable_device_state(self) -> None:
+        self.kv_tables = torch.stack([c.kv_cache.full_device_table() for c in self.seqs]).contiguous()
+        self.meta_tables = torch.stack([c.metadata_cache.full_device_table() for c in self.seqs]).contiguous()
+        self.max_pages = self.kv_tables.size(1)
+        self.step_states = torch.zeros(self.n_seqs, 8, dtype=torch.int32, device=self.device)
+        self.sync_device_state()
+
+    def sync_device_state(self) -> None:
+        rows = []
+        for c in self.seqs:
+            kv, meta = c.kv_cache, c.metadata_cache
+            rows.append([kv.seqlen, len(kv.indicies), kv.last_page_len, kv.indicies[-1], len(meta.indicies),
+                         meta.last_page_len, meta.indicies[-1], 0])
+        self.step_states.copy_(torch.tensor(rows, dtype=torch.int32))
+
+    def begin_graph_decode(self, dense_layers: bool = False) -> None:
+        """Plan the batched sparse decode once for the configured budget (every sequence must already be in
+        the sparse regime), and optionally the batched full-KV decode over the per-sequence capacity."""
+        budget = self._page_budget
+        assert all(len(c.kv_cache.indicies) >= budget for c in self.seqs), "graph decode needs pages >= budget"
+        self.inference_page_budget = budget
+        self._decode_handler.set_batch(self.n_seqs)
+        self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
+                                           self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
+        if dense_layers:
+            if self._dense_handler is None:
+                self._dense_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout=TensorLayout.FORMAT2STR[self.layout])
+            self._dense_handler.set_batch(self.n_seqs)
+            self._dense_handler.begin_forward(torch.tensor([0, self.max_pages - 1], dtype=torch.int32), self.num_heads,
+                                              self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
+
+    def clean_states(self) -> None:
+        for c in self.seqs:
+            c.clean_states()

@@ -49,6 +49,15 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
         self._wrapper.forward_fused_topk_dyn(q, o, paged_kv_data, page_table, scores, state, max_n_scores)
 
+    def set_batch(self, n_seqs: int) -> None:
+        self._wrapper.set_batch(n_seqs)
+
+    def forward_fused_topk_batched(self, q, o, paged_kv_data, kv_tables, scores, state, max_n_scores: int) -> None:
+        self._wrapper.forward_fused_topk_batched(q, o, paged_kv_data, kv_tables, scores, state, max_n_scores)
+
+    def forward_shared_batched(self, q, o, paged_kv_data, kv_tables, state) -> None:
+        self._wrapper.forward_shared_batched(q, o, paged_kv_data, kv_tables, state)
+
     def plan_info(self):
         return self._wrapper.plan_info()
 

@@ -77,11 +77,19 @@ class KvCache:
     """Key-value cache (or its min/max metadata) of one sequence."""
 
     def __init__(self, num_layers, num_heads, head_dim, max_seq_len: int, page_size, dtype: torch.dtype, device,
-                 layout: int = TensorLayout.NHD, shuffle_seed: Optional[int] = None):
+                 layout: int = TensorLayout.NHD, shuffle_seed: Optional[int] = None, pool: Optional[KvPool] = None):
         if max_seq_len <= 0:
             raise ValueError("init_len must be non-negative")
         capacity = (max_seq_len + page_size - 1) // page_size
-        self._pool = KvPool(num_layers, num_heads, head_dim, capacity, page_size, dtype, device, layout, shuffle_seed)
+        if pool is None:
+            self._pool = KvPool(num_layers, num_heads, head_dim, capacity, page_size, dtype, device, layout, shuffle_seed)
+            self._reserve: Optional[List[int]] = None
+        else:
+            # EXTENSION (batched decode): several sequences share one pool; each takes its `capacity` pages up
+            # front so that the order it will use them in is known (full_device_table) whatever the others do
+            self._pool = pool
+            self._reserve = [pool.alloc_block() for _ in range(capacity)][::-1]
+        self._capacity = capacity
         self._indicies: List[int] = []
         self._seqlen = 0
         self._table = torch.empty(capacity, dtype=torch.int32, device=device)  # device mirror of _indicies
@@ -116,9 +124,20 @@ class KvCache:
         S = self._pool.block_len
         need = (self._seqlen + seq_len + S - 1) // S - len(self._indicies)
         for _ in range(need):
-            self._indicies.append(self._pool.alloc_block())
+            self._indicies.append(self._alloc())
         self._seqlen += seq_len
         return need
+
+    @property
+    def capacity_pages(self) -> int:
+        return self._capacity
+
+    def _alloc(self) -> int:
+        if self._reserve is None:
+            return self._pool.alloc_block()
+        if not self._reserve:
+            raise RuntimeError("KvPool exhausted: max_seq_len too small for this sequence")
+        return self._reserve.pop()
 
     def device_table(self) -> torch.Tensor:
         """int32 device view of the page table, synchronised lazily (only the new tail is copied)."""
@@ -134,12 +153,15 @@ class KvCache:
         use followed by the free list in the order ``alloc_block`` will hand them out.  Valid because the
         pool belongs to this sequence alone (kv_cache.py:86-94 builds one pool per KvCache).  Used by the
         device-resident step state: page i of the sequence is ``table[i]`` before it is allocated."""
-        future = list(reversed(self._pool._free))
+        future = list(reversed(self._pool._free if self._reserve is None else self._reserve))
         return torch.tensor(self._indicies + future, dtype=torch.int32, device=self._table.device)
 
     def release(self) -> None:
         self._seqlen = 0
-        for idx in self._indicies:
-            self._pool.free_block(idx)
+        if self._reserve is None:
+            for idx in self._indicies:
+                self._pool.free_block(idx)
+        else:  # pages stay reserved for this sequence's next request, to be used in the same order
+            self._reserve.extend(reversed(self._indicies))
         self._indicies.clear()
         self._table_len = 0

@@ -1,0 +1,222 @@
+"""Batched state-driven decode (n sequences per launch, one shared pool) must reproduce, per sequence, what
+the single-sequence state-driven path computes: states, pool bytes, estimates and selections bit for bit,
+attention outputs bit for bit when the work split is the same and within the attention tolerance otherwise."""
+import numpy as np
+import pytest
+import torch
+
+from _harness import cuda, inputs
+
+pytestmark = pytest.mark.gpu
+PAGE = 16
+
+
+def _prefill(ctl, k, v, layers):
+    import quest_amd.utils as qu
+
+    L = k.shape[0]
+    ctl.prepare_metadata(L)
+    ctl.begin_forward(L)
+    for l in range(layers):
+        qu.append_kv(k, v, ctl, l)
+    ctl.end_forward()
+
+
+def _gather(buf_layer, indices, n_entries, layout):
+    """Logical [n_entries, H, D] K-slot / V-slot rows of a pool layer (device tensors)."""
+    idx = torch.tensor(list(indices), device=buf_layer.device)
+    pages = buf_layer[idx]
+    if layout == 1:
+        pages = pages.permute(0, 1, 3, 2, 4)
+    n, _, S, H, D = pages.shape
+    return pages[:, 0].reshape(n * S, H, D)[:n_entries], pages[:, 1].reshape(n * S, H, D)[:n_entries]
+
+
+@pytest.mark.parametrize("Hq,Hkv,layout,lens,same_split", [
+    (4, 4, 0, (16 * 31 + 10, 16 * 20 + 16, 16 * 40 + 1), True),
+    (8, 2, 1, (16 * 15 + 16, 16 * 33 + 5), True),
+    (8, 8, 0, (16 * 70 + 3, 16 * 24 + 15, 16 * 24 + 16, 16 * 50 + 8, 16 * 9 + 9), False),
+])
+def test_batched_decode_matches_single_sequence(Hq, Hkv, layout, lens, same_split):
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    layers, D, B, steps = 2, 128, 7, 36
+    n = len(lens)
+    cap = max(lens) + steps + 40
+    ks = [cuda(inputs(100 + i, L, Hq, Hkv, D)[1]) for i, L in enumerate(lens)]
+    vs = [cuda(inputs(100 + i, L, Hq, Hkv, D)[2]) for i, L in enumerate(lens)]
+    g = torch.Generator(device=dev).manual_seed(5)
+    new_q = torch.randn(steps, layers, n, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, layers, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, layers, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    # ---- reference: every sequence alone (own pools), single-sequence state-driven ops
+    singles, single_out, single_scores = [], [], []
+    for i, L in enumerate(lens):
+        c = qu.InferenceController(layers, Hq, D, PAGE, B, cap, torch.float16, dev, num_kv_heads=Hkv, layout=layout,
+                                   shuffle_seed=40 + i)
+        _prefill(c, ks[i], vs[i], layers)
+        c.enable_device_state()
+        if same_split:
+            c._decode_handler.set_pages_per_chunk(2)
+        c.begin_graph_decode()
+        singles.append(c)
+    for t in range(steps):
+        outs, scs = [], []
+        for i, c in enumerate(singles):
+            qu.step_advance_dyn(c)
+            sc = torch.zeros(layers, Hq, c.max_pages, device=dev, dtype=torch.float16)
+            o = []
+            for l in range(layers):
+                q, k = new_q[t, l, i:i + 1].clone(), new_k[t, l, i:i + 1].clone()
+                o.append(qu.decode_layer_dyn(q, k, new_v[t, l, i:i + 1], c, l, sc[l], apply_rope=True))
+            c.prepare_metadata(1)
+            outs.append(torch.stack(o))  # [layers, 1, Hq, D]
+            scs.append(sc)
+        single_out.append(torch.cat(outs, dim=1))  # [layers, n, Hq, D]
+        single_scores.append(scs)
+
+    # ---- batched: one shared pool, one launch per op for all sequences, captured once and replayed
+    b = qu.BatchedInferenceController(n, layers, Hq, D, PAGE, B, cap, torch.float16, dev, num_kv_heads=Hkv,
+                                      layout=layout, shuffle_seed=9)
+    for i in range(n):
+        _prefill(b.seqs[i], ks[i], vs[i], layers)
+    b.enable_device_state()
+    if same_split:
+        b._decode_handler.set_pages_per_chunk(2)
+    b.begin_graph_decode()
+    qbuf = torch.empty(layers, n, Hq, D, device=dev, dtype=torch.float16)
+    kbuf = torch.empty(layers, n, Hkv, D, device=dev, dtype=torch.float16)
+    vbuf = torch.empty(layers, n, Hkv, D, device=dev, dtype=torch.float16)
+    scores = torch.zeros(layers, n, Hq, b.max_pages, device=dev, dtype=torch.float16)
+    obuf = torch.empty(layers, n, Hq, D, device=dev, dtype=torch.float16)
+
+    def step():
+        qu.step_advance_batched(b)
+        for l in range(layers):
+            qu.decode_layer_batched(qbuf[l], kbuf[l], vbuf[l], b, l, scores[l], apply_rope=True, out=obuf[l])
+
+    qbuf.copy_(new_q[0]); kbuf.copy_(new_k[0]); vbuf.copy_(new_v[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()  # warm-up; the same token is folded again by the first replay (idempotent)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    b.sync_device_state()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    b.sync_device_state()
+
+    for t in range(steps):
+        qbuf.copy_(new_q[t]); kbuf.copy_(new_k[t]); vbuf.copy_(new_v[t])
+        graph.replay()
+        b.prepare_metadata(1)
+        st = b.step_states.cpu().tolist()
+        for i, c in enumerate(b.seqs):
+            kv, meta = c.kv_cache, c.metadata_cache
+            assert st[i][:7] == [kv.seqlen, len(kv.indicies), kv.last_page_len, kv.indicies[-1], len(meta.indicies),
+                                 meta.last_page_len, meta.indicies[-1]], f"token {t} seq {i}: state"
+            assert st[i][7] == 0
+            n_out = len(kv.indicies) - 1
+            for l in range(layers):  # estimates are bit-exact whatever the work split
+                assert torch.equal(scores[l, i, :, :n_out], single_scores[t][i][l][:, :n_out]), \
+                    f"token {t} seq {i} layer {l}: estimate"
+        if same_split:
+            assert torch.equal(obuf, single_out[t]), f"token {t}: batched output differs from single-sequence"
+        else:
+            torch.testing.assert_close(obuf.float(), single_out[t].float(), rtol=2e-3, atol=2e-3)
+
+    # pools: every sequence's logical KV rows and metadata entries are the same bits as in its own pool
+    for i, (c, s) in enumerate(zip(b.seqs, singles)):
+        L = c.kv_cache.seqlen
+        assert L == lens[i] + steps == s.kv_cache.seqlen
+        for l in range(layers):
+            bk, bv = _gather(b.kv_layer(l), c.kv_cache.indicies, L, layout)
+            sk, sv = _gather(s.kv_cache.buf_layer(l), s.kv_cache.indicies, L, layout)
+            assert torch.equal(bk, sk) and torch.equal(bv, sv), f"seq {i} layer {l}: KV pool"
+            np_ = len(c.kv_cache.indicies)
+            bmx, bmn = _gather(b.metadata_layer(l), c.metadata_cache.indicies, np_, layout)
+            smx, smn = _gather(s.metadata_cache.buf_layer(l), s.metadata_cache.indicies, np_, layout)
+            assert torch.equal(bmx, smx) and torch.equal(bmn, smn), f"seq {i} layer {l}: metadata pool"
+    # no page is owned by two sequences
+    owned = [p for c in b.seqs for p in c.kv_cache.indicies]
+    assert len(owned) == len(set(owned))
+
+
+def test_batched_dense_layer_matches_single_sequence():
+    """Full-KV (dense) layers of a batched step: append + group-shared attention over all pages."""
+    import quest_amd.utils as qu
+    from quest_amd.utils.decode_wrapper import BatchDecodeWithPagedKVCacheWrapper
+
+    dev = torch.device("cuda:0")
+    Hq, Hkv, D, B, layers, steps = 8, 2, 128, 6, 1, 20
+    lens = (16 * 12 + 16, 16 * 30 + 7, 16 * 21 + 1)
+    n, cap = len(lens), max(lens) + steps + 30
+    ks = [cuda(inputs(200 + i, L, Hq, Hkv, D)[1]) for i, L in enumerate(lens)]
+    vs = [cuda(inputs(200 + i, L, Hq, Hkv, D)[2]) for i, L in enumerate(lens)]
+    g = torch.Generator(device=dev).manual_seed(8)
+    new_q = torch.randn(steps, n, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    singles = []
+    for i, L in enumerate(lens):
+        c = qu.InferenceController(layers, Hq, D, PAGE, B, cap, torch.float16, dev, num_kv_heads=Hkv)
+        _prefill(c, ks[i], vs[i], layers)
+        c.enable_device_state()
+        c._dense_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout="NHD")
+        c._dense_handler.set_pages_per_chunk(4)  # same work split as the batched plan -> bit-identical merge
+        c.begin_graph_decode(dense_layers=True)
+        singles.append(c)
+    b = qu.BatchedInferenceController(n, layers, Hq, D, PAGE, B, cap, torch.float16, dev, num_kv_heads=Hkv)
+    for i in range(n):
+        _prefill(b.seqs[i], ks[i], vs[i], layers)
+    b.enable_device_state()
+    b._dense_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout="NHD")
+    b._dense_handler.set_pages_per_chunk(4)
+    b.begin_graph_decode(dense_layers=True)
+    for t in range(steps):
+        ref = []
+        for i, c in enumerate(singles):
+            qu.step_advance_dyn(c)
+            q, k = new_q[t, i:i + 1].clone(), new_k[t, i:i + 1].clone()
+            ref.append(qu.decode_layer_dense_dyn(q, k, new_v[t, i:i + 1], c, 0, apply_rope=True))
+            c.prepare_metadata(1)
+        qu.step_advance_batched(b)
+        q, k = new_q[t].clone(), new_k[t].clone()
+        got = qu.decode_layer_dense_batched(q, k, new_v[t], b, 0, apply_rope=True)
+        b.prepare_metadata(1)
+        assert torch.equal(got, torch.cat(ref)), f"token {t}"
+
+
+def test_batched_argument_errors():
+    import quest_amd.utils as qu
+    from quest_amd import _kernels
+
+    dev = torch.device("cuda:0")
+    b = qu.BatchedInferenceController(2, 1, 4, 128, PAGE, 4, 400, torch.float16, dev)
+    for c in b.seqs:
+        k = torch.zeros(200, 4, 128, device=dev, dtype=torch.float16)
+        _prefill(c, k, k, 1)
+    b.enable_device_state()
+    q = torch.zeros(2, 4, 128, device=dev, dtype=torch.float16)
+    o = torch.empty_like(q)
+    scores = torch.zeros(2, 4, b.max_pages, device=dev, dtype=torch.float16)
+    # handler planned for one sequence only -> refuses a batch of two
+    b._decode_handler.begin_forward(torch.tensor([0, 3], dtype=torch.int32), 4, 4, 128, PAGE, torch.float16)
+    with pytest.raises(RuntimeError, match="begin_forward"):
+        b._decode_handler.forward_fused_topk_batched(q, o, b.kv_layer(0), b.kv_tables, scores, b.step_states,
+                                                     b.max_pages - 1)
+    b.begin_graph_decode()
+    # q batch size disagrees with the states
+    with pytest.raises(RuntimeError):
+        b._decode_handler.forward_fused_topk_batched(q[:1], o[:1], b.kv_layer(0), b.kv_tables, scores, b.step_states,
+                                                     b.max_pages - 1)
+    with pytest.raises(RuntimeError):
+        _kernels.append_estimate_batched(q[:1], q[:1], b.kv_layer(0), b.kv_tables, q, scores, b.metadata_layer(0),
+                                         b.meta_tables, b.step_states, b.max_pages - 1, 0)
+    with pytest.raises(ValueError):
+        b._decode_handler.set_batch(0)
