@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--seqs-per-gpu", type=int, default=1,
                     help="independent sequences per GPU (BASELINE configs[4] uses 8); each runs its chain on its "
                          "own HIP stream inside the step graph so their latency phases overlap")
+    ap.add_argument("--multi-seq-mode", choices=["batched", "streams"], default="batched",
+                    help="with --seqs-per-gpu > 1: batched = ONE launch per op for all sequences over a shared pool "
+                         "(grid.z = sequence, quest_*_batched); streams = one chain per sequence on its own stream")
+    ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
     ap.add_argument("--no-multi-seq", action="store_true",
                     help="skip the side measurement with 8 sequences per GPU (BASELINE configs[4]'s per-GPU load)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,6 +155,56 @@ class Workload:
         return o
 
 
+class BatchedWorkload:
+    """n sequences sharing one pool, decoded with one launch per op (quest_amd.utils.*_batched)."""
+
+    dyn = True
+
+    def __init__(self, a, dev, n_seqs, seq_id0=0):
+        import quest_amd.utils as qu
+
+        self.qu, self.a, self.dev, self.n = qu, a, dev, n_seqs
+        self.page_budget = a.token_budget // a.page_size
+        L = a.seqlen
+        self.ctl = qu.BatchedInferenceController(n_seqs, a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
+                                                 L + a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,
+                                                 num_kv_heads=a.kv_heads, layout=a.layout, shuffle_seed=1234)
+        kbuf = torch.empty(L - 1, a.kv_heads, a.head_dim, dtype=torch.float16, device=dev)
+        vbuf = torch.empty_like(kbuf)
+        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id0)
+        for c in self.ctl.seqs:
+            c.prepare_metadata(L - 1)
+            c.begin_forward(L - 1)
+            for layer in range(a.layers):
+                kbuf.normal_(generator=g)
+                vbuf.normal_(generator=g)
+                qu.append_kv(kbuf, vbuf, c, layer)
+            c.end_forward()
+        del kbuf, vbuf
+        self.q = torch.randn(a.layers, n_seqs, a.heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
+        self.k1 = torch.randn(a.layers, n_seqs, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
+        self.v1 = torch.randn(a.layers, n_seqs, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
+        self.o = torch.empty_like(self.q)
+        self.ctl.enable_device_state()
+        if a.pages_per_chunk:
+            self.ctl._decode_handler.set_pages_per_chunk(a.pages_per_chunk)
+        self.ctl.begin_graph_decode()
+        self.scores = torch.empty(n_seqs, a.heads, self.ctl.max_pages, dtype=torch.float16, device=dev)
+
+    def step(self):
+        qu, b, a = self.qu, self.ctl, self.a
+        qu.step_advance_batched(b)
+        for layer in range(a.layers):
+            qu.decode_layer_batched(self.q[layer], self.k1[layer], self.v1[layer], b, layer, self.scores,
+                                    out=self.o[layer])
+
+    def after_replay(self):
+        self.ctl.prepare_metadata(1)
+
+    def sync(self):
+        self.ctl.sync_device_state()
+
+
 def bytes_per_layer(a):
     """Algorithmic bytes of one layer-step, SURVEY.md 8(d) accounting (= the reference benches')."""
     S, D, Hq, Hkv = a.page_size, a.head_dim, a.heads, a.kv_heads
@@ -192,25 +246,61 @@ def time_kernel_loop(fn, layers, reps):
     return e0.elapsed_time(e1) * 1e3 / (reps * layers)  # us
 
 
-def multi_seq_side_measurement(a, dev, bpl, dense_us, n_seqs=8, layers=8):
+def batched_op_times(bw, bpl):
+    """HIP-event time of the two batched launches of a layer (graph of one launch per layer, as in
+    time_kernel_loop) and the HBM figures they amount to."""
+    from quest_amd import _kernels
+
+    b, n = bw.ctl, bw.n
+    max_n = b.max_pages - 1
+
+    def ae(l):
+        _kernels.append_estimate_batched(bw.k1[l], bw.v1[l], b.kv_layer(l), b.kv_tables, bw.q[l], bw.scores,
+                                         b.metadata_layer(l), b.meta_tables, b.step_states, max_n, b.layout)
+
+    def ts(l):
+        b._decode_handler.forward_fused_topk_batched(bw.q[l], bw.o[l], b.kv_layer(l), b.kv_tables, bw.scores,
+                                                     b.step_states, max_n)
+
+    t_ae = time_kernel_loop(ae, bw.a.layers, 10)
+    t_ts = time_kernel_loop(ts, bw.a.layers, 10)
+    ppc, chunks = b._decode_handler.plan_info()
+    return {"batched_append_estimate_us": t_ae, "batched_topk_sparse_attn_us": t_ts,
+            "batched_append_estimate_gbs": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9,
+            "batched_topk_sparse_attn_gbs": n * (bpl["topk"] + bpl["attn"]) / (t_ts * 1e-6) / 1e9,
+            "batched_sparse_attn_frac_of_hbm_peak": n * bpl["attn"] / (t_ts * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}}
+
+
+def multi_seq_side_measurement(a, dev, bpl, dense_us, n_seqs=8, layers=8, mode="batched"):
     """Side figure (not `value`): the same chain with 8 independent sequences on one GPU -- the per-GPU load
-    of BASELINE configs[4] -- each on its own stream inside one step graph, so the fixed latencies of one
-    sequence's kernels overlap the data movement of another's.  8 layers per sequence keep it short."""
+    of BASELINE configs[4].  batched: one launch per op serves all sequences (shared pool, grid.z = sequence);
+    streams: each sequence's chain on its own stream inside one step graph.  Either way the fixed latencies
+    of one sequence's kernels overlap the data movement of another's.  8 layers per sequence keep it short."""
     import copy
 
     b = copy.copy(a)
-    b.layers, b.mode, b.steps, b.warmup = layers, "graph-static", 30, 5
-    ws = [Workload(b, dev, 100 + i) for i in range(n_seqs)]
-    streams = [torch.cuda.Stream() for _ in ws]
+    b.layers, b.steps, b.warmup = layers, 30, 5
+    if mode == "batched":
+        b.mode = "graph"
+        bw = BatchedWorkload(b, dev, n_seqs, 100)
+        ws = [bw]
 
-    def step_all():
-        cur = torch.cuda.current_stream()
-        for st, wl in zip(streams, ws):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                wl.step()
-        for st in streams:
-            cur.wait_stream(st)
+        def step_all():
+            bw.step()
+    else:
+        b.mode = "graph-static"
+        ws = [Workload(b, dev, 100 + i) for i in range(n_seqs)]
+        streams = [torch.cuda.Stream() for _ in ws]
+
+        def step_all():
+            cur = torch.cuda.current_stream()
+            for st, wl in zip(streams, ws):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    wl.step()
+            for st in streams:
+                cur.wait_stream(st)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -218,24 +308,34 @@ def multi_seq_side_measurement(a, dev, bpl, dense_us, n_seqs=8, layers=8):
         step_all()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    if mode == "batched":
+        bw.sync()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         step_all()
-    for _ in range(b.warmup):
+
+    def replay():
         g.replay()
+        if mode == "batched":
+            bw.after_replay()
+
+    for _ in range(b.warmup):
+        replay()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(b.steps):
-        g.replay()
+        replay()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     us = el * 1e6 / b.steps / layers / n_seqs
-    res = {"sequences": n_seqs, "layers_per_sequence": layers, "us_per_sequence_layer": us,
+    res = {"sequences": n_seqs, "layers_per_sequence": layers, "mode": mode, "us_per_sequence_layer": us,
            "chain_frac_of_hbm_peak": bpl["chain"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
            # a step of the full model yields n_seqs tokens in us * model_layers * n_seqs microseconds
            "tokens_per_s_scaled_to_model_layers": 1.0 / (us * 1e-6 * a.layers)}
     if dense_us is not None:
         res["speedup_vs_dense"] = dense_us / us
+    if mode == "batched":
+        res.update(batched_op_times(bw, bpl))
     del ws, g
     torch.cuda.empty_cache()
     return res
@@ -294,7 +394,13 @@ def main():
 
     from quest_amd.parallel import gather_tokens
 
-    ws = [Workload(a, dev, i) for i in range(a.seqs_per_gpu)]
+    batched = (a.seqs_per_gpu > 1 and a.multi_seq_mode == "batched" and a.mode == "graph" and a.skip_layers == 0
+               and not a.unfused)
+    n_local = a.seqs_per_gpu
+    if batched:
+        ws = [BatchedWorkload(a, dev, n_local)]
+    else:
+        ws = [Workload(a, dev, i) for i in range(n_local)]
     w = ws[0]
     streams = [torch.cuda.Stream() for _ in ws] if len(ws) > 1 else None
     torch.cuda.synchronize()
@@ -334,7 +440,7 @@ def main():
     else:
         run = step_all
 
-    tok = torch.zeros(len(ws), dtype=torch.int64, device=dev)  # stand-in for the sampled token ids of the local sequences
+    tok = torch.zeros(n_local, dtype=torch.int64, device=dev)  # stand-in for the sampled token ids of the local sequences
 
     def one_step():
         run()
@@ -361,11 +467,16 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed * 1e3 / a.steps
-    value = world * len(ws) * a.steps / elapsed  # one token per local sequence per step
+    value = world * n_local * a.steps / elapsed  # one token per local sequence per step
 
     out = None
     if rank == 0:
-        qu, ctl = w.qu, w.ctl
+        qu = w.qu
+        # per-op timings run on ONE sequence (the first of a batch) through the reference's op sequence
+        ctl = w.ctl.seqs[0] if batched else w.ctl
+        wq = [w.q[l][:1] for l in range(a.layers)] if batched else [w.q[l] for l in range(a.layers)]
+        wk = [w.k1[l][:1] for l in range(a.layers)] if batched else [w.k1[l] for l in range(a.layers)]
+        wv = [w.v1[l][:1] for l in range(a.layers)] if batched else [w.v1[l] for l in range(a.layers)]
         bpl = bytes_per_layer(a)
         # ---- per-operator launch time with HIP events on the launch stream (steady state of this very step)
         if w.dyn:
@@ -373,22 +484,22 @@ def main():
         ctl.set_page_budget(w.page_budget)
         ctl.begin_forward(1)
         ppc, chunks = ctl._decode_handler.plan_info()
-        est0 = [qu.decode_estimate(w.q[l], ctl, l) for l in range(a.layers)]
+        est0 = [qu.decode_estimate(wq[l], ctl, l) for l in range(a.layers)]
         for l in range(a.layers):
             qu.decode_topk(est0[l], ctl)
         idx = ctl.topk_dindices_buffer
         reps = 10
-        t_att = time_kernel_loop(lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, idx), a.layers, reps)
-        t_est = time_kernel_loop(lambda l: qu.decode_estimate(w.q[l], ctl, l), a.layers, reps)
+        t_att = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, idx), a.layers, reps)
+        t_est = time_kernel_loop(lambda l: qu.decode_estimate(wq[l], ctl, l), a.layers, reps)
         t_topk = time_kernel_loop(lambda l: qu.decode_topk(est0[l], ctl), a.layers, reps)
-        t_app = time_kernel_loop(lambda l: qu.append_kv(w.k1[l], w.v1[l], ctl, l), a.layers, reps)
-        t_ae = time_kernel_loop(lambda l: qu.decode_append_estimate(w.q[l], w.k1[l], w.v1[l], ctl, l), a.layers, reps)
-        t_ts = time_kernel_loop(lambda l: qu.decode_topk_sparse_attn(w.q[l], est0[l], ctl, l, write_topk=False),
+        t_app = time_kernel_loop(lambda l: qu.append_kv(wk[l], wv[l], ctl, l), a.layers, reps)
+        t_ae = time_kernel_loop(lambda l: qu.decode_append_estimate(wq[l], wk[l], wv[l], ctl, l), a.layers, reps)
+        t_ts = time_kernel_loop(lambda l: qu.decode_topk_sparse_attn(wq[l], est0[l], ctl, l, write_topk=False),
                                 a.layers, reps)
         ctl.end_forward()
         ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_plus_merge_us": t_att,
                "fused_append_estimate_us": t_ae, "fused_topk_sparse_attn_plus_merge_us": t_ts,
-               "chain_us_in_step": ms_per_step * 1e3 / a.layers / len(ws),
+               "chain_us_in_step": ms_per_step * 1e3 / a.layers / n_local,
                "note": "per launch inside a hipGraph of 32 back-to-back launches (one per layer), "
                        "dependent-launch boundary included"}
         dense_us = None
@@ -396,7 +507,7 @@ def main():
             ctl.set_page_budget(1 << 20)
             ctl.begin_forward(1, updateTensor=False)
             dense_us = time_kernel_loop(
-                lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, ctl.kv_indices_without_last), a.layers, 3)
+                lambda l: qu.decode_sparse_attn(wq[l], ctl, l, ctl.kv_indices_without_last), a.layers, 3)
             ctl.end_forward()
         achieved = bpl["attn"] / (t_att * 1e-6) / 1e9
         traffic = None
@@ -414,28 +525,32 @@ def main():
             "config": {"workload": "BASELINE configs[2]: Yarn-Llama-2-7B-128K shapes, 1 sequence per GPU, "
                                    "self-attention chain (append+estimate+top-k+sparse attn) x all layers per token",
                        "layers": a.layers, "num_qo_heads": a.heads, "num_kv_heads": a.kv_heads,
-                       "head_dim": a.head_dim, "seqlen": a.seqlen, "seqlen_after_run": w.ctl.kv_cache.seqlen, "page_size": a.page_size,
+                       "head_dim": a.head_dim, "seqlen": a.seqlen, "seqlen_after_run": ctl.kv_cache.seqlen, "page_size": a.page_size,
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
                        "kv_layout": a.layout, "mode": a.mode, "skip_layers": a.skip_layers,
                        "launches_per_layer": "5 (reference op sequence)" if a.unfused else
                        "3 (append+estimate | top-k+sparse attn | merge)",
-                       "sequences_per_gpu": len(ws), "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
+                       "sequences_per_gpu": n_local,
+                       "multi_sequence": ("batched launches, shared pool" if batched else "one stream per sequence")
+                       if n_local > 1 else None, "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
             "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel + merge_states_kernel (one decode_sparse_attn op)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att,
                          "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}},
             "ops_us": ops,
-            "selfattn_us_per_layer": ms_per_step * 1e3 / a.layers / len(ws),
+            "selfattn_us_per_layer": ms_per_step * 1e3 / a.layers / n_local,
             "chain_bytes_per_layer": bpl["chain"],
-            "chain_frac_of_hbm_peak": bpl["chain"] * len(ws) / (ms_per_step * 1e-3 / a.layers) / 1e9 / HBM_PEAK_GBS,
+            "chain_frac_of_hbm_peak": bpl["chain"] * n_local / (ms_per_step * 1e-3 / a.layers) / 1e9 / HBM_PEAK_GBS,
         }
         if dense_us is not None:
             out["dense_full_kv_us"] = dense_us
             out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
-            out["speedup_vs_dense"] = dense_us / (ms_per_step * 1e3 / a.layers / len(ws))
-        if world == 1 and len(ws) == 1 and not a.no_multi_seq:
-            out["eight_sequences_per_gpu"] = multi_seq_side_measurement(a, dev, bpl, dense_us)
+            out["speedup_vs_dense"] = dense_us / (ms_per_step * 1e3 / a.layers / n_local)
+        if batched:
+            out["batched_ops"] = batched_op_times(w, bpl)
+        if world == 1 and n_local == 1 and not a.no_multi_seq:
+            out["eight_sequences_per_gpu"] = multi_seq_side_measurement(a, dev, bpl, dense_us, mode=a.multi_seq_mode)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, a.cpu_sample_s)
         else:

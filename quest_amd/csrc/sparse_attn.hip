@@ -84,7 +84,7 @@ __device__ __forceinline__ SeqView select_sequence(const DecodeParams& p, uint32
     return v;
 }
 
-constexpr int kFusedMaxPpc = 64;  // pages per workgroup the fused front end can stage in LDS
+constexpr int kFusedMaxPpc = 128;  // pages per workgroup the fused front end can stage in LDS
 
 template <int D>
 struct RowState {
@@ -614,19 +614,29 @@ struct quest_decode_handler {
     uint32_t dec_waves = 4;
     uint32_t shared_ppc = 0, shared_chunks = 0;  // plan of the group-shared kernel (grid.y = kv heads)
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
+    uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
 };
 
-// Workgroups the planner aims for: the kernel is built for 2 workgroups (8 waves) per CU, so 512
-// workgroups are one fully resident round on 256 CUs, each wave with 16 x 1 KiB loads in flight.
-static constexpr uint32_t kTargetWorkgroups = 512;
+// Workgroups the planner aims for.  One sequence: the kernel is built for 2 workgroups (8 waves) per CU,
+// so 2 x CUs workgroups (512) are one fully resident round, each wave with 16 x 1 KiB loads in flight.
+// A batch: ONE workgroup per CU (256) -- measured at cfg-3 shapes for 2/4/8/16 sequences:
+// every extra workgroup of a head repeats the fused selection and adds a partial record to merge, and
+// with 8 x 32 (sequence, head) pairs the split disappears altogether (one workgroup per head, no merge
+// launch).
+static uint32_t target_workgroups(const quest_decode_handler* h) { return h->batch > 1 ? h->num_cus : 2 * h->num_cus; }
 static constexpr uint32_t kMaxChunks = 1024;  // merge kernel's LDS weight table
-static constexpr uint32_t kBatchRounds = 2;   // batched launches: resident rounds of workgroups aimed for
 
 extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout) {
     if (!out || layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
     quest_decode_handler* h = new (std::nothrow) quest_decode_handler();
     if (!h) return (int)hipErrorOutOfMemory;
     h->layout = layout;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        h->num_cus = (uint32_t)cus;
+    else
+        (void)hipGetLastError();  // no device (CPU-only import): keep the MI355X default
     if (const char* e = getenv("QUEST_DEC_WAVES")) h->dec_waves = atoi(e) == 8 ? 8 : 4;  // tuning knob
     *out = h;
     return 0;
@@ -667,9 +677,9 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     if (h->forced_ppc) {
         ppc = h->forced_ppc;
     } else {
-        // a batch brings its own parallelism: the same number of workgroups is spread over the sequences
-        // (fewer, longer chunks per head -> fewer partials and fewer repeats of the fused selection)
-        uint32_t chunks = kTargetWorkgroups * (h->batch > 1 ? kBatchRounds : 1u) / (num_qo_heads * h->batch);
+        // a batch brings its own parallelism: the workgroups are spread over the sequences (fewer, longer
+        // chunks per head -> fewer partials and fewer repeats of the fused selection)
+        uint32_t chunks = target_workgroups(h) / (num_qo_heads * h->batch);
         if (chunks < 1) chunks = 1;
         if (chunks > n_slots) chunks = n_slots;
         ppc = (n_slots + chunks - 1) / chunks;
@@ -679,7 +689,7 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     h->pages_per_chunk = ppc;
     h->n_chunks = (n_slots + ppc - 1) / ppc;
     {   // the group-shared kernel runs one workgroup per (chunk, KV head): plan it for the same 512 workgroups
-        uint32_t chunks = kTargetWorkgroups * (h->batch > 1 ? kBatchRounds : 1u) / (num_kv_heads * h->batch);
+        uint32_t chunks = 2 * h->num_cus / (num_kv_heads * h->batch);
         if (chunks < 1) chunks = 1;
         if (chunks > n_slots) chunks = n_slots;
         if (chunks > kMaxChunks) chunks = kMaxChunks;

@@ -137,3 +137,21 @@ class QuestAttention(nn.Module):
                                            self.rope_theta, apply_rope=True)
         return self.o_proj(attn.reshape(1, 1, self.hidden_size))
 
+
+    def forward_batched(self, hidden_states: torch.Tensor, bController: "qutils.BatchedInferenceController",
+                        scores: torch.Tensor, dense: bool) -> torch.Tensor:
+        """``forward_dyn`` for ``n`` sequences at once: ``hidden_states`` is ``[n, 1, hidden]`` (one decode token
+        per sequence), all sequences share the controller's pools and every op is ONE launch for the batch
+        (``quest_amd.utils.decode_layer_batched``).  EXTENSION: the reference module asserts batch size 1."""
+        n, q_len, _ = hidden_states.size()
+        assert q_len == 1 and n == bController.n_seqs
+        q = self.q_proj(hidden_states).view(n, self.num_heads, self.head_dim)
+        k = self.k_proj(hidden_states).view(n, self.num_key_value_heads, self.head_dim)
+        v = self.v_proj(hidden_states).view(n, self.num_key_value_heads, self.head_dim)
+        if dense:
+            attn = qutils.decode_layer_dense_batched(q, k, v, bController, self.layer_idx, self.rope_scale,
+                                                     self.rope_theta, apply_rope=True)
+        else:
+            attn = qutils.decode_layer_batched(q, k, v, bController, self.layer_idx, scores, self.rope_scale,
+                                               self.rope_theta, apply_rope=True)
+        return self.o_proj(attn.reshape(n, 1, self.hidden_size))

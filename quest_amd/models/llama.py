@@ -79,6 +79,12 @@ class LlamaDecoderLayer(nn.Module):
         return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
 
 
+    def forward_batched(self, hidden_states: torch.Tensor, bController, scores, dense: bool) -> torch.Tensor:
+        h = self.self_attn.forward_batched(self.input_layernorm(hidden_states), bController, scores, dense)
+        hidden_states = hidden_states + h
+        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+
+
 class LlamaModel(nn.Module):
     def __init__(self, config: LlamaConfig, fused: bool = True):
         super().__init__()
@@ -116,6 +122,15 @@ class LlamaModel(nn.Module):
         qutils.step_advance_dyn(ctl)
         for idx, layer in enumerate(self.layers):
             h = layer.forward_dyn(h, ctl, scores, dense=idx < self._quest_skip_layer)
+        return self.norm(h)
+
+
+    def forward_decode_batched(self, h: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
+        """One decode token of every sequence of ``self.bController`` (``h``: ``[n, 1, hidden]``)."""
+        b = self.bController
+        qutils.step_advance_batched(b)
+        for idx, layer in enumerate(self.layers):
+            h = layer.forward_batched(h, b, scores, dense=idx < self._quest_skip_layer)
         return self.norm(h)
 
 
@@ -193,3 +208,65 @@ class LlamaForCausalLM(nn.Module):
         self.model.iController.prepare_metadata(1)  # host mirror of the device-side reservation
         return self.graph_logits
 
+
+    # ------------------------------------------------------------------ batched serving (EXTENSION)
+    def quest_init_batched(self, n_seqs: int, page_size: int, max_seq_len: int, token_budget: int = 512,
+                           dtype=torch.float16, device=torch.device("cuda:0")) -> None:
+        """``quest_init`` for ``n_seqs`` sequences decoded together: one shared KV pool and metadata pool
+        (``BatchedInferenceController``).  Prompts are processed one sequence at a time with
+        ``prefill_sequence``; decode steps then run all sequences in one hipGraph replay."""
+        assert self.model.iController is None and getattr(self.model, "bController", None) is None
+        cfg = self.config
+        self.model._quest_page_budget = token_budget // page_size
+        self.model.bController = qutils.BatchedInferenceController(
+            n_seqs, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads,
+            page_size, self.model._quest_page_budget, max_seq_len, dtype, device,
+            num_kv_heads=cfg.num_key_value_heads)
+
+    def prefill_sequence(self, seq: int, input_ids: torch.Tensor) -> torch.Tensor:
+        """Run the prompt of sequence ``seq`` (``[1, L]``) through the ordinary single-sequence path over the
+        shared pools; returns the logits of its last position."""
+        m = self.model
+        m.iController = m.bController.seqs[seq]
+        try:
+            return self.forward(input_ids=input_ids)
+        finally:
+            m.iController = None
+
+    def capture_decode_graph_batched(self) -> None:
+        """Batched ``capture_decode_graph``: input ``self.graph_input`` ``[n, 1, hidden]``, logits
+        ``self.graph_logits`` ``[n, 1, vocab]``."""
+        m, b = self.model, self.model.bController
+        dev = next(self.parameters()).device
+        b.enable_device_state()
+        b.begin_graph_decode(dense_layers=m._quest_skip_layer > 0)
+        n = b.n_seqs
+        self.graph_input = torch.zeros(n, 1, self.config.hidden_size, dtype=self.lm_head.weight.dtype, device=dev)
+        self._graph_scores = torch.empty(n, self.config.num_attention_heads, b.max_pages, dtype=torch.float16,
+                                         device=dev)
+
+        def step():
+            return self.lm_head(m.forward_decode_batched(self.graph_input, self._graph_scores))
+
+        # warm-up folds a dummy key into every sequence's current metadata entry: snapshot / restore those
+        # pages (see capture_decode_graph)
+        pages = torch.tensor([c.metadata_cache.indicies[-1] for c in b.seqs], device=dev)
+        saved = b.metadata_pool.buf[:, pages].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.inference_mode():
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        b.metadata_pool.buf[:, pages] = saved
+        b.sync_device_state()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.inference_mode(), torch.cuda.graph(self._graph):
+            self.graph_logits = step()
+
+    def decode_graph_step_batched(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """One token for every sequence: ``input_ids`` ``[n]`` -> logits ``[n, 1, vocab]`` (the graph's buffer)."""
+        self.graph_input.copy_(self.model.embed_tokens(input_ids.view(-1, 1)))
+        self._graph.replay()
+        self.model.bController.prepare_metadata(1)
+        return self.graph_logits

@@ -220,3 +220,61 @@ def test_batched_argument_errors():
                                          b.meta_tables, b.step_states, b.max_pages - 1, 0)
     with pytest.raises(ValueError):
         b._decode_handler.set_batch(0)
+
+
+def test_model_batched_generation_matches_single_sequence():
+    """A Llama-architecture model (2 dense layers + sparse layers, GQA) decoding three prompts of different
+    lengths together -- one hipGraph replay per token for the whole batch -- against the same model decoding
+    each prompt alone (teacher-forced with the single-sequence greedy tokens)."""
+    from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
+
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
+                      num_attention_heads=4, num_key_value_heads=2)
+    lens = (300, 215, 330)
+    prompts = [((torch.arange(L, device=dev)[None] * (5 + 2 * i)) + i) % 256 for i, L in enumerate(lens)]
+    n_new = 24
+
+    def build():
+        torch.manual_seed(11)
+        with torch.device(dev):
+            m = LlamaForCausalLM(cfg).half()
+        for p_ in m.parameters():
+            p_.data.normal_(0, 0.05)
+        return m
+
+    # each prompt alone: graph-replayed single-sequence generation
+    toks, logits = [], []
+    for pr in prompts:
+        m = build()
+        m.quest_init(16, 512, token_budget=96)
+        with torch.inference_mode():
+            first = m(input_ids=pr)
+        m.capture_decode_graph()
+        tk, lg = [int(first.argmax(-1))], [first.float().clone()]
+        with torch.inference_mode():
+            for _ in range(n_new):
+                out = m.decode_graph_step(input_ids=torch.tensor([[tk[-1]]], device=dev))
+                lg.append(out.float().clone())
+                tk.append(int(out.argmax(-1)))
+        toks.append(tk)
+        logits.append(lg)
+        del m
+
+    mb = build()
+    mb.quest_init_batched(len(prompts), 16, 512, token_budget=96)
+    with torch.inference_mode():
+        for i, pr in enumerate(prompts):
+            first = mb.prefill_sequence(i, pr)
+            assert torch.equal(first.float(), logits[i][0]), "prefill over the shared pool differs"
+    mb.capture_decode_graph_batched()
+    with torch.inference_mode():
+        for t in range(n_new):
+            ids = torch.tensor([toks[i][t] for i in range(len(prompts))], device=dev)
+            out = mb.decode_graph_step_batched(ids).float()
+            for i in range(len(prompts)):
+                # GEMMs run with M = 3 instead of M = 1 (different rocBLAS kernels / summation order), so the
+                # comparison is a tolerance, not bits; logits are O(1)
+                torch.testing.assert_close(out[i], logits[i][t + 1][0], rtol=3e-2, atol=3e-2)
+    for i, c in enumerate(mb.model.bController.seqs):
+        assert c.kv_cache.seqlen == lens[i] + n_new
