@@ -265,7 +265,17 @@ def batched_op_times(bw, bpl):
     t_ae = time_kernel_loop(ae, bw.a.layers, 10)
     t_ts = time_kernel_loop(ts, bw.a.layers, 10)
     ppc, chunks = b._decode_handler.plan_info()
+    # full-KV decode of the same batch in one launch (group-shared kernel over every page of every sequence)
+    b.begin_graph_decode(dense_layers=True)
+
+    def dense(l):
+        b._dense_handler.forward_shared_batched(bw.q[l], bw.o[l], b.kv_layer(l), b.kv_tables, b.step_states)
+
+    t_dense = time_kernel_loop(dense, bw.a.layers, 3)
     return {"batched_append_estimate_us": t_ae, "batched_topk_sparse_attn_us": t_ts,
+            "batched_dense_full_kv_us": t_dense, "batched_dense_full_kv_us_per_sequence": t_dense / n,
+            "batched_dense_gbs": n * bpl["dense"] / (t_dense * 1e-6) / 1e9,
+            "speedup_vs_batched_dense": t_dense / (t_ae + t_ts),
             "batched_append_estimate_gbs": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9,
             "batched_topk_sparse_attn_gbs": n * (bpl["topk"] + bpl["attn"]) / (t_ts * 1e-6) / 1e9,
             "batched_sparse_attn_frac_of_hbm_peak": n * bpl["attn"] / (t_ts * 1e-6) / 1e9 / HBM_PEAK_GBS,

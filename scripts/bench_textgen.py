@@ -42,6 +42,56 @@ def time_decode(model, ctl, emb, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def time_batched(cfg, a, dense, dev):
+    """`--seqs` > 1: all sequences decode together, one hipGraph replay per token for the batch
+    (LlamaForCausalLM.capture_decode_graph_batched).  dense = every layer full-KV (group-shared kernel)."""
+    from quest_amd.models.llama import LlamaForCausalLM
+    import quest_amd.utils as qu
+
+    with torch.device(dev):
+        model = LlamaForCausalLM(cfg).half()
+    for p in model.parameters():
+        p.data.normal_(0, 0.02)
+    for m in model.modules():
+        if hasattr(m, "variance_epsilon"):
+            m.weight.data.fill_(1.0)
+    model.quest_init_batched(a.seqs, 16, a.ctx + 256, a.token_budget)
+    if dense:
+        model.model._quest_skip_layer = a.layers
+    b = model.model.bController
+    g = torch.Generator(device=dev).manual_seed(1)
+    D = a.hidden // a.heads
+    k = torch.empty(a.ctx, a.kv_heads, D, dtype=torch.float16, device=dev)
+    v = torch.empty_like(k)
+    for c in b.seqs:
+        c.prepare_metadata(a.ctx)
+        c.begin_forward(a.ctx)
+        for l in range(a.layers):
+            k.normal_(generator=g)
+            v.normal_(generator=g)
+            qu.append_kv(k, v, c, l)
+        c.end_forward()
+    del k, v
+    model.capture_decode_graph_batched()
+    model.graph_input.copy_(torch.randn(a.seqs, 1, a.hidden, generator=g, device=dev, dtype=torch.float16) * 0.1)
+    for _ in range(3):
+        model._graph.replay()
+        b.prepare_metadata(1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        model._graph.replay()
+        b.prepare_metadata(1)
+    e1.record()
+    torch.cuda.synchronize()
+    assert torch.isfinite(model.graph_logits.float()).all()
+    ms = e0.elapsed_time(e1) / a.reps
+    del model, b
+    torch.cuda.empty_cache()
+    return ms
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ctx", type=int, default=32768)
@@ -53,6 +103,7 @@ def main():
     ap.add_argument("--inter", type=int, default=11008)
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--seqs", type=int, default=1, help="sequences decoded together (batched launches)")
     a = ap.parse_args()
     from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
     import quest_amd.utils as qu
@@ -61,6 +112,15 @@ def main():
     torch.manual_seed(0)
     cfg = LlamaConfig(vocab_size=a.vocab, hidden_size=a.hidden, intermediate_size=a.inter, num_hidden_layers=a.layers,
                       num_attention_heads=a.heads, num_key_value_heads=a.kv_heads, max_position_embeddings=a.ctx + 1024)
+    if a.seqs > 1:
+        q_ms = time_batched(cfg, a, False, dev)
+        d_ms = time_batched(cfg, a, True, dev)
+        print(json.dumps({"bench": "e2e batched decode, random-weight Llama", "sequences": a.seqs, "ctx": a.ctx,
+                          "token_budget": a.token_budget, "layers": a.layers, "hidden": a.hidden, "heads": a.heads,
+                          "kv_heads": a.kv_heads, "dense_first_layers": 2, "ms_per_step_quest": q_ms,
+                          "ms_per_step_full_kv": d_ms, "tokens_per_s_quest": a.seqs / (q_ms * 1e-3),
+                          "tokens_per_s_full_kv": a.seqs / (d_ms * 1e-3), "speedup": d_ms / q_ms}))
+        return
     results = {}
     for name, budget in (("quest", a.token_budget), ("dense", 1 << 24)):
         with torch.device(dev):
