@@ -104,6 +104,48 @@ def test_kv_cache_bookkeeping():
     assert shuf.device_table().tolist() == shuf.indicies
 
 
+def test_shared_pool_reservation_and_batched_controller_host_logic():
+    """Sequences sharing one pool reserve disjoint page sets whose use order is known in advance (what the
+    batched device-resident page tables rely on); release keeps the reservation and the order."""
+    from quest_amd.utils import BatchedInferenceController, KvCache
+    from quest_amd.utils.kv_cache import KvPool
+
+    pool = KvPool(1, 2, 64, 12, 16, torch.float16, "cpu", shuffle_seed=5)
+    a = KvCache(1, 2, 64, 64, 16, torch.float16, "cpu", pool=pool)   # 4 pages
+    b = KvCache(1, 2, 64, 100, 16, torch.float16, "cpu", pool=pool)  # 7 pages
+    assert pool.num_free_blocks == 1 and a.capacity_pages == 4 and b.capacity_pages == 7
+    plan_a, plan_b = a.full_device_table().tolist(), b.full_device_table().tolist()
+    assert len(plan_a) == 4 and len(plan_b) == 7 and not set(plan_a) & set(plan_b)
+    b.append_seq(20)
+    a.append_seq(40)
+    b.append_seq(60)
+    assert a.indicies == plan_a[:3] and b.indicies == plan_b[:5]
+    assert a.full_device_table().tolist() == plan_a and b.full_device_table().tolist() == plan_b
+    with pytest.raises(RuntimeError, match="KvPool exhausted"):
+        a.append_seq(64)  # would need a 5th page: the free block of the pool is not this sequence's
+    a.release()
+    assert a.seqlen == 0 and pool.num_free_blocks == 1 and a.full_device_table().tolist() == plan_a
+    a.append_seq(64)
+    assert a.indicies == plan_a
+
+    bc = BatchedInferenceController(3, 2, 4, 128, 16, 5, 200, torch.float16, "cpu", num_kv_heads=2, shuffle_seed=1)
+    assert bc.kv_pool.capacity == 3 * 13 and bc.metadata_pool.capacity == 3 * 1
+    assert bc.kv_layer(1).shape == (39, 2, 16, 2, 128)
+    for i, c in enumerate(bc.seqs):
+        c.prepare_metadata(100 + 16 * i)
+    bc.enable_device_state()
+    assert bc.kv_tables.shape == (3, 13) and bc.meta_tables.shape == (3, 1) and bc.max_pages == 13
+    rows = bc.kv_tables.tolist()
+    assert len({p for r in rows for p in r}) == 39  # disjoint reservations cover the pool
+    st = bc.step_states.tolist()
+    assert [s[0] for s in st] == [100, 116, 132] and [s[1] for s in st] == [7, 8, 9]
+    assert [s[2] for s in st] == [4, 4, 4] and [s[3] for s in st] == [bc.seqs[i].kv_cache.indicies[-1] for i in range(3)]
+    bc.prepare_metadata(1)
+    assert [c.kv_cache.seqlen for c in bc.seqs] == [101, 117, 133]
+    with pytest.raises(ValueError):
+        BatchedInferenceController(0, 1, 4, 128, 16, 5, 200, torch.float16, "cpu")
+
+
 def test_controller_budget_logic(monkeypatch):
     """need_estimate / inference_page_budget / index tensors (controller.py:80-142), with the handler stubbed
     (it needs the GPU only for its workspace)."""
