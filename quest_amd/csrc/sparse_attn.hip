@@ -24,6 +24,18 @@
 
 #include "topk_select.cuh"
 
+// Developer aid (scripts/timeline.py): -DQUEST_TIMELINE makes one workgroup of sparse_decode_kernel write
+// clock stamps of its phases into the `lse` buffer instead of the log-sum-exp.
+#ifdef QUEST_TIMELINE
+#define QUEST_LSE_ENABLED false
+#define QUEST_STAMP(i) \
+    do { __builtin_amdgcn_s_waitcnt(0); tl[i] = clock64(); } while (0)
+#else
+#define QUEST_LSE_ENABLED true
+#define QUEST_STAMP(i) \
+    do { } while (0)
+#endif
+
 namespace quest {
 
 constexpr float kNegFloor = -1.0e30f;  // finite "-inf": exp2(floor - floor) stays finite, weights it carries are 0
@@ -56,6 +68,8 @@ struct DecodeParams {
     uint32_t ids_lds_offset;
     const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
     uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
+    uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
+    uint32_t direct;  // fused front end: scores / page ids are fetched in ownership layout with 8/16-byte loads
 };
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
@@ -145,6 +159,12 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hq = blockIdx.y, hk = hq / p.group;
+#ifdef QUEST_TIMELINE
+    long long tl[10] = {};
+    long long sub_out[9] = {};
+    const long long wall0 = wall_clock64();
+    QUEST_STAMP(0);
+#endif
     const SeqView sv = select_sequence(p, gridDim.y, D);
     // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
     // row length comes from the state
@@ -169,48 +189,100 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
-        if (p.state) {  // live lengths (the column ownership below depends on the live row length)
+        const uint32_t n_cap0 = p.n_scores;  // as launched: the longest row this launch may see
+        if (p.state) {  // live lengths
             const quest_step_state_t st = *sv.state;
             p.n_scores = (uint32_t)(st.n_pages - 1);
             p.last_page_len = (uint32_t)st.kv_last_page_len;
             p.last_page_idx = st.kv_last_page_idx;
         }
-        const uint32_t n = p.n_scores;
+        const uint32_t n = p.n_scores, n_cap = n_cap0;
         constexpr int NT = NW * kWave;
-        const uint32_t cpt = topk_cols_per_thread<NT>(n);  // <= FC (FC is sized for n_cap >= n)
+        // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n), so no address
+        // below depends on the live length -- in a state-driven launch the score loads do not wait for the
+        // state load.
+        const uint32_t cpt = p.cpt;
         const uint32_t c0 = threadIdx.x * cpt;
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
         const int32_t* table = sv.indices;
-        // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         uint16_t* keys_s = reinterpret_cast<uint16_t*>(fe_dyn);
         const bool stage_ids = p.stage_ids != 0;
         int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
-        uint16_t kraw[FC];
-        int32_t iraw[FC];
-#pragma unroll
-        for (int i = 0; i < FC; ++i) {
-            const uint32_t e = threadIdx.x + i * NT, ec = e < n ? e : n - 1;  // clamped, unconditional
-            kraw[i] = srow[ec];
-            iraw[i] = stage_ids ? table[ec] : 0;
-        }
-        topk_clear<NT>(sm);  // overlaps the score / page-id loads above
-#pragma unroll
-        for (int i = 0; i < FC; ++i) {
-            const uint32_t e = threadIdx.x + i * NT;
-            if (e < n) {
-                keys_s[e] = (uint16_t)half_key(kraw[i]);
-                if (stage_ids) ids_s[e] = iraw[i];
+        uint32_t key[FC];
+        int32_t idr[8] = {};  // direct path: page ids of the owned columns
+        const bool direct = p.direct != 0;  // block-uniform
+        if (direct) {
+            // scores and page ids straight into ownership layout: lane t reads the 8/16 (+16/32) bytes of its
+            // cpt columns, a wave reads 0.5-1 KiB contiguous -- no LDS transpose.  Chunks past the capacity
+            // re-read the last chunk (their columns are masked by c0 + i < n everywhere).
+            const uint32_t last = ((n_cap - 1) / cpt) * cpt, cb = c0 < last ? c0 : last;
+            uint32_t w[4] = {};
+            if (cpt == 8) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(srow + cb);
+                const int4 a = *reinterpret_cast<const int4*>(table + cb), b = *reinterpret_cast<const int4*>(table + cb + 4);
+                w[0] = k4.x, w[1] = k4.y, w[2] = k4.z, w[3] = k4.w;
+                idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w, idr[4] = b.x, idr[5] = b.y, idr[6] = b.z, idr[7] = b.w;
+            } else {  // cpt == 4
+                const uint2 k2 = *reinterpret_cast<const uint2*>(srow + cb);
+                const int4 a = *reinterpret_cast<const int4*>(table + cb);
+                w[0] = k2.x, w[1] = k2.y;
+                idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w;
             }
+            topk_clear<NT>(sm);  // overlaps the loads above
+            QUEST_STAMP(1);
+            uint32_t mm = kMmNeutral;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                if (i < 8) {
+                    const uint32_t raw = (i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu;
+                    key[i] = half_key((uint16_t)raw);
+                    if ((uint32_t)i < cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
+                } else {
+                    key[i] = 0;
+                }
+            }
+            topk_publish_range<NT>(sm, mm);
+            QUEST_STAMP(2);
+        } else {
+            // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
+            uint16_t kraw[FC];
+            int32_t iraw[FC];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const uint32_t e = threadIdx.x + i * NT, ec = e < n ? e : n - 1;  // clamped, unconditional
+                kraw[i] = srow[ec];
+                iraw[i] = stage_ids ? table[ec] : 0;
+            }
+            topk_clear<NT>(sm);  // overlaps the score / page-id loads above
+            QUEST_STAMP(1);
+            uint32_t mm = kMmNeutral;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const uint32_t e = threadIdx.x + i * NT;
+                if (e < n) {
+                    const uint32_t kk = half_key(kraw[i]);
+                    mm = pk_max_u16(mm, mm_pack(kk));
+                    keys_s[e] = (uint16_t)kk;
+                    if (stage_ids) ids_s[e] = iraw[i];
+                }
+            }
+            topk_publish_range<NT>(sm, mm);
+            QUEST_STAMP(2);
         }
         __syncthreads();
-        uint32_t key[FC];
-#pragma unroll
-        for (int i = 0; i < FC; ++i) {
-            const uint32_t c = c0 + i;
-            key[i] = keys_s[c < n ? c : n - 1];
-        }
+        QUEST_STAMP(3);
+        if (!direct) topk_load_keys<FC>(keys_s, c0, n, cpt, key);
+#ifdef QUEST_TIMELINE
+        long long sub[9] = {};
+        TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, sub);
+#else
         TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt);
+#endif
+#ifdef QUEST_TIMELINE
+        for (int i = 0; i < 9; ++i) sub_out[i] = sub[i];
+#endif
+        QUEST_STAMP(4);
         uint32_t my_slot[FC];
         bool mine[FC];
 #pragma unroll
@@ -222,7 +294,9 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                 // two separate loads: a select between an LDS and a global ADDRESS becomes one flat load
                 // whose address-space cast this compiler miscompiles (illegal v_cmp on src_shared_base)
                 int32_t pg;
-                if (stage_ids) {
+                if (direct) {
+                    pg = idr[i & 7];
+                } else if (stage_ids) {
                     pg = ids_s[c0 + i];
                 } else {
                     pg = table[c0 + i];
@@ -232,6 +306,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             }
         }
         __syncthreads();
+        QUEST_STAMP(5);
         // optional copy of the selection for callers that inspect it: issued after the barrier so no
         // workgroup waits on these stores before it starts fetching K/V
         if (p.sel_idx_out) {
@@ -315,6 +390,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         }
     }
 
+    QUEST_STAMP(6);
     // rows of the wave -> one state (xor butterfly across rows; both partners get the same bits)
 #pragma unroll
     for (int off = LPR; off < kWave; off <<= 1) {
@@ -338,7 +414,9 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             s_md[wave][1] = st.d;
         }
     }
+    QUEST_STAMP(7);
     __syncthreads();
+    QUEST_STAMP(8);
     const int f = threadIdx.x;
     if (f < D) {
         float M = s_md[0][0];
@@ -353,7 +431,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         }
         if (p.n_chunks == 1) {
             sv.o[(size_t)hq * D + f] = (half_t)(acc / den);
-            if (p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
+            if (QUEST_LSE_ENABLED && p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
         } else {
             float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
             w[f] = acc;
@@ -363,6 +441,15 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             }
         }
     }
+#ifdef QUEST_TIMELINE
+    QUEST_STAMP(9);
+    if (p.lse && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
+        if constexpr (FC > 0)
+            for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
+        p.lse[10] = (float)(wall_clock64() - wall0);  // 100 MHz ticks over the same span as tl[9] - tl[0]
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,7 +828,7 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     QUEST_LAUNCH_CHECK();
     if (h->n_chunks > 1) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
-                           (const float*)p.ws, p.o, p.lse, h->n_chunks, p.ws_stride);
+                           (const float*)p.ws, p.o, QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
     }
     return 0;
@@ -817,13 +904,27 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor
     int fc = 0;
     uint32_t waves = h->dec_waves;
+    p.cpt = 0;
+    p.direct = 0;
     if (fused) {
-        // keys per thread stay <= 8 up to 4096 pages by doubling the workgroup (the attention part runs
-        // the same with 4 or 8 waves; the selection's cost follows keys per thread)
-        if (kv.page_size == 16 && n_scores > 8u * 4u * kWave) waves = 8;
+        // the selection is VALU-issue bound (~1000 instructions per wave at 8 keys per thread), so rows
+        // beyond 1024 pages get 8 waves (<= 4 keys per thread up to 2048 pages, <= 8 up to 4096); the
+        // attention part runs the same with 4 or 8 waves.  Measured at cfg 3: 15.2 vs 15.8 us.
+        if (kv.page_size == 16 && n_scores > 4u * 4u * kWave) waves = 8;
         const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
         const uint32_t per_thread = (n_scores + nt - 1) / nt;
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
+        // ownership chunk: a multiple of 4 columns when the register capacity allows, so chunks are 8/16-byte
+        // aligned units of the score row and the page table
+        const uint32_t r4 = (per_thread + 3) / 4 * 4;
+        p.cpt = r4 <= (uint32_t)fc ? r4 : per_thread;
+        // direct (ownership-layout) loads need every chunk the launch can touch -- up to the capacity rounded
+        // to a chunk -- to be aligned, in-row and in-table, for every head and sequence
+        const uint32_t c = p.cpt, span = (n_scores + c - 1) / c * c;
+        const uint32_t table_len = batch.n_seqs > 1 ? batch.kv_table_stride : n_scores + 1;
+        const bool seq_ok = batch.n_seqs == 1 || (batch.kv_table_stride % c == 0);
+        p.direct = (c == 4 || c == 8) && (uintptr_t)scores % (c * 2) == 0 && p.score_stride % c == 0 &&
+                   span <= p.score_stride && (uintptr_t)kv.indices % (c * 4) == 0 && span <= table_len && seq_ok;
     }
     switch (kv.head_dim) {
         case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);

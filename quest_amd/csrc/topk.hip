@@ -53,21 +53,21 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
         iraw[i] = stage_ids ? ii[ec] : 0;
     }
     topk_clear<kTkThreads>(sm);  // overlaps the loads above
+    uint32_t mm = kMmNeutral;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         const uint32_t e = tid + i * kTkThreads;
         if (e < n) {
-            keys_s[e] = (uint16_t)half_key(kraw[i]);
+            const uint32_t kk = half_key(kraw[i]);
+            mm = pk_max_u16(mm, mm_pack(kk));
+            keys_s[e] = (uint16_t)kk;
             if (stage_ids) ids_s[e] = iraw[i];
         }
     }
+    topk_publish_range<kTkThreads>(sm, mm);
     __syncthreads();
     uint32_t key[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const uint32_t c = c0 + i;
-        key[i] = keys_s[c < n ? c : n - 1];
-    }
+    topk_load_keys<C>(keys_s, c0, n, cpt, key);
     TopkCursor cur = topk_select<kTkThreads, C>(sm, key, n, k, cpt);
     // Selected (value, id) pairs are compacted in LDS by output slot (k <= n), then written out by the
     // first k threads: coalesced stores instead of a divergent scatter of 2- and 4-byte writes.

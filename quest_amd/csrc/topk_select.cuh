@@ -8,9 +8,9 @@
 //
 // Thread t of NT owns the contiguous columns [t*cpt, t*cpt+cpt) with cpt = ceil(n / NT) <= C at run time
 // (C is only the compile-time capacity of the register arrays, so a kernel built for long rows does not
-// do long-row work on short ones).  Method: 11-bit histogram (2048 bins, LDS
-// atomics) + block suffix scan -> threshold bin; 5-bit histogram of that bin's members -> exact T;
-// packed block scan of per-thread (>T, ==T) counts -> output slots.
+// do long-row work on short ones).  Method: histogram of (key - row min) >> shift over <= 2048 bins (LDS
+// atomics) + block suffix scan -> threshold bin; histogram of that bin's members' low `shift` (<= 5) bits
+// -> exact T; packed block scan of per-thread (>T, ==T) counts -> output slots.
 #pragma once
 #include "quest_common.cuh"
 
@@ -22,11 +22,35 @@ constexpr int kBins2 = 1 << kLowBits;         // 32
 
 template <int NT>
 struct TopkSmem {
-    uint32_t hist1[kBins1];
+    alignas(16) uint32_t hist1[kBins1];
     uint32_t hist2[kBins2];
     uint32_t wave_tot[2][NT / kWave];  // one row per block scan, so a scan needs a single barrier
+    uint32_t wave_mm[NT / kWave];      // per wave: (max key << 16) | (0xffff - min key)
     uint32_t misc[4];                  // thr_bin, above, T, need_eq
 };
+
+// Packed (max, 0xffff - min) of 16-bit keys: one v_pk_max_u16 combines both halves.
+typedef uint16_t ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, a),
+                                                                   __builtin_bit_cast(ushort2_t, b)));
+}
+__device__ __forceinline__ uint32_t mm_pack(uint32_t key) { return (key << 16) | (0xffffu - key); }
+constexpr uint32_t kMmNeutral = 0u;  // max = 0, min = 0xffff
+
+// Publish the wave's key range (call with the packed range of the thread's VALID keys, in any ownership --
+// e.g. straight from the coalesced loads) before the barrier that precedes topk_select.
+template <int NT>
+__device__ __forceinline__ void topk_publish_range(TopkSmem<NT>& sm, uint32_t mm) {
+    int v = (int)mm;
+    v = (int)pk_max_u16((uint32_t)v, (uint32_t)dpp_i<kDppRowRor + 8>(v));
+    v = (int)pk_max_u16((uint32_t)v, (uint32_t)dpp_i<kDppRowRor + 4>(v));
+    v = (int)pk_max_u16((uint32_t)v, (uint32_t)dpp_i<kDppRowRor + 2>(v));
+    v = (int)pk_max_u16((uint32_t)v, (uint32_t)dpp_i<kDppRowRor + 1>(v));
+    v = (int)pk_max_u16((uint32_t)v, (uint32_t)__shfl_xor(v, 16, kWave));
+    v = (int)pk_max_u16((uint32_t)v, (uint32_t)__shfl_xor(v, 32, kWave));
+    if ((threadIdx.x & 63) == 0) sm.wave_mm[threadIdx.x >> 6] = (uint32_t)v;
+}
 
 // Inclusive block scan of one uint32 per thread; `wave_tot` must not be reused by a later scan of the
 // same kernel (each call site gets its own row), which is what lets it run with ONE barrier.
@@ -64,28 +88,100 @@ __device__ __forceinline__ uint32_t topk_cols_per_thread(uint32_t n) {
     return (n + NT - 1) / NT;
 }
 
-// Precondition: topk_clear() + __syncthreads() already done; key[i] holds column tid*cpt + i for i < cpt.
+// Fetch the thread's cpt contiguous keys from the LDS staging array (16-byte aligned, padded to a multiple of
+// 8 keys).  cpt of 2/4/8 -- the common cases -- is one 4/8/16-byte read per thread; 2-byte reads at a stride
+// of cpt keys between lanes are bank conflicts (4-way at cpt = 8).  Chunks that start past the row re-read
+// the row's last chunk; callers mask columns >= n themselves.
+template <int C>
+__device__ __forceinline__ void topk_load_keys(const uint16_t* keys_s, uint32_t c0, uint32_t n, uint32_t cpt,
+                                               uint32_t (&key)[C]) {
+    if (cpt == 8 && C >= 8) {
+        const uint32_t cb = c0 < n ? c0 : (n - 1) & ~7u;
+        const uint4 q4 = *reinterpret_cast<const uint4*>(keys_s + cb);
+        const uint32_t w[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int i = 0; i < C; ++i) key[i] = i < 8 ? ((i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu) : 0u;
+    } else if (cpt == 4 && C >= 4) {
+        const uint32_t cb = c0 < n ? c0 : (n - 1) & ~3u;
+        const uint2 q2 = *reinterpret_cast<const uint2*>(keys_s + cb);
+        const uint32_t w[2] = {q2.x, q2.y};
+#pragma unroll
+        for (int i = 0; i < C; ++i) key[i] = i < 4 ? ((i & 1) ? w[(i >> 1) & 1] >> 16 : w[(i >> 1) & 1] & 0xffffu) : 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const uint32_t c = c0 + i;
+            key[i] = keys_s[c < n ? c : n - 1];
+        }
+    }
+}
+
+// Precondition: topk_clear() + topk_publish_range() + __syncthreads() already done; key[i] holds column
+// tid*cpt + i for i < cpt.
+#ifdef QUEST_TIMELINE
+#define QUEST_SUBSTAMP(i) \
+    do { if (sub) { __builtin_amdgcn_s_waitcnt(0); sub[i] = clock64(); } } while (0)
+#else
+#define QUEST_SUBSTAMP(i) \
+    do { } while (0)
+#endif
+
 template <int NT, int C>
 __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k,
-                                                  uint32_t cpt) {
+                                                  uint32_t cpt, long long* sub = nullptr) {
     constexpr int BPT = kBins1 / NT;  // histogram bins per thread in the suffix scan
     static_assert(kBins1 % NT == 0 && NT >= kWave, "thread count must divide the bin count");
     const uint32_t tid = threadIdx.x;
     const uint32_t c0 = tid * cpt;
 
+    // Bins are taken over the row's own key range [kmin, kmax], not over the 16-bit key space: page scores
+    // of one head sit in one or two binades, where fixed top-11-bit bins put ~100 keys on each of ~20
+    // addresses and the LDS atomics serialise (measured 1.2 us of the 3 us selection); spread over up to
+    // 2048 bins of width 2^shift they do not collide, and the threshold bin holds a handful of keys.
+    uint32_t mm = kMmNeutral;
+#pragma unroll
+    for (int w = 0; w < NT / kWave; ++w) mm = pk_max_u16(mm, sm.wave_mm[w]);
+    const uint32_t kmax = mm >> 16, kmin = 0xffffu - (mm & 0xffffu);
+    const uint32_t range = kmax - kmin;  // < 65536
+    const uint32_t bits = 32u - (uint32_t)__builtin_clz(range | 1u);
+    const uint32_t shift = bits > 11u ? bits - 11u : 0u;  // <= kLowBits
+    const uint32_t low_mask = (1u << shift) - 1u;
 #pragma unroll
     for (int i = 0; i < C; ++i)
-        if ((uint32_t)i < cpt && c0 + i < n) atomicAdd(&sm.hist1[key[i] >> kLowBits], 1u);
+        if ((uint32_t)i < cpt && c0 + i < n) atomicAdd(&sm.hist1[(key[i] - kmin) >> shift], 1u);
+    QUEST_SUBSTAMP(0);
     __syncthreads();
+    QUEST_SUBSTAMP(1);
 
     {  // suffix scan from the top bin: thread t owns bins kBins1-1-BPT*t .. kBins1-BPT*(t+1), descending
+        // the thread's BPT bins are one contiguous, BPT*4-byte aligned block: fetch it with 8/16-byte LDS
+        // reads (word reads at a stride of BPT words are BPT-way bank conflicts: ~1 us at BPT = 8)
         uint32_t h[BPT], tot = 0;
+        {
+            const uint32_t* blk = &sm.hist1[kBins1 - BPT * (tid + 1)];  // ascending bins; h[] is descending
+            uint32_t asc[BPT];
+            if constexpr (BPT % 4 == 0) {
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            h[j] = sm.hist1[kBins1 - 1 - (BPT * tid + j)];
-            tot += h[j];
+                for (int v = 0; v < BPT / 4; ++v) {
+                    const uint4 q4 = reinterpret_cast<const uint4*>(blk)[v];
+                    asc[4 * v] = q4.x, asc[4 * v + 1] = q4.y, asc[4 * v + 2] = q4.z, asc[4 * v + 3] = q4.w;
+                }
+            } else if constexpr (BPT == 2) {
+                const uint2 q2 = *reinterpret_cast<const uint2*>(blk);
+                asc[0] = q2.x, asc[1] = q2.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < BPT; ++j) asc[j] = blk[j];
+            }
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                h[j] = asc[BPT - 1 - j];
+                tot += h[j];
+            }
         }
+        QUEST_SUBSTAMP(2);
         const uint32_t incl = block_scan_incl<NT>(tot, sm.wave_tot[0]);
+        QUEST_SUBSTAMP(3);
         uint32_t run = incl - tot;
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
@@ -97,12 +193,14 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
         }
     }
     __syncthreads();
+    QUEST_SUBSTAMP(4);
     const uint32_t thr_bin = sm.misc[0];
 #pragma unroll
     for (int i = 0; i < C; ++i)
-        if ((uint32_t)i < cpt && c0 + i < n && (key[i] >> kLowBits) == thr_bin)
-            atomicAdd(&sm.hist2[key[i] & (kBins2 - 1)], 1u);
+        if ((uint32_t)i < cpt && c0 + i < n && ((key[i] - kmin) >> shift) == thr_bin)
+            atomicAdd(&sm.hist2[(key[i] - kmin) & low_mask], 1u);
     __syncthreads();
+    QUEST_SUBSTAMP(5);
 
     if (tid < kWave) {  // wave 0: lane l looks at low digit 31-l, suffix sums by shuffle
         const uint32_t above0 = sm.misc[1];
@@ -110,11 +208,12 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
         const uint32_t incl = wave_scan_incl_dpp(cnt);
         const uint32_t excl = incl - cnt;
         if (tid < kBins2 && above0 + excl < k && k <= above0 + incl) {
-            sm.misc[2] = (thr_bin << kLowBits) | (kBins2 - 1 - tid);
+            sm.misc[2] = kmin + ((thr_bin << shift) | (kBins2 - 1 - tid));
             sm.misc[3] = k - (above0 + excl);
         }
     }
     __syncthreads();
+    QUEST_SUBSTAMP(6);
     TopkCursor cur;
     cur.T = sm.misc[2];
     cur.need = sm.misc[3];
@@ -127,7 +226,9 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
         eq += in && key[i] == cur.T;
     }
     const uint32_t packed = gt | (eq << 16);  // both totals < 65536 (n <= 16384)
+    QUEST_SUBSTAMP(7);
     const uint32_t before = block_scan_incl<NT>(packed, sm.wave_tot[1]) - packed;
+    QUEST_SUBSTAMP(8);
     cur.eq_rank = before >> 16;
     cur.pos = (before & 0xffffu) + (cur.eq_rank < cur.need ? cur.eq_rank : cur.need);
     return cur;

@@ -72,6 +72,8 @@ def main():
         idx = ctl.topk_dindices_buffer
         t_s = graph_time(lambda l: qu.decode_sparse_attn(w.q[l], ctl, l, idx), L)
         print(f"sparse_attn(+merge) ppc={plan[0]:4d} chunks={plan[1]:4d}: {t_s:7.2f} us  {bpl['attn'] / t_s / 1e3:7.1f} GB/s")
+        t_ts = graph_time(lambda l: qu.decode_topk_sparse_attn(w.q[l], est[l], ctl, l, write_topk=False), L)
+        print(f"topk+sparse_attn(+merge) ppc={plan[0]:4d} chunks={plan[1]:4d}: {t_ts:7.2f} us")
         if ppc == a0.ppc[0]:
             t_e = graph_time(lambda l: qu.decode_estimate(w.q[l], ctl, l), L)
             print(f"estimate: {t_e:7.2f} us  {bpl['estimate'] / t_e / 1e3:7.1f} GB/s")
