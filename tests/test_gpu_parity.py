@@ -139,8 +139,11 @@ def test_topk_golden_values_and_oracle_indices(golden):
                                   (4000, 3999), (64, 64), (1, 1), (3, 2)])
 def test_topk_ties_bit_exact(n, kk):
     rng = np.random.default_rng(n + kk)
-    rows = 5
+    rows = 8
     vals = np.empty((rows, n), np.float16)
+    vals[5] = rng.integers(0, 65536, n).astype(np.uint16).view(np.float16)   # every bit pattern, NaNs included
+    vals[6] = (180 + 10 * rng.standard_normal(n)).astype(np.float16)         # one binade, like real page scores
+    vals[7] = np.where(rng.random(n) < 0.02, 60000.0, 1e-4 * rng.random(n)).astype(np.float16)  # 2 clusters, wide gap
     vals[0] = (rng.integers(-8, 8, n) * 0.25).astype(np.float16)           # massive ties
     vals[1] = rng.standard_normal(n).astype(np.float16) * 64                 # cfg-like scores
     vals[2] = 1.0                                                            # all equal
