@@ -379,11 +379,25 @@ def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, c
     if hq != num_kv_heads:
         k = k.repeat_interleave(hq // num_kv_heads, dim=1)
         v = v.repeat_interleave(hq // num_kv_heads, dim=1)
-    mask = None
-    if causal:
-        mask = torch.ones(n, kv_len, dtype=torch.bool, device=q.device).tril(diagonal=kv_len - n)
-    o = torch.nn.functional.scaled_dot_product_attention(
-        q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), attn_mask=mask, scale=1.0 / math.sqrt(head_dim))
+    sdpa = torch.nn.functional.scaled_dot_product_attention
+    qh, kh, vh = q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)
+    scale = 1.0 / math.sqrt(head_dim)
+    if not causal:
+        o = sdpa(qh, kh, vh, scale=scale)
+    else:
+        # Query i sees keys 0 .. kv_len - n + i (whole prompt: n == kv_len; chunked prefill: n < kv_len).
+        # Blocks of query rows keep whatever the backend materialises bounded: the math backend (the one this
+        # ROCm build picks for these shapes) allocates heads x rows x keys scores -- 64 GiB for a 32K prompt at
+        # once, <= 1 GiB per block here.
+        o = torch.empty_like(qh)
+        blk = max(1, min(n, (1 << 28) // max(hq * kv_len, 1)))
+        cols = torch.arange(kv_len, device=q.device)
+        for r0 in range(0, n, blk):
+            r1 = min(n, r0 + blk)
+            hi = kv_len - n + r1  # keys beyond the block's last row are masked for every row of it
+            limit = (kv_len - n + torch.arange(r0, r1, device=q.device)).unsqueeze(1)
+            o[:, r0:r1] = sdpa(qh[:, r0:r1], kh[:, :hi], vh[:, :hi], attn_mask=cols[:hi].unsqueeze(0) <= limit,
+                               scale=scale)
     return o.transpose(0, 1).contiguous()
 
 

@@ -585,3 +585,39 @@ def test_dense_decode_shared_lists_gqa(Hq, Hkv, D, L, layout):
     table = np.array(ctl.kv_cache.indicies, np.int32)
     eo, _ = oracle.sparse_attn(q, kv_o, np.tile(table[:-1], (Hq, 1)), len(table) - 1, int(table[-1]), kv_o.last_page_len)
     _close(o.cpu().numpy(), eo, tol=2e-3)
+
+
+@pytest.mark.parametrize("Hq,Hkv,layout", [(4, 4, 0), (8, 2, 1)])
+def test_prefill_attention_whole_and_chunked(Hq, Hkv, layout):
+    """prefill_forward (not on the sparse path; torch SDPA over the paged cache): the whole prompt at once and
+    the same prompt in two chunks over a growing cache both equal causal attention in fp32."""
+    qu = _qu()
+    dev = torch.device("cuda:0")
+    L, D, split = 203, 128, 77
+    g = torch.Generator(device=dev).manual_seed(4)
+    q = torch.randn(L, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    k = torch.randn(L, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    v = torch.randn(L, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    kk = k.float().repeat_interleave(Hq // Hkv, 1)
+    vv = v.float().repeat_interleave(Hq // Hkv, 1)
+    s = torch.einsum("qhd,khd->hqk", q.float(), kk) / D ** 0.5
+    s = s.masked_fill(~torch.ones(L, L, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    ref = torch.einsum("hqk,khd->qhd", s.softmax(-1), vv)
+
+    ctl = make_controller(L, Hq, Hkv, D, PAGE, 4, layout=layout, shuffle_seed=2)
+    ctl.prepare_metadata(L)
+    ctl.begin_forward(L)
+    qu.append_kv(k, v, ctl, 0)
+    o = qu.prefill_forward(q, ctl, 0)
+    ctl.end_forward()
+    torch.testing.assert_close(o.float(), ref, rtol=5e-3, atol=5e-3)
+
+    ctl = make_controller(L, Hq, Hkv, D, PAGE, 4, layout=layout, shuffle_seed=3)
+    outs = []
+    for a, b in ((0, split), (split, L)):
+        ctl.prepare_metadata(b - a)
+        ctl.begin_forward(b - a)
+        qu.append_kv(k[a:b], v[a:b], ctl, 0)
+        outs.append(qu.prefill_forward(q[a:b], ctl, 0))
+        ctl.end_forward()
+    torch.testing.assert_close(torch.cat(outs).float(), ref, rtol=5e-3, atol=5e-3)
