@@ -117,7 +117,17 @@ __global__ __launch_bounds__(kEstWaves* kWave) void estimate_kernel(const half_t
         // Loads are unconditional from a clamped entry: a predicated load compiles to branch + load + wait
         // and serialises the round trips.  Clamped rows re-read the last entry (tail tiles only).
         ecl[j] = e < n_cap ? e : n_cap - 1;
-        page[j] = (size_t)idx[ecl[j] / S];
+    }
+    if (S % EW == 0) {
+        // the tile's EW consecutive entries (and the clamped ones of a tail tile) lie in ONE metadata page: a
+        // single wave-uniform (scalar) table load instead of a vector load per row at the head of the
+        // table -> metadata dependency chain
+        const size_t pg = (size_t)idx[e0 / S];
+#pragma unroll
+        for (int j = 0; j < kEstIter; ++j) page[j] = pg;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kEstIter; ++j) page[j] = (size_t)idx[ecl[j] / S];
     }
     if (tail.state) {  // live length (<= n_cap); whole tiles past it have nothing to do
         n_out = (uint32_t)(tail.state->n_pages - 1);

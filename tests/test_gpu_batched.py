@@ -32,16 +32,18 @@ def _gather(buf_layer, indices, n_entries, layout):
     return pages[:, 0].reshape(n * S, H, D)[:n_entries], pages[:, 1].reshape(n * S, H, D)[:n_entries]
 
 
-@pytest.mark.parametrize("Hq,Hkv,layout,lens,same_split", [
-    (4, 4, 0, (16 * 31 + 10, 16 * 20 + 16, 16 * 40 + 1), True),
-    (8, 2, 1, (16 * 15 + 16, 16 * 33 + 5), True),
-    (8, 8, 0, (16 * 70 + 3, 16 * 24 + 15, 16 * 24 + 16, 16 * 50 + 8, 16 * 9 + 9), False),
+@pytest.mark.parametrize("Hq,Hkv,layout,lens,same_split,D", [
+    (4, 4, 0, (16 * 31 + 10, 16 * 20 + 16, 16 * 40 + 1), True, 128),
+    (8, 4, 0, (16 * 12 + 3, 16 * 26 + 16), True, 64),
+    (2, 1, 1, (16 * 18 + 7, 16 * 11 + 1, 16 * 30 + 16), True, 256),
+    (8, 2, 1, (16 * 15 + 16, 16 * 33 + 5), True, 128),
+    (8, 8, 0, (16 * 70 + 3, 16 * 24 + 15, 16 * 24 + 16, 16 * 50 + 8, 16 * 9 + 9), False, 128),
 ])
-def test_batched_decode_matches_single_sequence(Hq, Hkv, layout, lens, same_split):
+def test_batched_decode_matches_single_sequence(Hq, Hkv, layout, lens, same_split, D):
     import quest_amd.utils as qu
 
     dev = torch.device("cuda:0")
-    layers, D, B, steps = 2, 128, 7, 36
+    layers, B, steps = 2, 7, 36
     n = len(lens)
     cap = max(lens) + steps + 40
     ks = [cuda(inputs(100 + i, L, Hq, Hkv, D)[1]) for i, L in enumerate(lens)]
