@@ -532,7 +532,7 @@ def main():
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Yarn-Llama-2-7B-128K shapes, 1 sequence per GPU, "
+            "config": {"workload": f"BASELINE configs[2]: Yarn-Llama-2-7B-128K shapes, {n_local} sequence(s) per GPU, "
                                    "self-attention chain (append+estimate+top-k+sparse attn) x all layers per token",
                        "layers": a.layers, "num_qo_heads": a.heads, "num_kv_heads": a.kv_heads,
                        "head_dim": a.head_dim, "seqlen": a.seqlen, "seqlen_after_run": ctl.kv_cache.seqlen, "page_size": a.page_size,
