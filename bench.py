@@ -80,7 +80,7 @@ class Workload:
         self.page_budget = a.token_budget // a.page_size
         L = a.seqlen
         self.ctl = qu.InferenceController(a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
-                                          L + a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,
+                                          L + 2 * a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,  # 2x: the N > 1 no-gather rerun
                                           num_kv_heads=a.kv_heads,
                                           layout=a.layout, shuffle_seed=1234)
         g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id)
@@ -167,7 +167,7 @@ class BatchedWorkload:
         self.page_budget = a.token_budget // a.page_size
         L = a.seqlen
         self.ctl = qu.BatchedInferenceController(n_seqs, a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
-                                                 L + a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,
+                                                 L + 2 * a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,  # 2x: the N > 1 no-gather rerun
                                                  num_kv_heads=a.kv_heads, layout=a.layout, shuffle_seed=1234)
         kbuf = torch.empty(L - 1, a.kv_heads, a.head_dim, dtype=torch.float16, device=dev)
         vbuf = torch.empty_like(kbuf)
@@ -479,6 +479,20 @@ def main():
     ms_per_step = elapsed * 1e3 / a.steps
     value = world * n_local * a.steps / elapsed  # one token per local sequence per step
 
+    # side figure for N > 1 ("report both with and without the gather"): the same K steps again
+    # without the all_gather of token ids; not part of `value`
+    ms_no_gather = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_no_gather = float(t.item()) * 1e3 / a.steps
+
     out = None
     if rank == 0:
         qu = w.qu
@@ -549,6 +563,7 @@ def main():
                          "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att,
                          "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}},
             "ops_us": ops,
+            "ms_per_step_without_token_gather": ms_no_gather,
             "selfattn_us_per_layer": ms_per_step * 1e3 / a.layers / n_local,
             "chain_bytes_per_layer": bpl["chain"],
             "chain_frac_of_hbm_peak": bpl["chain"] * n_local / (ms_per_step * 1e-3 / a.layers) / 1e9 / HBM_PEAK_GBS,

@@ -61,7 +61,14 @@ def _check_half(x: torch.Tensor, op: str) -> None:
         raise RuntimeError(f"{op} failed to dispatch with dtype {x.dtype}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(x: torch.Tensor) -> int:
+    """hipStream_t of torch's current stream on x's device (raw handle: ~0.3 us instead of ~3 us through
+    torch.cuda.current_stream(), which matters for the host-bound eager path)."""
+    if _raw_stream is not None:
+        return _raw_stream(x.device.index)
     return torch.cuda.current_stream(x.device).cuda_stream
 
 

@@ -213,10 +213,10 @@ class BatchedInferenceController:
         self._dense_handler = None
 
     def kv_layer(self, layer_idx: int) -> torch.Tensor:
-        return self.kv_pool.buf[layer_idx]
+        return self.kv_pool.layer(layer_idx)
 
     def metadata_layer(self, layer_idx: int) -> torch.Tensor:
-        return self.metadata_pool.buf[layer_idx]
+        return self.metadata_pool.layer(layer_idx)
 
     def prepare_metadata(self, seq_len: int = 1) -> None:
         """Host mirror of the device-side reservation (``step_advance_batched``) for every sequence."""

@@ -34,6 +34,7 @@ class KvPool:
             order = torch.randperm(capacity, generator=g).tolist()
         self._free: List[int] = order[::-1]
         self._in_use = [False] * capacity
+        self._layers = [self._buf[i] for i in range(num_layers)]  # per-layer views, built once (hot in eager decode)
 
     @property
     def layout(self) -> int:
@@ -46,6 +47,9 @@ class KvPool:
     @property
     def num_layers(self) -> int:
         return self._buf.shape[0]
+
+    def layer(self, layer_idx: int) -> torch.Tensor:
+        return self._layers[layer_idx]
 
     @property
     def capacity(self) -> int:
@@ -114,8 +118,7 @@ class KvCache:
     indices = indicies
 
     def buf_layer(self, layer_idx: int) -> torch.Tensor:
-        assert layer_idx < self._pool.num_layers
-        return self._pool.buf[layer_idx]
+        return self._pool.layer(layer_idx)  # IndexError past the last layer
 
     def append_seq(self, seq_len: int) -> int:
         """Reserve room for ``seq_len`` more tokens; returns how many pages were added."""
