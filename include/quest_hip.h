@@ -228,7 +228,9 @@ int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_heads, uint3
  *     materialised up to its capacity like the single-sequence tables above;
  *   - `state` is an array of n_seqs step states; q / o / k / v are [n_seqs][heads][dim], scores
  *     [n_seqs][num_qo_heads][score_stride], lse [n_seqs][num_qo_heads].
- * Results per sequence are bit-identical to the single-sequence *_dyn entry points.
+ * Per sequence: pools, estimates and page selections are bit-identical to the single-sequence *_dyn entry
+ * points; attention outputs too when the work split (pages per workgroup) is the same, otherwise they differ
+ * by the fp32 rounding of a different partial-state merge order (tests: <= 2e-3).
  */
 typedef struct quest_batch {
     uint32_t n_seqs;
