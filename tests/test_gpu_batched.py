@@ -1,6 +1,8 @@
 """Batched state-driven decode (n sequences per launch, one shared pool) must reproduce, per sequence, what
 the single-sequence state-driven path computes: states, pool bytes, estimates and selections bit for bit,
 attention outputs bit for bit when the work split is the same and within the attention tolerance otherwise."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -43,7 +45,7 @@ def test_batched_decode_matches_single_sequence(Hq, Hkv, layout, lens, same_spli
     import quest_amd.utils as qu
 
     dev = torch.device("cuda:0")
-    layers, B, steps = 2, 7, 36
+    layers, B, steps = 2, 7, int(os.environ.get("QUEST_SOAK_STEPS", "36"))  # soak: QUEST_SOAK_STEPS=400
     n = len(lens)
     cap = max(lens) + steps + 40
     ks = [cuda(inputs(100 + i, L, Hq, Hkv, D)[1]) for i, L in enumerate(lens)]
