@@ -174,9 +174,12 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         p.last_page_len = (uint32_t)st.kv_last_page_len;
         p.last_page_idx = st.kv_last_page_idx;
     }
-    const uint32_t n_slots = p.n_sel + 1;  // selected pages + the current page
+    // slots = selected pages + the current page; a state-driven launch on a sequence still shorter than the
+    // budget selects ALL of its pages (k = n: the reference's full-attention branch, QuestAttention.py:123-132)
+    // and workgroups whose chunk lies past the live list write an empty partial (weight 0 in the merge)
+    uint32_t n_slots = p.n_sel + 1;
     const uint32_t slot_begin = chunk * p.pages_per_chunk;
-    const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
+    uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
 
     // q is requested now but first used after the top-k front end, so its latency hides under the selection
     const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);
@@ -195,9 +198,13 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             p.n_scores = (uint32_t)(st.n_pages - 1);
             p.last_page_len = (uint32_t)st.kv_last_page_len;
             p.last_page_idx = st.kv_last_page_idx;
+            p.n_sel = min(p.n_sel, p.n_scores);
+            n_slots = p.n_sel + 1;
+            slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
         }
         const uint32_t n = p.n_scores, n_cap = n_cap0;
         constexpr int NT = NW * kWave;
+        if (n > 0) {  // block-uniform; a one-page sequence has no row to select from (only the current page)
         // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n), so no address
         // below depends on the live length -- in a state-driven launch the score loads do not wait for the
         // state load.
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                     if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + my_slot[i]] = key_to_half_bits(key[i]);
                 }
         }
+        }  // n > 0
     }
     float8 qv = to_f32(q_raw);
     qv *= p.scale_log2;

@@ -166,7 +166,8 @@ class LlamaForCausalLM(nn.Module):
     # ------------------------------------------------------------------ one hipGraph per generated token
     def capture_decode_graph(self) -> None:
         """Capture ONE decode step (all layers + lm_head) and keep it for ``decode_graph_step``.  Call after
-        the prompt has been processed (the cache must already hold at least `page budget` pages).  The
+        the prompt has been processed (any length: while the cache holds fewer pages than the budget the
+        sparse layers attend all of them, like the reference's full-attention branch).  The
         graph reads its input from ``self.graph_input`` ``[1, 1, hidden]`` and leaves the logits in
         ``self.graph_logits``; sequence lengths live on the device (EXTENSION)."""
         m, ctl = self.model, self.model.iController

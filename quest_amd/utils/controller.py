@@ -107,7 +107,7 @@ class InferenceController:
         if seq_len > 1:
             return  # prefill: append_kv_cache_prefill + prefill_with_paged_kv_cache need nothing else
 
-        assert n_pages > 1, "decode needs at least two pages (the current page is excluded from selection)"
+        assert n_pages >= 1, "decode needs a non-empty cache"  # one page: attention over the current page only
         if updateTensor and self._without_last_pages != n_pages:
             # input ids of the top-k ([H, n_pages-1], controller.py:106), rebuilt only when a page was added
             self.kv_indices_without_last = self.kv_indices_with_last[:-1].unsqueeze(0).expand(
@@ -144,11 +144,14 @@ class InferenceController:
 
     def begin_graph_decode(self, dense_layers: bool = False) -> None:
         """Plan the sparse decode for the configured budget once, for a graph that will be replayed over
-        many tokens (the plan depends only on the budget, which is constant once pages >= budget).  With
+        many tokens (the plan depends only on the budget).  With
         ``dense_layers`` a second handler is planned for full-KV layers (the model's first layers,
         llama.py:428-430) over the pool's capacity."""
-        budget = self._page_budget
-        assert len(self.kv_cache.indicies) >= budget, "graph decode needs the sparse regime (pages >= budget)"
+        # The sequence may still be shorter than the budget: the state-driven attention launch then selects all
+        # of its pages (k = n), which is the reference's full-attention branch (QuestAttention.py:123-132), and
+        # moves into the sparse regime by itself as the sequence grows -- same graph.
+        assert len(self.kv_cache.indicies) >= 1, "prefill first"
+        budget = min(self._page_budget, self.max_pages)
         self.inference_page_budget = budget
         self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
                                            self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
@@ -241,8 +244,9 @@ class BatchedInferenceController:
     def begin_graph_decode(self, dense_layers: bool = False) -> None:
         """Plan the batched sparse decode once for the configured budget (every sequence must already be in
         the sparse regime), and optionally the batched full-KV decode over the per-sequence capacity."""
-        budget = self._page_budget
-        assert all(len(c.kv_cache.indicies) >= budget for c in self.seqs), "graph decode needs pages >= budget"
+        # sequences shorter than the budget attend all of their pages (see InferenceController.begin_graph_decode)
+        assert all(len(c.kv_cache.indicies) >= 1 for c in self.seqs), "prefill every sequence first"
+        budget = min(self._page_budget, self.max_pages)
         self.inference_page_budget = budget
         self._decode_handler.set_batch(self.n_seqs)
         self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,

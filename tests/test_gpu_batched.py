@@ -37,6 +37,8 @@ def _gather(buf_layer, indices, n_entries, layout):
 @pytest.mark.parametrize("Hq,Hkv,layout,lens,same_split,D", [
     (4, 4, 0, (16 * 31 + 10, 16 * 20 + 16, 16 * 40 + 1), True, 128),
     (8, 4, 0, (16 * 12 + 3, 16 * 26 + 16), True, 64),
+    # mixed regimes in one batch: shorter than the budget (all pages attended), at the budget, far beyond it
+    (4, 4, 0, (19, 16 * 30 + 5, 16 * 6 + 16, 7), True, 128),
     (2, 1, 1, (16 * 18 + 7, 16 * 11 + 1, 16 * 30 + 16), True, 256),
     (8, 2, 1, (16 * 15 + 16, 16 * 33 + 5), True, 128),
     (8, 8, 0, (16 * 70 + 3, 16 * 24 + 15, 16 * 24 + 16, 16 * 50 + 8, 16 * 9 + 9), False, 128),

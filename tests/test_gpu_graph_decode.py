@@ -167,3 +167,89 @@ def test_state_advance_stops_at_pool_capacity():
         ctl.prepare_metadata(1)
     with pytest.raises(RuntimeError, match="KvPool exhausted"):
         ctl.prepare_metadata(1)
+
+
+@pytest.mark.parametrize("L0", [5, 16, 40])
+def test_graph_decode_from_short_context_into_the_sparse_regime(L0):
+    """ONE graph captured while the sequence is still shorter than the page budget (down to a single page):
+    it attends all pages (the reference's full-attention branch) and slides into the sparse regime as the
+    sequence grows.  Reference: the eager host-planned path, which switches branches by itself."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    Hq, Hkv, D, B, layers, steps = 4, 2, 128, 5, 2, 150  # 5-page budget; 150 tokens cross it at page 6
+    _, k0, v0 = inputs(31, L0, Hq, Hkv, D)
+    g = torch.Generator(device=dev).manual_seed(12)
+    new_q = torch.randn(steps, layers, 1, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, layers, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, layers, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    def prefilled():
+        ctl = make_controller(L0 + steps + 40, Hq, Hkv, D, PAGE, B, num_layers=layers, max_seq_len=L0 + steps + 40)
+        ctl.prepare_metadata(L0)
+        ctl.begin_forward(L0)
+        for l in range(layers):
+            qu.append_kv(cuda(k0), cuda(v0), ctl, l)
+        ctl.end_forward()
+        return ctl
+
+    ea = prefilled()
+    eager_out, regimes = [], set()
+    for t in range(steps):
+        ea.prepare_metadata(1)
+        ea.begin_forward(1)
+        regimes.add(ea.need_estimate())
+        outs = []
+        for l in range(layers):
+            q, k = new_q[t, l].clone(), new_k[t, l].clone()
+            qu.apply_rope_in_place(q, k, ea.kv_cache.seqlen - 1)
+            if ea.need_estimate():
+                est = qu.decode_append_estimate(q, k, new_v[t, l], ea, l)
+                outs.append(qu.decode_topk_sparse_attn(q, est, ea, l, write_topk=False))
+            else:
+                qu.append_kv(k, new_v[t, l], ea, l)
+                outs.append(qu.decode_sparse_attn(q, ea, l, ea.kv_indices_without_last))
+        ea.end_forward()
+        eager_out.append(torch.stack(outs))
+    assert regimes == {False, True}, "the run must start dense and end sparse"
+
+    gr = prefilled()
+    gr.enable_device_state()
+    gr.begin_graph_decode()
+    qbuf = torch.empty(layers, 1, Hq, D, device=dev, dtype=torch.float16)
+    kbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
+    vbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
+    scores = torch.empty(Hq, gr.max_pages, device=dev, dtype=torch.float16)
+    obuf = [None] * layers
+
+    def step():
+        qu.step_advance_dyn(gr)
+        for l in range(layers):
+            obuf[l] = qu.decode_layer_dyn(qbuf[l], kbuf[l], vbuf[l], gr, l, scores, apply_rope=True)
+
+    qbuf.copy_(new_q[0]); kbuf.copy_(new_k[0]); vbuf.copy_(new_v[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr.sync_device_state()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    gr.sync_device_state()
+    for t in range(steps):
+        qbuf.copy_(new_q[t]); kbuf.copy_(new_k[t]); vbuf.copy_(new_v[t])
+        graph.replay()
+        gr.prepare_metadata(1)
+        got = torch.stack([o.clone() for o in obuf])
+        # dense regime: same pages, different partial-merge order than the eager full-attention kernel -> tolerance
+        torch.testing.assert_close(got.float(), eager_out[t].float(), rtol=2e-3, atol=2e-3)
+    for l in range(layers):
+        ia = torch.tensor(ea.kv_cache.indicies, device=dev)
+        L = ea.kv_cache.seqlen
+        assert gr.kv_cache.indicies == ea.kv_cache.indicies and gr.kv_cache.seqlen == L
+        a = ea.kv_cache.buf_layer(l)[ia].reshape(-1, 2, PAGE, Hkv, D).transpose(0, 1).reshape(2, -1, Hkv, D)[:, :L]
+        b = gr.kv_cache.buf_layer(l)[ia].reshape(-1, 2, PAGE, Hkv, D).transpose(0, 1).reshape(2, -1, Hkv, D)[:, :L]
+        assert torch.equal(a, b)
