@@ -205,125 +205,125 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         const uint32_t n = p.n_scores, n_cap = n_cap0;
         constexpr int NT = NW * kWave;
         if (n > 0) {  // block-uniform; a one-page sequence has no row to select from (only the current page)
-        // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n), so no address
-        // below depends on the live length -- in a state-driven launch the score loads do not wait for the
-        // state load.
-        const uint32_t cpt = p.cpt;
-        const uint32_t c0 = threadIdx.x * cpt;
-        const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
-        const int32_t* table = sv.indices;
-        extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
-        uint16_t* keys_s = reinterpret_cast<uint16_t*>(fe_dyn);
-        const bool stage_ids = p.stage_ids != 0;
-        int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
-        uint32_t key[FC];
-        int32_t idr[8] = {};  // direct path: page ids of the owned columns
-        const bool direct = p.direct != 0;  // block-uniform
-        if (direct) {
-            // scores and page ids straight into ownership layout: lane t reads the 8/16 (+16/32) bytes of its
-            // cpt columns, a wave reads 0.5-1 KiB contiguous -- no LDS transpose.  Chunks past the capacity
-            // re-read the last chunk (their columns are masked by c0 + i < n everywhere).
-            const uint32_t last = ((n_cap - 1) / cpt) * cpt, cb = c0 < last ? c0 : last;
-            uint32_t w[4] = {};
-            if (cpt == 8) {
-                const uint4 k4 = *reinterpret_cast<const uint4*>(srow + cb);
-                const int4 a = *reinterpret_cast<const int4*>(table + cb), b = *reinterpret_cast<const int4*>(table + cb + 4);
-                w[0] = k4.x, w[1] = k4.y, w[2] = k4.z, w[3] = k4.w;
-                idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w, idr[4] = b.x, idr[5] = b.y, idr[6] = b.z, idr[7] = b.w;
-            } else {  // cpt == 4
-                const uint2 k2 = *reinterpret_cast<const uint2*>(srow + cb);
-                const int4 a = *reinterpret_cast<const int4*>(table + cb);
-                w[0] = k2.x, w[1] = k2.y;
-                idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w;
-            }
-            topk_clear<NT>(sm);  // overlaps the loads above
-            QUEST_STAMP(1);
-            uint32_t mm = kMmNeutral;
-#pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                if (i < 8) {
-                    const uint32_t raw = (i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu;
-                    key[i] = half_key((uint16_t)raw);
-                    if ((uint32_t)i < cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
-                } else {
-                    key[i] = 0;
+            // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n), so no address
+            // below depends on the live length -- in a state-driven launch the score loads do not wait for the
+            // state load.
+            const uint32_t cpt = p.cpt;
+            const uint32_t c0 = threadIdx.x * cpt;
+            const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
+            const int32_t* table = sv.indices;
+            extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
+            uint16_t* keys_s = reinterpret_cast<uint16_t*>(fe_dyn);
+            const bool stage_ids = p.stage_ids != 0;
+            int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
+            uint32_t key[FC];
+            int32_t idr[8] = {};  // direct path: page ids of the owned columns
+            const bool direct = p.direct != 0;  // block-uniform
+            if (direct) {
+                // scores and page ids straight into ownership layout: lane t reads the 8/16 (+16/32) bytes of its
+                // cpt columns, a wave reads 0.5-1 KiB contiguous -- no LDS transpose.  Chunks past the capacity
+                // re-read the last chunk (their columns are masked by c0 + i < n everywhere).
+                const uint32_t last = ((n_cap - 1) / cpt) * cpt, cb = c0 < last ? c0 : last;
+                uint32_t w[4] = {};
+                if (cpt == 8) {
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(srow + cb);
+                    const int4 a = *reinterpret_cast<const int4*>(table + cb), b = *reinterpret_cast<const int4*>(table + cb + 4);
+                    w[0] = k4.x, w[1] = k4.y, w[2] = k4.z, w[3] = k4.w;
+                    idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w, idr[4] = b.x, idr[5] = b.y, idr[6] = b.z, idr[7] = b.w;
+                } else {  // cpt == 4
+                    const uint2 k2 = *reinterpret_cast<const uint2*>(srow + cb);
+                    const int4 a = *reinterpret_cast<const int4*>(table + cb);
+                    w[0] = k2.x, w[1] = k2.y;
+                    idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w;
                 }
-            }
-            topk_publish_range<NT>(sm, mm);
-            QUEST_STAMP(2);
-        } else {
-            // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
-            uint16_t kraw[FC];
-            int32_t iraw[FC];
+                topk_clear<NT>(sm);  // overlaps the loads above
+                QUEST_STAMP(1);
+                uint32_t mm = kMmNeutral;
 #pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const uint32_t e = threadIdx.x + i * NT, ec = e < n ? e : n - 1;  // clamped, unconditional
-                kraw[i] = srow[ec];
-                iraw[i] = stage_ids ? table[ec] : 0;
-            }
-            topk_clear<NT>(sm);  // overlaps the score / page-id loads above
-            QUEST_STAMP(1);
-            uint32_t mm = kMmNeutral;
-#pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const uint32_t e = threadIdx.x + i * NT;
-                if (e < n) {
-                    const uint32_t kk = half_key(kraw[i]);
-                    mm = pk_max_u16(mm, mm_pack(kk));
-                    keys_s[e] = (uint16_t)kk;
-                    if (stage_ids) ids_s[e] = iraw[i];
+                for (int i = 0; i < FC; ++i) {
+                    if (i < 8) {
+                        const uint32_t raw = (i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu;
+                        key[i] = half_key((uint16_t)raw);
+                        if ((uint32_t)i < cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
+                    } else {
+                        key[i] = 0;
+                    }
                 }
+                topk_publish_range<NT>(sm, mm);
+                QUEST_STAMP(2);
+            } else {
+                // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
+                uint16_t kraw[FC];
+                int32_t iraw[FC];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const uint32_t e = threadIdx.x + i * NT, ec = e < n ? e : n - 1;  // clamped, unconditional
+                    kraw[i] = srow[ec];
+                    iraw[i] = stage_ids ? table[ec] : 0;
+                }
+                topk_clear<NT>(sm);  // overlaps the score / page-id loads above
+                QUEST_STAMP(1);
+                uint32_t mm = kMmNeutral;
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const uint32_t e = threadIdx.x + i * NT;
+                    if (e < n) {
+                        const uint32_t kk = half_key(kraw[i]);
+                        mm = pk_max_u16(mm, mm_pack(kk));
+                        keys_s[e] = (uint16_t)kk;
+                        if (stage_ids) ids_s[e] = iraw[i];
+                    }
+                }
+                topk_publish_range<NT>(sm, mm);
+                QUEST_STAMP(2);
             }
-            topk_publish_range<NT>(sm, mm);
-            QUEST_STAMP(2);
-        }
-        __syncthreads();
-        QUEST_STAMP(3);
-        if (!direct) topk_load_keys<FC>(keys_s, c0, n, cpt, key);
+            __syncthreads();
+            QUEST_STAMP(3);
+            if (!direct) topk_load_keys<FC>(keys_s, c0, n, cpt, key);
 #ifdef QUEST_TIMELINE
-        long long sub[9] = {};
-        TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, sub);
+            long long sub[9] = {};
+            TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, sub);
 #else
-        TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt);
+            TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt);
 #endif
 #ifdef QUEST_TIMELINE
-        for (int i = 0; i < 9; ++i) sub_out[i] = sub[i];
+            for (int i = 0; i < 9; ++i) sub_out[i] = sub[i];
 #endif
-        QUEST_STAMP(4);
-        uint32_t my_slot[FC];
-        bool mine[FC];
+            QUEST_STAMP(4);
+            uint32_t my_slot[FC];
+            bool mine[FC];
 #pragma unroll
-        for (int i = 0; i < FC; ++i) {
-            uint32_t slot;
-            mine[i] = topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot) && slot >= slot_begin && slot < slot_end;
-            my_slot[i] = slot;
-            if (mine[i]) {
-                // two separate loads: a select between an LDS and a global ADDRESS becomes one flat load
-                // whose address-space cast this compiler miscompiles (illegal v_cmp on src_shared_base)
-                int32_t pg;
-                if (direct) {
-                    pg = idr[i & 7];
-                } else if (stage_ids) {
-                    pg = ids_s[c0 + i];
-                } else {
-                    pg = table[c0 + i];
-                    asm volatile("" : "+v"(pg));
-                }
-                s_sel[slot - slot_begin] = pg;
-            }
-        }
-        __syncthreads();
-        QUEST_STAMP(5);
-        // optional copy of the selection for callers that inspect it: issued after the barrier so no
-        // workgroup waits on these stores before it starts fetching K/V
-        if (p.sel_idx_out) {
-#pragma unroll
-            for (int i = 0; i < FC; ++i)
+            for (int i = 0; i < FC; ++i) {
+                uint32_t slot;
+                mine[i] = topk_take(cur, key[i], (uint32_t)i < cpt && c0 + i < n, slot) && slot >= slot_begin && slot < slot_end;
+                my_slot[i] = slot;
                 if (mine[i]) {
-                    p.sel_idx_out[(size_t)hq * p.n_sel + my_slot[i]] = s_sel[my_slot[i] - slot_begin];
-                    if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + my_slot[i]] = key_to_half_bits(key[i]);
+                    // two separate loads: a select between an LDS and a global ADDRESS becomes one flat load
+                    // whose address-space cast this compiler miscompiles (illegal v_cmp on src_shared_base)
+                    int32_t pg;
+                    if (direct) {
+                        pg = idr[i & 7];
+                    } else if (stage_ids) {
+                        pg = ids_s[c0 + i];
+                    } else {
+                        pg = table[c0 + i];
+                        asm volatile("" : "+v"(pg));
+                    }
+                    s_sel[slot - slot_begin] = pg;
                 }
-        }
+            }
+            __syncthreads();
+            QUEST_STAMP(5);
+            // optional copy of the selection for callers that inspect it: issued after the barrier so no
+            // workgroup waits on these stores before it starts fetching K/V
+            if (p.sel_idx_out) {
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+                    if (mine[i]) {
+                        p.sel_idx_out[(size_t)hq * p.n_sel + my_slot[i]] = s_sel[my_slot[i] - slot_begin];
+                        if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + my_slot[i]] = key_to_half_bits(key[i]);
+                    }
+            }
         }  // n > 0
     }
     float8 qv = to_f32(q_raw);
