@@ -1,0 +1,84 @@
+"""Seeded random sweep of shapes through the whole chain -- unfused ops, fused launches and the state-driven
+(graph-replayable) launches -- against the CPU oracle: pools / estimates / selections bit-exact, attention
+within the attention tolerance.  Complements the hand-picked cases of test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _harness import cuda, fill, inputs, make_controller, oracle_pools, pools_match
+
+pytestmark = pytest.mark.gpu
+U16 = lambda a: np.ascontiguousarray(a).view(np.uint16)
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        D = int(rng.choice([64, 128, 128, 128, 256]))
+        Hkv = int(rng.choice([1, 2, 3, 4, 8]))
+        G = int(rng.choice([1, 1, 2, 4, 8]))
+        if Hkv * G > 16:
+            continue
+        page = int(rng.choice([16, 16, 16, 4, 8, 32, 5]))
+        n_pages = int(rng.integers(2, 60))
+        L = (n_pages - 1) * page + int(rng.integers(1, page + 1))
+        B = int(rng.integers(2, n_pages + 3))  # sometimes >= pages: the full-attention branch
+        out.append((Hkv * G, Hkv, D, page, L, B, int(rng.integers(0, 2)), int(rng.integers(0, 1 << 20))))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(36, 2024), ids=lambda c: "Hq%d_Hkv%d_D%d_S%d_L%d_B%d_lay%d" % c[:7])
+def test_random_shape_chain_matches_oracle(case):
+    import quest_amd.utils as qu
+
+    Hq, Hkv, D, page, L, B, layout, seed = case
+    q, k, v = inputs(seed % 9973, L, Hq, Hkv, D)
+    ctl = make_controller(L, Hq, Hkv, D, page, B, layout=layout, shuffle_seed=seed)
+    fill(ctl, k, v, split=max(1, L - 1 - seed % 3))  # last 1-3 tokens through the decode append
+    kv_o, meta_o = oracle_pools(ctl, k, v)
+    assert pools_match(ctl, kv_o, meta_o, L)
+    table = np.array(ctl.kv_cache.indicies, np.int32)
+    qd = cuda(q)
+    if not ctl.need_estimate():  # budget covers the cache: full attention over every page
+        o = qu.decode_sparse_attn(qd, ctl, 0, ctl.kv_indices_without_last)
+        ctl.end_forward()
+        idx = np.tile(table[:-1], (Hq, 1)) if len(table) > 1 else np.zeros((Hq, 1), np.int32)
+        eo, _ = oracle.sparse_attn(q, kv_o, idx, len(table) - 1, int(table[-1]), kv_o.last_page_len)
+        np.testing.assert_allclose(o.cpu().numpy().astype(np.float32), eo.astype(np.float32), rtol=2e-3, atol=2e-3)
+        return
+    # reference op sequence
+    est = qu.decode_estimate(qd, ctl, 0)
+    e_est = oracle.estimate(q, meta_o)
+    assert np.array_equal(U16(est.cpu().numpy()), U16(e_est))
+    qu.decode_topk(est, ctl)
+    budget = ctl.inference_page_budget
+    ev, ei = oracle.topk(e_est, np.tile(table[:-1], (Hq, 1)), budget - 1)
+    assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
+    assert np.array_equal(U16(ctl.topk_dout_buffer.cpu().numpy()), U16(ev))
+    o = qu.decode_sparse_attn(qd, ctl, 0, ctl.topk_dindices_buffer)
+    eo, _ = oracle.sparse_attn(q, kv_o, ei, budget - 1, int(table[-1]), kv_o.last_page_len)
+    np.testing.assert_allclose(o.cpu().numpy().astype(np.float32), eo.astype(np.float32), rtol=2e-3, atol=2e-3)
+    # fused top-k + attention: same selection, same output bits
+    ctl.topk_dindices_buffer.zero_()
+    o2 = qu.decode_topk_sparse_attn(qd, est, ctl, 0, write_topk=True)
+    assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
+    assert torch.equal(o, o2)
+    ctl.end_forward()
+    # state-driven launches on the same cache: rewind one token on the device state and decode it again
+    # (append of the same key/value is idempotent on the pools)
+    ctl.enable_device_state()
+    st = ctl.step_state.cpu().tolist()
+    # undo the last token: the state must describe the cache BEFORE it
+    if st[2] > 1:
+        st[0] -= 1; st[2] -= 1
+        ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
+        ctl.begin_graph_decode()
+        scores = torch.zeros(Hq, ctl.max_pages, dtype=torch.float16, device="cuda:0")
+        qu.step_advance_dyn(ctl)
+        o3 = qu.decode_layer_dyn(qd, cuda(k[L - 1:L]), cuda(v[L - 1:L]), ctl, 0, scores)
+        n_out = len(table) - 1
+        assert np.array_equal(U16(scores[:, :n_out].cpu().numpy()), U16(e_est))
+        assert pools_match(ctl, kv_o, meta_o, L)
+        np.testing.assert_allclose(o3.cpu().numpy().astype(np.float32), eo.astype(np.float32), rtol=2e-3, atol=2e-3)
