@@ -299,6 +299,18 @@ def test_rope_vs_oracle(past, n, Hq, Hkv, D):
     _close(qd2.cpu().numpy(), qe2, tol=3e-3)
 
 
+def test_rope_vs_hf_fixtures(rope_golden):
+    """HIP rope against the oracle of the reference's rope test (HF functions; make_rope_golden.py), 5e-3."""
+    qu = _qu()
+    for seed, past, n, H in rope_golden["rope_cases"]:
+        seed, past, n, H = int(seed), int(past), int(n), int(H)
+        qd = cuda(synth.normal_f16(seed * 3, (n, H, 128)))
+        kd = cuda(synth.normal_f16(seed * 3 + 1, (n, H, 128)))
+        qu.apply_rope_in_place(qd, kd, past)
+        _close(qd.cpu().numpy(), rope_golden[f"rope_q_{past}_{n}"])
+        _close(kd.cpu().numpy(), rope_golden[f"rope_k_{past}_{n}"])
+
+
 @pytest.mark.parametrize("rows,cols", [(1, 4096), (7, 4096), (3, 256), (2, 11008)])
 def test_rms_norm_vs_oracle(rows, cols):
     qu = _qu()

@@ -188,9 +188,22 @@ def test_append_decode_equals_prefill_and_extrema():
             assert np.array_equal(mn.astype(np.float32), blk.min(0))
 
 
+def test_rope_oracle_vs_hf_fixtures(rope_golden):
+    """The C restatement against the oracle of the reference's own rope test (HF LlamaRotaryEmbedding +
+    apply_rotary_pos_emb, fixtures from tests/golden/make_rope_golden.py), at the reference's tolerance
+    (test_rope.py:9-14: 5e-3)."""
+    for seed, past, n, H in rope_golden["rope_cases"]:
+        seed, past, n, H = int(seed), int(past), int(n), int(H)
+        q, k = synth.normal_f16(seed * 3, (n, H, 128)), synth.normal_f16(seed * 3 + 1, (n, H, 128))
+        oracle.rope_in_place(q, past, 1.0, 1e4)
+        oracle.rope_in_place(k, past, 1.0, 1e4)
+        _close(q, rope_golden[f"rope_q_{past}_{n}"])
+        _close(k, rope_golden[f"rope_k_{past}_{n}"])
+
+
 def test_rope_and_rmsnorm_oracle_vs_torch():
-    """No reference fixture for rope here (its oracle needs an older transformers API), so the C
-    restatement is checked against the HF rotate-half formula written out in torch fp32."""
+    """The rope restatement also against the HF rotate-half formula written out in torch fp32 (tighter than the
+    fp16-table fixtures above), and rmsnorm against numpy."""
     n, H, D, past = 9, 4, 128, 37
     x = synth.normal_f16(11, (n, H, D))
     got = x.copy()
