@@ -514,6 +514,10 @@ def main():
         idx = ctl.topk_dindices_buffer
         reps = 10
         t_att = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, idx), a.layers, reps)
+        # the dominant kernel by itself (merge launch skipped; partial states stay in the workspace)
+        ctl._decode_handler.set_skip_merge(True)
+        t_att_kernel = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, idx), a.layers, reps)
+        ctl._decode_handler.set_skip_merge(False)
         t_est = time_kernel_loop(lambda l: qu.decode_estimate(wq[l], ctl, l), a.layers, reps)
         t_topk = time_kernel_loop(lambda l: qu.decode_topk(est0[l], ctl), a.layers, reps)
         t_app = time_kernel_loop(lambda l: qu.append_kv(wk[l], wv[l], ctl, l), a.layers, reps)
@@ -522,6 +526,7 @@ def main():
                                 a.layers, reps)
         ctl.end_forward()
         ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_plus_merge_us": t_att,
+               "sparse_attn_kernel_only_us": t_att_kernel,
                "fused_append_estimate_us": t_ae, "fused_topk_sparse_attn_plus_merge_us": t_ts,
                "chain_us_in_step": ms_per_step * 1e3 / a.layers / n_local,
                "note": "per launch inside a hipGraph of 32 back-to-back launches (one per layer), "
@@ -533,7 +538,7 @@ def main():
             dense_us = time_kernel_loop(
                 lambda l: qu.decode_sparse_attn(wq[l], ctl, l, ctl.kv_indices_without_last), a.layers, 3)
             ctl.end_forward()
-        achieved = bpl["attn"] / (t_att * 1e-6) / 1e9
+        achieved = bpl["attn"] / (t_att_kernel * 1e-6) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")  # PMC bytes/launch, filled from rocprofv3 --pmc runs
         if os.path.exists(tp):
@@ -557,10 +562,12 @@ def main():
                        "sequences_per_gpu": n_local,
                        "multi_sequence": ("batched launches, shared pool" if batched else "one stream per sequence")
                        if n_local > 1 else None, "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
-            "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel + merge_states_kernel (one decode_sparse_attn op)",
+            "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel (the decode_sparse_attn op without its merge launch; "
+                                                   "op incl. merge: op_us)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att,
+                         "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att_kernel, "op_us": t_att,
+                         "op_frac": bpl["attn"] / (t_att * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}},
             "ops_us": ops,
             "ms_per_step_without_token_gather": ms_no_gather,

@@ -269,6 +269,10 @@ int quest_decode_set_batch(quest_decode_handler_t* h, uint32_t n_seqs);
 /* Introspection of the current plan (for benches/tests): pages per workgroup, workgroups per head. */
 int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_chunk,
                            uint32_t* chunks_per_head);
+/* Measurement aid: with skip != 0, quest_decode_forward* launch only the attention kernel and leave the
+ * per-workgroup partial states in the handler's workspace (the output tensor is NOT written when the plan has
+ * more than one workgroup per head).  Lets a bench time the dominant kernel by itself. */
+int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
 /* Override the planner (0 = automatic).  Used by tuning sweeps. */
 int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);
 

@@ -575,3 +575,7 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
 
     def set_pages_per_chunk(self, ppc: int) -> None:
         check(lib.quest_decode_set_pages_per_chunk(self._h, int(ppc)), "set_pages_per_chunk")
+
+    def set_skip_merge(self, skip: bool) -> None:
+        """Measurement aid: launch only the attention kernel (partial states stay unmerged, ``o`` unwritten)."""
+        check(lib.quest_decode_set_skip_merge(self._h, int(bool(skip))), "set_skip_merge")

@@ -710,6 +710,7 @@ struct quest_decode_handler {
     uint32_t shared_ppc = 0, shared_chunks = 0;  // plan of the group-shared kernel (grid.y = kv heads)
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
+    bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
 };
 
 // Workgroups the planner aims for.  One sequence: the kernel is built for 2 workgroups (8 waves) per CU,
@@ -746,6 +747,12 @@ extern "C" void quest_decode_handler_destroy(quest_decode_handler_t* h) {
 extern "C" int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t ppc) {
     if (!h) return QUEST_EINVAL;
     h->forced_ppc = ppc;
+    return 0;
+}
+
+extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) {
+    if (!h) return QUEST_EINVAL;
+    h->skip_merge = skip != 0;
     return 0;
 }
 
@@ -834,7 +841,7 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     else
         hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), lds, s, p);
     QUEST_LAUNCH_CHECK();
-    if (h->n_chunks > 1) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
+    if (h->n_chunks > 1 && !h->skip_merge) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();

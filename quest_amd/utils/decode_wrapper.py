@@ -63,3 +63,6 @@ class BatchDecodeWithPagedKVCacheWrapper:
 
     def set_pages_per_chunk(self, ppc: int) -> None:
         self._wrapper.set_pages_per_chunk(ppc)
+
+    def set_skip_merge(self, skip: bool) -> None:
+        self._wrapper.set_skip_merge(skip)
