@@ -69,7 +69,6 @@ struct DecodeParams {
     const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
     uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
-    uint32_t direct;  // fused front end: scores / page ids are fetched in ownership layout with 8/16-byte loads
 };
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
-        const uint32_t n_cap0 = p.n_scores;  // as launched: the longest row this launch may see
+        const uint32_t n_cap = p.n_scores;  // as launched: the longest row this launch may see (buffers cover it)
         if (p.state) {  // live lengths
             const quest_step_state_t st = *sv.state;
             p.n_scores = (uint32_t)(st.n_pages - 1);
@@ -202,12 +201,10 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             n_slots = p.n_sel + 1;
             slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
         }
-        const uint32_t n = p.n_scores, n_cap = n_cap0;
+        const uint32_t n = p.n_scores;
         constexpr int NT = NW * kWave;
         if (n > 0) {  // block-uniform; a one-page sequence has no row to select from (only the current page)
-            // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n), so no address
-            // below depends on the live length -- in a state-driven launch the score loads do not wait for the
-            // state load.
+            // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n).
             const uint32_t cpt = p.cpt;
             const uint32_t c0 = threadIdx.x * cpt;
             const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
@@ -217,69 +214,35 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             const bool stage_ids = p.stage_ids != 0;
             int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
             uint32_t key[FC];
-            int32_t idr[8] = {};  // direct path: page ids of the owned columns
-            const bool direct = p.direct != 0;  // block-uniform
-            if (direct) {
-                // scores and page ids straight into ownership layout: lane t reads the 8/16 (+16/32) bytes of its
-                // cpt columns, a wave reads 0.5-1 KiB contiguous -- no LDS transpose.  Chunks past the capacity
-                // re-read the last chunk (their columns are masked by c0 + i < n everywhere).
-                const uint32_t last = ((n_cap - 1) / cpt) * cpt, cb = c0 < last ? c0 : last;
-                uint32_t w[4] = {};
-                if (cpt == 8) {
-                    const uint4 k4 = *reinterpret_cast<const uint4*>(srow + cb);
-                    const int4 a = *reinterpret_cast<const int4*>(table + cb), b = *reinterpret_cast<const int4*>(table + cb + 4);
-                    w[0] = k4.x, w[1] = k4.y, w[2] = k4.z, w[3] = k4.w;
-                    idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w, idr[4] = b.x, idr[5] = b.y, idr[6] = b.z, idr[7] = b.w;
-                } else {  // cpt == 4
-                    const uint2 k2 = *reinterpret_cast<const uint2*>(srow + cb);
-                    const int4 a = *reinterpret_cast<const int4*>(table + cb);
-                    w[0] = k2.x, w[1] = k2.y;
-                    idr[0] = a.x, idr[1] = a.y, idr[2] = a.z, idr[3] = a.w;
-                }
-                topk_clear<NT>(sm);  // overlaps the loads above
-                QUEST_STAMP(1);
-                uint32_t mm = kMmNeutral;
+            // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
+            uint16_t kraw[FC];
+            int32_t iraw[FC];
 #pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    if (i < 8) {
-                        const uint32_t raw = (i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu;
-                        key[i] = half_key((uint16_t)raw);
-                        if ((uint32_t)i < cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
-                    } else {
-                        key[i] = 0;
-                    }
-                }
-                topk_publish_range<NT>(sm, mm);
-                QUEST_STAMP(2);
-            } else {
-                // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
-                uint16_t kraw[FC];
-                int32_t iraw[FC];
-#pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    const uint32_t e = threadIdx.x + i * NT, ec = e < n ? e : n - 1;  // clamped, unconditional
-                    kraw[i] = srow[ec];
-                    iraw[i] = stage_ids ? table[ec] : 0;
-                }
-                topk_clear<NT>(sm);  // overlaps the score / page-id loads above
-                QUEST_STAMP(1);
-                uint32_t mm = kMmNeutral;
-#pragma unroll
-                for (int i = 0; i < FC; ++i) {
-                    const uint32_t e = threadIdx.x + i * NT;
-                    if (e < n) {
-                        const uint32_t kk = half_key(kraw[i]);
-                        mm = pk_max_u16(mm, mm_pack(kk));
-                        keys_s[e] = (uint16_t)kk;
-                        if (stage_ids) ids_s[e] = iraw[i];
-                    }
-                }
-                topk_publish_range<NT>(sm, mm);
-                QUEST_STAMP(2);
+            for (int i = 0; i < FC; ++i) {
+                // clamped (unconditional) to the CAPACITY, not the live length: the addresses do not wait for the
+                // state load of a state-driven launch; columns in [n, n_cap) are readable and masked below
+                const uint32_t e = threadIdx.x + i * NT, ec = e < n_cap ? e : n_cap - 1;
+                kraw[i] = srow[ec];
+                iraw[i] = stage_ids ? table[ec] : 0;
             }
+            topk_clear<NT>(sm);  // overlaps the score / page-id loads above
+            QUEST_STAMP(1);
+            uint32_t mm = kMmNeutral;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const uint32_t e = threadIdx.x + i * NT;
+                if (e < n) {
+                    const uint32_t kk = half_key(kraw[i]);
+                    mm = pk_max_u16(mm, mm_pack(kk));
+                    keys_s[e] = (uint16_t)kk;
+                    if (stage_ids) ids_s[e] = iraw[i];
+                }
+            }
+            topk_publish_range<NT>(sm, mm);
+            QUEST_STAMP(2);
             __syncthreads();
             QUEST_STAMP(3);
-            if (!direct) topk_load_keys<FC>(keys_s, c0, n, cpt, key);
+            topk_load_keys<FC>(keys_s, c0, n, cpt, key);
 #ifdef QUEST_TIMELINE
             long long sub[9] = {};
             TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, sub);
@@ -301,9 +264,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                     // two separate loads: a select between an LDS and a global ADDRESS becomes one flat load
                     // whose address-space cast this compiler miscompiles (illegal v_cmp on src_shared_base)
                     int32_t pg;
-                    if (direct) {
-                        pg = idr[i & 7];
-                    } else if (stage_ids) {
+                    if (stage_ids) {
                         pg = ids_s[c0 + i];
                     } else {
                         pg = table[c0 + i];
@@ -920,7 +881,6 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     int fc = 0;
     uint32_t waves = h->dec_waves;
     p.cpt = 0;
-    p.direct = 0;
     if (fused) {
         // the selection is VALU-issue bound (~1000 instructions per wave at 8 keys per thread), so rows
         // beyond 1024 pages get 8 waves (<= 4 keys per thread up to 2048 pages, <= 8 up to 4096); the
@@ -929,17 +889,10 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
         const uint32_t per_thread = (n_scores + nt - 1) / nt;
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
-        // ownership chunk: a multiple of 4 columns when the register capacity allows, so chunks are 8/16-byte
-        // aligned units of the score row and the page table
+        // ownership chunk: a multiple of 4 columns when the register capacity allows, so a thread's keys are one
+        // 8/16-byte LDS read (topk_load_keys)
         const uint32_t r4 = (per_thread + 3) / 4 * 4;
         p.cpt = r4 <= (uint32_t)fc ? r4 : per_thread;
-        // direct (ownership-layout) loads need every chunk the launch can touch -- up to the capacity rounded
-        // to a chunk -- to be aligned, in-row and in-table, for every head and sequence
-        const uint32_t c = p.cpt, span = (n_scores + c - 1) / c * c;
-        const uint32_t table_len = batch.n_seqs > 1 ? batch.kv_table_stride : n_scores + 1;
-        const bool seq_ok = batch.n_seqs == 1 || (batch.kv_table_stride % c == 0);
-        p.direct = (c == 4 || c == 8) && (uintptr_t)scores % (c * 2) == 0 && p.score_stride % c == 0 &&
-                   span <= p.score_stride && (uintptr_t)kv.indices % (c * 4) == 0 && span <= table_len && seq_ok;
     }
     switch (kv.head_dim) {
         case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
