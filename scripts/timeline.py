@@ -37,7 +37,7 @@ est = [qu.decode_estimate(w.q[l], ctl, l) for l in range(a.layers)]
 names = ["entry", "loads issued+hist cleared", "scores arrived, keys in LDS", "barrier", "topk_select done",
          "page list in LDS (barrier)", "all K/V folded", "row butterfly + LDS write", "barrier", "partial written"]
 h = ctl._decode_handler._wrapper
-# state-driven twin of the same sequence (direct ownership-layout loads apply there: padded score rows)
+# state-driven twin of the same sequence (8-wave workgroups, lengths from the device state)
 a2 = bench.parse()
 a2.mode, a2.layers = "graph", a.layers
 w2 = bench.Workload(a2, dev)
