@@ -198,6 +198,7 @@ def test_batched_dense_layer_matches_single_sequence():
         assert torch.equal(got, torch.cat(ref)), f"token {t}"
 
 
+@pytest.mark.skipif(os.environ.get("QUEST_TORCH_CHECK") == "0", reason="argument validation is switched off")
 def test_batched_argument_errors():
     import quest_amd.utils as qu
     from quest_amd import _kernels
