@@ -41,12 +41,17 @@ namespace quest {
 constexpr float kNegFloor = -1.0e30f;  // finite "-inf": exp2(floor - floor) stays finite, weights it carries are 0
 
 struct DecodeParams {
+    // The pointers come first: with -amdgpu-kernarg-preload-count=16 (build.py) the first 16 kernarg dwords
+    // arrive in SGPRs at wave launch, so the first loads of a workgroup do not wait for a scalar load of the
+    // argument block (0.3 us per launch on the fused kernel).
     const half_t* q;
-    half_t* o;
-    float* lse;
     const half_t* kv;
     const int32_t* indices;
-    float* ws;  // [Hq][n_chunks][D + 2] fp32 partial (acc[D], m, d)
+    const uint16_t* scores;           // fused front end: [Hq][n_scores] fp16 estimate output
+    const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
+    half_t* o;
+    float* ws;  // [Hq][n_chunks][ws_stride] fp32 partial (acc[D], m, d)
+    float* lse;
     PoolStrides st;
     uint32_t idx_stride;
     uint32_t n_sel;
@@ -58,7 +63,6 @@ struct DecodeParams {
     uint32_t n_chunks;
     float scale_log2;  // 1/sqrt(D) * log2(e)
     // fused top-k front end (FC > 0): `indices` is then the sequence's page table [n_scores + 1]
-    const uint16_t* scores;  // [Hq][n_scores] fp16 estimate output
     uint32_t n_scores;
     uint16_t* sel_val_out;   // optional [Hq][n_sel]
     int32_t* sel_idx_out;    // optional [Hq][n_sel]
@@ -66,7 +70,6 @@ struct DecodeParams {
     uint32_t score_stride;  // row stride of `scores`
     uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
     uint32_t ids_lds_offset;
-    const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
     uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
 };
