@@ -195,28 +195,37 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
     __syncthreads();
     QUEST_SUBSTAMP(4);
     const uint32_t thr_bin = sm.misc[0];
-#pragma unroll
-    for (int i = 0; i < C; ++i)
-        if ((uint32_t)i < cpt && c0 + i < n && ((key[i] - kmin) >> shift) == thr_bin)
-            atomicAdd(&sm.hist2[(key[i] - kmin) & low_mask], 1u);
-    __syncthreads();
-    QUEST_SUBSTAMP(5);
-
-    if (tid < kWave) {  // wave 0: lane l looks at low digit 31-l, suffix sums by shuffle
-        const uint32_t above0 = sm.misc[1];
-        const uint32_t cnt = tid < kBins2 ? sm.hist2[kBins2 - 1 - tid] : 0u;
-        const uint32_t incl = wave_scan_incl_dpp(cnt);
-        const uint32_t excl = incl - cnt;
-        if (tid < kBins2 && above0 + excl < k && k <= above0 + incl) {
-            sm.misc[2] = kmin + ((thr_bin << shift) | (kBins2 - 1 - tid));
-            sm.misc[3] = k - (above0 + excl);
-        }
-    }
-    __syncthreads();
-    QUEST_SUBSTAMP(6);
     TopkCursor cur;
-    cur.T = sm.misc[2];
-    cur.need = sm.misc[3];
+    if (shift == 0) {
+        // the row's keys span fewer than 2048 values (the usual case: one binade of fp16 scores is 1024 keys):
+        // a bin IS a key value, so the threshold bin is T itself -- no second histogram, two barriers less
+        cur.T = kmin + thr_bin;
+        cur.need = k - sm.misc[1];
+        QUEST_SUBSTAMP(5);
+        QUEST_SUBSTAMP(6);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+            if ((uint32_t)i < cpt && c0 + i < n && ((key[i] - kmin) >> shift) == thr_bin)
+                atomicAdd(&sm.hist2[(key[i] - kmin) & low_mask], 1u);
+        __syncthreads();
+        QUEST_SUBSTAMP(5);
+
+        if (tid < kWave) {  // wave 0: lane l looks at low digit 31-l, suffix sums by shuffle
+            const uint32_t above0 = sm.misc[1];
+            const uint32_t cnt = tid < kBins2 ? sm.hist2[kBins2 - 1 - tid] : 0u;
+            const uint32_t incl = wave_scan_incl_dpp(cnt);
+            const uint32_t excl = incl - cnt;
+            if (tid < kBins2 && above0 + excl < k && k <= above0 + incl) {
+                sm.misc[2] = kmin + ((thr_bin << shift) | (kBins2 - 1 - tid));
+                sm.misc[3] = k - (above0 + excl);
+            }
+        }
+        __syncthreads();
+        QUEST_SUBSTAMP(6);
+        cur.T = sm.misc[2];
+        cur.need = sm.misc[3];
+    }
 
     uint32_t gt = 0, eq = 0;
 #pragma unroll
