@@ -220,13 +220,20 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
             uint16_t kraw[FC];
             int32_t iraw[FC];
+            // FC is the power-of-two register capacity; only the first ceil(n_cap / NT) rounds hold columns
+            // (5 of 8 at 2058 pages x 512 threads): the rest are skipped by a wave-uniform test
+            const uint32_t rounds = (n_cap + NT - 1) / NT;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
-                // clamped (unconditional) to the CAPACITY, not the live length: the addresses do not wait for the
-                // state load of a state-driven launch; columns in [n, n_cap) are readable and masked below
-                const uint32_t e = threadIdx.x + i * NT, ec = e < n_cap ? e : n_cap - 1;
-                kraw[i] = srow[ec];
-                iraw[i] = stage_ids ? table[ec] : 0;
+                kraw[i] = 0;
+                iraw[i] = 0;
+                if ((uint32_t)i < rounds) {
+                    // clamped (unconditional) to the CAPACITY, not the live length: the addresses do not wait for
+                    // the state load of a state-driven launch; columns in [n, n_cap) are readable and masked below
+                    const uint32_t e = threadIdx.x + i * NT, ec = e < n_cap ? e : n_cap - 1;
+                    kraw[i] = srow[ec];
+                    iraw[i] = stage_ids ? table[ec] : 0;
+                }
             }
             topk_clear<NT>(sm);  // overlaps the score / page-id loads above
             QUEST_STAMP(1);
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
                 const uint32_t e = threadIdx.x + i * NT;
-                if (e < n) {
+                if ((uint32_t)i < rounds && e < n) {
                     const uint32_t kk = half_key(kraw[i]);
                     mm = pk_max_u16(mm, mm_pack(kk));
                     keys_s[e] = (uint16_t)kk;
