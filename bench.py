@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--cpu-sample-s", type=float, default=12.0)
+    ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic K/V/q (SURVEY 8d: seeds 0, 1, 2)")
     return ap.parse_args()
 
 
@@ -83,7 +84,7 @@ class Workload:
                                           L + 2 * a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,  # 2x: the N > 1 no-gather rerun
                                           num_kv_heads=a.kv_heads,
                                           layout=a.layout, shuffle_seed=1234)
-        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id)
+        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id + 7919 * a.seed)
         ctl = self.ctl
         # prefill L-1 tokens (device-side append with fused min/max metadata), then one decode token
         ctl.prepare_metadata(L - 1)
@@ -171,7 +172,7 @@ class BatchedWorkload:
                                                  num_kv_heads=a.kv_heads, layout=a.layout, shuffle_seed=1234)
         kbuf = torch.empty(L - 1, a.kv_heads, a.head_dim, dtype=torch.float16, device=dev)
         vbuf = torch.empty_like(kbuf)
-        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id0)
+        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id0 + 7919 * a.seed)
         for c in self.ctl.seqs:
             c.prepare_metadata(L - 1)
             c.begin_forward(L - 1)
@@ -556,7 +557,7 @@ def main():
                        "layers": a.layers, "num_qo_heads": a.heads, "num_kv_heads": a.kv_heads,
                        "head_dim": a.head_dim, "seqlen": a.seqlen, "seqlen_after_run": ctl.kv_cache.seqlen, "page_size": a.page_size,
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
-                       "kv_layout": a.layout, "mode": a.mode, "skip_layers": a.skip_layers,
+                       "kv_layout": a.layout, "mode": a.mode, "seed": a.seed, "skip_layers": a.skip_layers,
                        "launches_per_layer": "5 (reference op sequence)" if a.unfused else
                        "3 (append+estimate | top-k+sparse attn | merge)",
                        "sequences_per_gpu": n_local,
