@@ -3,45 +3,65 @@
 at BASELINE.json's metric point -- Yarn-Llama-2-7B shapes (32 layers, 32 heads, D=128, fp16),
 seqlen 32768, token budget 2048 = 128 pages of 16 -- on N GPUs of one node.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config {2,3,4,5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
-A "step" is one decode token of one sequence per GPU: the four-operator chain run for every
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment makes this process a LAUNCHER: it starts N
+fresh rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), never touches
+the GPU itself, and relays rank 0's JSON line.  Under torchrun (WORLD_SIZE set) it is a rank.
+
+A "step" is one decode token of every sequence of every GPU: the four-operator chain run for every
 layer of the model against that layer's own KV / metadata pools (so consecutive kernels touch
 different memory and the 256 MiB Infinity Cache cannot hold the working set).  Everything goes
 through the C ABI of libquest_hip.so; tokens/s is attention-only (no weights offline).
 Sequences are independent, so GPUs never exchange data inside a step; with N > 1 each step ends
-with one RCCL all_gather of the sampled token ids (weak scaling: one sequence per GPU).
+with one RCCL all_gather of the sampled token ids (weak scaling: the same sequences per GPU).
 
-One JSON line on stdout (rank 0).  Extra objects: "roofline" (dominant kernel: sparse paged decode
-attention, algorithmic bytes / HIP-event launch time) and "cpu_baseline" (oracle/torch_ref eager
-port timed on the host cores, bounded sample).
+One JSON line on stdout (rank 0).  Extra objects: "roofline" (the dominant kernel OF THE TIMED STEP:
+sparse_decode_kernel with its top-k front end; algorithmic bytes / HIP-event launch time) and
+"cpu_baseline" (oracle/torch_ref eager port timed on the host cores, bounded sample).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
+# SURVEY.md 8 "BASELINE configs -> concrete sizes" (cfg n = BASELINE.json configs[n-1]); budgets in TOKENS here
+CONFIGS = {
+    2: dict(label="BASELINE configs[1]: LongChat-7B-v1.5-32K shapes (page budget 512 >= 256 pages: full KV)",
+            layers=32, heads=32, kv_heads=32, seqlen=4096, token_budget=512 * 16, seqs_per_gpu=1),
+    3: dict(label="BASELINE configs[2]: Yarn-Llama-2-7B-128K shapes", layers=32, heads=32, kv_heads=32, seqlen=32768,
+            token_budget=2048, seqs_per_gpu=1),
+    4: dict(label="BASELINE configs[3]: Llama-3.1-8B-Instruct (GQA) shapes", layers=32, heads=32, kv_heads=8,
+            seqlen=131072, token_budget=4096, seqs_per_gpu=1),
+    5: dict(label="BASELINE configs[4]: Llama-3.1-8B (GQA) shapes, 64 x 32K sequences sharded 8 per GPU", layers=32,
+            heads=32, kv_heads=8, seqlen=32768, token_budget=2048, seqs_per_gpu=8),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--layers", type=int, default=32)
-    ap.add_argument("--heads", type=int, default=32)
-    ap.add_argument("--kv-heads", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=1000,
+                    help="timed decode tokens per sequence (default: ~1 s of timed region at the headline config)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
+                    help="SURVEY cfg number: 3 = BASELINE configs[2] (headline), 4 = 128K GQA, 5 = 8 x 32K GQA per GPU, "
+                         "2 = 4K full-KV; the shape flags below override single fields")
+    ap.add_argument("--layers", type=int)
+    ap.add_argument("--heads", type=int)
+    ap.add_argument("--kv-heads", type=int)
     ap.add_argument("--head-dim", type=int, default=128)
-    ap.add_argument("--seqlen", type=int, default=32768)
-    ap.add_argument("--token-budget", type=int, default=2048)
+    ap.add_argument("--seqlen", type=int)
+    ap.add_argument("--token-budget", type=int)
     ap.add_argument("--page-size", type=int, default=16)
     ap.add_argument("--layout", choices=["NHD", "HND"], default="NHD")
     ap.add_argument("--mode", choices=["graph", "graph-static", "eager"], default="graph",
@@ -53,38 +73,79 @@ def parse():
     ap.add_argument("--unfused", action="store_true",
                     help="issue the reference's five launches per layer instead of the fused append+estimate and "
                          "top-k+attention launches (same results)")
-    ap.add_argument("--seqs-per-gpu", type=int, default=1,
-                    help="independent sequences per GPU (BASELINE configs[4] uses 8); each runs its chain on its "
-                         "own HIP stream inside the step graph so their latency phases overlap")
-    ap.add_argument("--multi-seq-mode", choices=["batched", "streams"], default="batched",
-                    help="with --seqs-per-gpu > 1: batched = ONE launch per op for all sequences over a shared pool "
-                         "(grid.z = sequence, quest_*_batched); streams = one chain per sequence on its own stream")
+    ap.add_argument("--seqs-per-gpu", type=int,
+                    help="independent sequences per GPU (config 5 uses 8), decoded with ONE launch per op over a "
+                         "shared pool (grid.z = sequence) unless --multi-seq-mode streams")
+    ap.add_argument("--multi-seq-mode", choices=["batched", "streams"], default="batched")
     ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
-    ap.add_argument("--no-multi-seq", action="store_true",
-                    help="skip the side measurement with 8 sequences per GPU (BASELINE configs[4]'s per-GPU load)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
-    ap.add_argument("--cpu-sample-s", type=float, default=12.0)
+    ap.add_argument("--cpu-sample-s", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic K/V/q (SURVEY 8d: seeds 0, 1, 2)")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    preset = CONFIGS[a.config]
+    custom = []
+    for key in ("layers", "heads", "kv_heads", "seqlen", "token_budget", "seqs_per_gpu"):
+        if getattr(a, key) is None:
+            setattr(a, key, preset[key])
+        elif getattr(a, key) != preset[key]:
+            custom.append(f"{key}={getattr(a, key)}")
+    a.workload_label = preset["label"] if not custom else f"custom ({preset['label']} with {', '.join(custom)})"
+    return a
 
+
+# ------------------------------------------------------------------------------------------------ launcher
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Start n rank processes of this script and relay rank 0's stdout.  The launcher never initialises the
+    GPU (no torch.cuda / HIP call) and no process that has done so is ever re-exec'd: every rank is a fresh
+    child.  Returns the exit code (non-zero if any rank failed)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ workloads
 
 class Workload:
     """One sequence: controller + filled pools + per-layer decode inputs."""
 
     def __init__(self, a, dev, seq_id=0):
+        import torch
         import quest_amd.utils as qu
 
         self.qu = qu
         self.a = a
         self.dev = dev
+        self.n = 1
         self.page_budget = a.token_budget // a.page_size
         L = a.seqlen
-        self.ctl = qu.InferenceController(a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
-                                          L + 2 * a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,  # 2x: the N > 1 no-gather rerun
-                                          num_kv_heads=a.kv_heads,
-                                          layout=a.layout, shuffle_seed=1234)
-        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id + 7919 * a.seed)
+        cap_tokens = L + 2 * a.steps + a.warmup + 4 * a.page_size  # 2x: the N > 1 no-gather rerun
+        self.ctl = qu.InferenceController(a.layers, a.heads, a.head_dim, a.page_size, self.page_budget, cap_tokens,
+                                          torch.float16, dev, num_kv_heads=a.kv_heads, layout=a.layout,
+                                          shuffle_seed=1234)
+        self.gen_seed = 1000 + dev.index + 97 * seq_id + 7919 * a.seed
+        g = torch.Generator(device=dev).manual_seed(self.gen_seed)
         ctl = self.ctl
         # prefill L-1 tokens (device-side append with fused min/max metadata), then one decode token
         ctl.prepare_metadata(L - 1)
@@ -101,11 +162,15 @@ class Workload:
         self.k1 = torch.randn(a.layers, 1, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
         self.v1 = torch.randn(a.layers, 1, a.kv_heads, a.head_dim, generator=g, device=dev, dtype=torch.float16)
         self.outs = [None] * a.layers
+        n_pages_end = (cap_tokens + a.page_size - 1) // a.page_size
+        self.dense = self.page_budget >= n_pages_end  # budget covers the cache for the whole run: full-KV decode
         self.dyn = a.mode == "graph" and a.skip_layers == 0 and not a.unfused
         if self.dyn:
             # state-driven stepping: the graph's first node reserves the token on the device
             ctl.enable_device_state()
-            ctl.begin_graph_decode()
+            if a.pages_per_chunk:
+                ctl._decode_handler.set_pages_per_chunk(a.pages_per_chunk)
+            ctl.begin_graph_decode(dense_layers=self.dense)
             self.scores = torch.empty(a.heads, ctl.max_pages, dtype=torch.float16, device=dev)
         else:
             ctl.prepare_metadata(1)
@@ -115,12 +180,19 @@ class Workload:
         qu, ctl, a = self.qu, self.ctl, self.a
         qu.step_advance_dyn(ctl)
         for layer in range(a.layers):
-            self.outs[layer] = qu.decode_layer_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer,
-                                                   self.scores)
+            if self.dense:
+                self.outs[layer] = qu.decode_layer_dense_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer)
+            else:
+                self.outs[layer] = qu.decode_layer_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer,
+                                                       self.scores)
 
     def after_replay(self):
         if self.dyn:
             self.ctl.prepare_metadata(1)  # host mirror of the device-side reservation (Python ints only)
+
+    def sync(self):
+        if self.dyn:
+            self.ctl.sync_device_state()
 
     def step(self):
         """One decode token: llama.py:424-439 controller sequence + QuestAttention.py:99-157 per layer."""
@@ -128,12 +200,8 @@ class Workload:
             return self.step_dyn()
         qu, ctl, a = self.qu, self.ctl, self.a
         skip = a.skip_layers
-        if skip > 0:
-            ctl.set_page_budget(1 << 20)
-            ctl.begin_forward(1)
-        else:
-            ctl.set_page_budget(self.page_budget)
-            ctl.begin_forward(1)
+        ctl.set_page_budget(1 << 20 if skip > 0 else self.page_budget)
+        ctl.begin_forward(1)
         for layer in range(a.layers):
             if skip > 0 and layer == skip:
                 ctl.end_forward()
@@ -160,19 +228,22 @@ class BatchedWorkload:
     """n sequences sharing one pool, decoded with one launch per op (quest_amd.utils.*_batched)."""
 
     dyn = True
+    dense = False
 
     def __init__(self, a, dev, n_seqs, seq_id0=0):
+        import torch
         import quest_amd.utils as qu
 
         self.qu, self.a, self.dev, self.n = qu, a, dev, n_seqs
         self.page_budget = a.token_budget // a.page_size
         L = a.seqlen
         self.ctl = qu.BatchedInferenceController(n_seqs, a.layers, a.heads, a.head_dim, a.page_size, self.page_budget,
-                                                 L + 2 * a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,  # 2x: the N > 1 no-gather rerun
+                                                 L + 2 * a.steps + a.warmup + 4 * a.page_size, torch.float16, dev,
                                                  num_kv_heads=a.kv_heads, layout=a.layout, shuffle_seed=1234)
         kbuf = torch.empty(L - 1, a.kv_heads, a.head_dim, dtype=torch.float16, device=dev)
         vbuf = torch.empty_like(kbuf)
-        g = torch.Generator(device=dev).manual_seed(1000 + dev.index + 97 * seq_id0 + 7919 * a.seed)
+        self.gen_seed = 1000 + dev.index + 97 * seq_id0 + 7919 * a.seed
+        g = torch.Generator(device=dev).manual_seed(self.gen_seed)
         for c in self.ctl.seqs:
             c.prepare_metadata(L - 1)
             c.begin_forward(L - 1)
@@ -206,8 +277,32 @@ class BatchedWorkload:
         self.ctl.sync_device_state()
 
 
+class StubWorkload:
+    """QUEST_BENCH_STUB=1: no GPU, no kernels -- a trivial CPU step, so that the launcher, the rendezvous, the
+    per-step token gather, the max-over-ranks timing and the JSON contract can be exercised on a CPU-only
+    box (tests/test_parallel_gloo.py).  The line it produces is marked "data": "stub" and measures nothing."""
+
+    dyn = False
+    dense = False
+
+    def __init__(self, a):
+        import torch
+
+        self.n = a.seqs_per_gpu
+        self.x = torch.zeros(16)
+
+    def step(self):
+        self.x += 1
+
+    def after_replay(self):
+        pass
+
+    def sync(self):
+        pass
+
+
 def bytes_per_layer(a):
-    """Algorithmic bytes of one layer-step, SURVEY.md 8(d) accounting (= the reference benches')."""
+    """Algorithmic bytes of one layer-step of ONE sequence, SURVEY.md 8(d) accounting (= the reference benches')."""
     S, D, Hq, Hkv = a.page_size, a.head_dim, a.heads, a.kv_heads
     N = (a.seqlen + S - 1) // S
     B = min(a.token_budget // S, N)
@@ -216,7 +311,10 @@ def bytes_per_layer(a):
     topk = Hq * (N - 1) * (2 + 4) + Hq * (B - 1) * (2 + 4)
     att = B * S * 2 * Hq * D * 2 + Hq * D * 2 + Hq * (B - 1) * 4 + Hq * D * 2
     dense = N * S * 2 * Hkv * D * 2 + Hq * D * 2 + Hq * (N - 1) * 4 + Hq * D * 2  # every kv head read once
-    return {"append": app, "estimate": est, "topk": topk, "attn": att, "chain": app + est + topk + att, "dense": dense}
+    sparse = B < N
+    chain = app + est + topk + att if sparse else app + dense
+    return {"append": app, "estimate": est, "topk": topk, "attn": att, "chain": chain, "dense": dense,
+            "pages": N, "budget_pages": B, "sparse": sparse}
 
 
 def time_kernel_loop(fn, layers, reps):
@@ -224,6 +322,8 @@ def time_kernel_loop(fn, layers, reps):
     every launch reads a different pool) are captured into a hipGraph on torch's current stream -- the
     stream the kernels are launched on -- and `reps` replays are bracketed by two HIP events.  The
     figure includes the dependent-launch boundary (~1.5 us), i.e. what the op costs inside a step."""
+    import torch
+
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -247,178 +347,207 @@ def time_kernel_loop(fn, layers, reps):
     return e0.elapsed_time(e1) * 1e3 / (reps * layers)  # us
 
 
-def batched_op_times(bw, bpl):
-    """HIP-event time of the two batched launches of a layer (graph of one launch per layer, as in
-    time_kernel_loop) and the HBM figures they amount to."""
+def step_op_times(w, a, bpl, reps=10):
+    """HIP-event time of the launches the timed step is made of, each as a graph of one launch per layer
+    on the stream the kernels are launched on, reading the same device-resident state as the step.
+    Returns (ops dict, roofline dict).  The roofline describes the DOMINANT kernel of the step."""
     from quest_amd import _kernels
 
-    b, n = bw.ctl, bw.n
-    max_n = b.max_pages - 1
+    n = w.n
+    if isinstance(w, BatchedWorkload):
+        b = w.ctl
+        max_n = b.max_pages - 1
+        handler = b._decode_handler
 
-    def ae(l):
-        _kernels.append_estimate_batched(bw.k1[l], bw.v1[l], b.kv_layer(l), b.kv_tables, bw.q[l], bw.scores,
-                                         b.metadata_layer(l), b.meta_tables, b.step_states, max_n, b.layout)
+        def ae(l):
+            _kernels.append_estimate_batched(w.k1[l], w.v1[l], b.kv_layer(l), b.kv_tables, w.q[l], w.scores,
+                                             b.metadata_layer(l), b.meta_tables, b.step_states, max_n, b.layout)
 
-    def ts(l):
-        b._decode_handler.forward_fused_topk_batched(bw.q[l], bw.o[l], b.kv_layer(l), b.kv_tables, bw.scores,
-                                                     b.step_states, max_n)
-
-    t_ae = time_kernel_loop(ae, bw.a.layers, 10)
-    t_ts = time_kernel_loop(ts, bw.a.layers, 10)
-    ppc, chunks = b._decode_handler.plan_info()
-    # full-KV decode of the same batch in one launch (group-shared kernel over every page of every sequence)
-    b.begin_graph_decode(dense_layers=True)
-
-    def dense(l):
-        b._dense_handler.forward_shared_batched(bw.q[l], bw.o[l], b.kv_layer(l), b.kv_tables, b.step_states)
-
-    t_dense = time_kernel_loop(dense, bw.a.layers, 3)
-    return {"batched_append_estimate_us": t_ae, "batched_topk_sparse_attn_us": t_ts,
-            "batched_dense_full_kv_us": t_dense, "batched_dense_full_kv_us_per_sequence": t_dense / n,
-            "batched_dense_gbs": n * bpl["dense"] / (t_dense * 1e-6) / 1e9,
-            "speedup_vs_batched_dense": t_dense / (t_ae + t_ts),
-            "batched_append_estimate_gbs": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9,
-            "batched_topk_sparse_attn_gbs": n * (bpl["topk"] + bpl["attn"]) / (t_ts * 1e-6) / 1e9,
-            "batched_sparse_attn_frac_of_hbm_peak": n * bpl["attn"] / (t_ts * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}}
-
-
-def multi_seq_side_measurement(a, dev, bpl, dense_us, n_seqs=8, layers=8, mode="batched"):
-    """Side figure (not `value`): the same chain with 8 independent sequences on one GPU -- the per-GPU load
-    of BASELINE configs[4].  batched: one launch per op serves all sequences (shared pool, grid.z = sequence);
-    streams: each sequence's chain on its own stream inside one step graph.  Either way the fixed latencies
-    of one sequence's kernels overlap the data movement of another's.  8 layers per sequence keep it short."""
-    import copy
-
-    b = copy.copy(a)
-    b.layers, b.steps, b.warmup = layers, 30, 5
-    if mode == "batched":
-        b.mode = "graph"
-        bw = BatchedWorkload(b, dev, n_seqs, 100)
-        ws = [bw]
-
-        def step_all():
-            bw.step()
+        def ts(l):
+            handler.forward_fused_topk_batched(w.q[l], w.o[l], b.kv_layer(l), b.kv_tables, w.scores, b.step_states, max_n)
     else:
-        b.mode = "graph-static"
-        ws = [Workload(b, dev, 100 + i) for i in range(n_seqs)]
-        streams = [torch.cuda.Stream() for _ in ws]
+        ctl = w.ctl
+        max_n = ctl.max_pages - 1
+        handler = ctl._decode_handler
+        o = [w.q[l].clone() for l in range(a.layers)]
 
-        def step_all():
-            cur = torch.cuda.current_stream()
-            for st, wl in zip(streams, ws):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    wl.step()
-            for st in streams:
-                cur.wait_stream(st)
+        def ae(l):
+            _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
+                                         ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n,
+                                         ctl.layout)
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        step_all()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    if mode == "batched":
-        bw.sync()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        step_all()
+        def ts(l):
+            handler.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores,
+                                           ctl.step_state, max_n)
 
-    def replay():
-        g.replay()
-        if mode == "batched":
-            bw.after_replay()
-
-    for _ in range(b.warmup):
-        replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(b.steps):
-        replay()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    us = el * 1e6 / b.steps / layers / n_seqs
-    res = {"sequences": n_seqs, "layers_per_sequence": layers, "mode": mode, "us_per_sequence_layer": us,
-           "chain_frac_of_hbm_peak": bpl["chain"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           # a step of the full model yields n_seqs tokens in us * model_layers * n_seqs microseconds
-           "tokens_per_s_scaled_to_model_layers": 1.0 / (us * 1e-6 * a.layers)}
-    if dense_us is not None:
-        res["speedup_vs_dense"] = dense_us / us
-    if mode == "batched":
-        res.update(batched_op_times(bw, bpl))
-    del ws, g
-    torch.cuda.empty_cache()
-    return res
+    ppc, chunks = handler.plan_info()
+    t_ae = time_kernel_loop(ae, a.layers, reps)
+    t_ts = time_kernel_loop(ts, a.layers, reps)
+    handler.set_skip_merge(True)  # the attention kernel by itself (partial states stay in the workspace)
+    t_ts_kernel = time_kernel_loop(ts, a.layers, reps)
+    handler.set_skip_merge(False)
+    alg = n * (bpl["attn"] + bpl["topk"])
+    achieved = alg / (t_ts_kernel * 1e-6) / 1e9
+    waves = 8 if (a.page_size == 16 and max_n > 1024) or os.environ.get("QUEST_DEC_WAVES") == "8" else 4
+    fc = max(8, 1 << (max(1, -(-max_n // (waves * 64))) - 1).bit_length())
+    ops = {"append_estimate_us": t_ae, "topk_sparse_attn_plus_merge_us": t_ts, "topk_sparse_attn_kernel_only_us": t_ts_kernel,
+           "append_estimate_gbs": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9,
+           "append_estimate_frac_of_hbm_peak": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "note": "per launch inside a hipGraph of one launch per layer (each on its own pool), dependent-launch "
+                   "boundary included; state-driven entry points = the launches of the timed step"}
+    roof = {"bound": "hbm",
+            "kernel": f"sparse_decode_kernel<{a.head_dim},{a.page_size if a.page_size == 16 else 0},{fc},{waves}> (top-k front "
+                      "end + gather of the selected K/V pages; the dominant kernel of the timed step, merge launch excluded)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg, "launch_us": t_ts_kernel, "sequences_per_launch": n,
+            "op_us_with_merge": t_ts, "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}}
+    if isinstance(w, BatchedWorkload) and not a.no_dense:
+        # full-KV decode of the same batch in one launch (group-shared kernel over every page of every sequence)
+        b.begin_graph_decode(dense_layers=True)
+        t_dense = time_kernel_loop(lambda l: b._dense_handler.forward_shared_batched(w.q[l], w.o[l], b.kv_layer(l),
+                                                                                      b.kv_tables, b.step_states),
+                                   a.layers, 3)
+        ops.update({"batched_dense_full_kv_us": t_dense, "batched_dense_full_kv_us_per_sequence": t_dense / n,
+                    "batched_dense_gbs": n * bpl["dense"] / (t_dense * 1e-6) / 1e9,
+                    "speedup_vs_batched_dense_ops": t_dense / (t_ae + t_ts)})
+    return ops, roof
 
 
-def cpu_baseline(a, budget_s):
-    """The eager-PyTorch port of the reference's CPU-runnable oracle, on the host cores."""
+def reference_op_times(w, a, bpl, reps=10):
+    """Side figures: the reference's five-op sequence (and the two fused launches) on ONE sequence through the
+    host-planned entry points, plus the full-KV (dense) decode the speed-up is quoted against."""
+    import torch
+
+    qu = w.qu
+    batched = isinstance(w, BatchedWorkload)
+    ctl = w.ctl.seqs[0] if batched else w.ctl
+    wq = [w.q[l][:1] for l in range(a.layers)] if batched else [w.q[l] for l in range(a.layers)]
+    wk = [w.k1[l][:1] for l in range(a.layers)] if batched else [w.k1[l] for l in range(a.layers)]
+    wv = [w.v1[l][:1] for l in range(a.layers)] if batched else [w.v1[l] for l in range(a.layers)]
+    ops = {}
+    if w.dyn:
+        ctl.end_forward()
+    if bpl["sparse"]:
+        ctl.set_page_budget(w.page_budget)
+        ctl.begin_forward(1)
+        est0 = [qu.decode_estimate(wq[l], ctl, l) for l in range(a.layers)]
+        for l in range(a.layers):
+            qu.decode_topk(est0[l], ctl)
+        idx = ctl.topk_dindices_buffer
+        h = ctl._decode_handler
+        ops["sparse_attn_plus_merge_us"] = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, idx), a.layers, reps)
+        h.set_skip_merge(True)
+        t_k = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, idx), a.layers, reps)
+        h.set_skip_merge(False)
+        ops["sparse_attn_kernel_only_us"] = t_k  # the index-tensor instantiation (no front end): NOT on the timed path
+        ops["sparse_attn_kernel_only_frac_of_hbm_peak"] = bpl["attn"] / (t_k * 1e-6) / 1e9 / HBM_PEAK_GBS
+        ops["estimate_us"] = time_kernel_loop(lambda l: qu.decode_estimate(wq[l], ctl, l), a.layers, reps)
+        ops["topk_us"] = time_kernel_loop(lambda l: qu.decode_topk(est0[l], ctl), a.layers, reps)
+        ops["append_us"] = time_kernel_loop(lambda l: qu.append_kv(wk[l], wv[l], ctl, l), a.layers, reps)
+        ctl.end_forward()
+    dense_us = None
+    if not a.no_dense:
+        ctl.set_page_budget(1 << 20)
+        ctl.begin_forward(1, updateTensor=not bpl["sparse"])
+        dense_us = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, ctl.kv_indices_without_last),
+                                    a.layers, 3)
+        ctl.end_forward()
+    ops["note"] = ("reference op sequence on one sequence, host-planned entry points; per launch inside a hipGraph of "
+                   "one launch per layer, dependent-launch boundary included")
+    return ops, dense_us
+
+
+def cpu_baseline(a, w, budget_s):
+    """The eager-PyTorch port of the reference's CPU-runnable oracle on the host cores, on the GPU run's own
+    layer-0 inputs of the first sequence (regenerated from the workload's seed, copied to the host): one
+    warm-up, then the median of >= 5 runs within the time budget."""
+    import torch
     from oracle import torch_ref
 
-    torch.manual_seed(0)
-    L, H, D = a.seqlen, a.heads, a.head_dim
-    q = torch.randn(1, H, D).half()
-    k = torch.randn(L, H, D).half()
-    v = torch.randn(L, H, D).half()
+    L = a.seqlen
+    g = torch.Generator(device=w.dev).manual_seed(w.gen_seed)
+    kd = torch.empty(L - 1, a.kv_heads, a.head_dim, dtype=torch.float16, device=w.dev).normal_(generator=g)
+    vd = torch.empty_like(kd).normal_(generator=g)  # same draw order as the workload's layer 0
+    batched = isinstance(w, BatchedWorkload)
+    k = torch.cat([kd, (w.k1[0][:1] if batched else w.k1[0]).reshape(1, a.kv_heads, a.head_dim)]).cpu()
+    v = torch.cat([vd, (w.v1[0][:1] if batched else w.v1[0]).reshape(1, a.kv_heads, a.head_dim)]).cpu()
+    q = (w.q[0][:1] if batched else w.q[0]).reshape(1, a.heads, a.head_dim).cpu()
+    del kd, vd
+    G = a.heads // a.kv_heads
+    if G > 1:  # the eager oracle is written for expanded K/V (evaluation/quest_attention.py:139-184 repeat_kv)
+        k, v = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
     B = a.token_budget // a.page_size
+    times = []
     with torch.inference_mode():
         torch_ref.sparse_decode(q, k, v, a.page_size, B)  # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while True:
+        t_begin = time.perf_counter()
+        while len(times) < 5 or (time.perf_counter() - t_begin < budget_s and len(times) < 64):
+            t0 = time.perf_counter()
             torch_ref.sparse_decode(q, k, v, a.page_size, B)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 64:
-                break
-    per_layer = el / n
+            times.append(time.perf_counter() - t0)
+    per_layer = statistics.median(times)
     return {"value": 1.0 / (per_layer * a.layers), "unit": "tokens/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{n} layer-steps of oracle.torch_ref.sparse_decode (eager fp16 CPU, L={L}, budget {B} pages, "
-                      f"H={H}); {per_layer * 1e3:.0f} ms per layer-step, scaled to {a.layers} layers"}
+            "sample": f"median of {len(times)} layer-steps (after 1 warm-up) of oracle.torch_ref.sparse_decode on the GPU "
+                      f"run's layer-0 inputs (eager fp16 CPU, L={L}, budget {B} pages, Hq={a.heads}, Hkv={a.kv_heads}); "
+                      f"{per_layer * 1e3:.0f} ms per layer-step, scaled to {a.layers} layers, one sequence"}
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus))
+
+    import torch
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = os.environ.get("QUEST_BENCH_STUB") == "1"
+    rehearse = os.environ.get("QUEST_BENCH_REHEARSE") == "1" or stub
     if world > 1 or os.environ.get("QUEST_BENCH_FORCE_DIST") == "1":  # the latter: rehearse the RCCL path on 1 GPU
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("QUEST_BENCH_REHEARSE") == "1":
-            # rehearsal of the N > 1 control flow on a ONE-GPU box: all ranks share cuda:0, gloo collectives
+        if rehearse:
+            # rehearsal of the N > 1 control flow on a ONE-GPU (or, with the stub, CPU-only) box: gloo collectives
             local = 0
-            torch.cuda.set_device(0)
+            if not stub:
+                torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        world_seen = dist.get_world_size()
     else:
         dist = None
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the quest_amd operators have no CPU fallback")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        world_seen = 1
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the quest_amd operators have no CPU fallback")
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
 
     from quest_amd.parallel import gather_tokens
 
-    batched = (a.seqs_per_gpu > 1 and a.multi_seq_mode == "batched" and a.mode == "graph" and a.skip_layers == 0
-               and not a.unfused)
     n_local = a.seqs_per_gpu
-    if batched:
+    batched = (n_local > 1 and a.multi_seq_mode == "batched" and a.mode == "graph" and a.skip_layers == 0
+               and not a.unfused)
+    if stub:
+        ws = [StubWorkload(a)]
+    elif batched:
         ws = [BatchedWorkload(a, dev, n_local)]
     else:
         ws = [Workload(a, dev, i) for i in range(n_local)]
     w = ws[0]
     streams = [torch.cuda.Stream() for _ in ws] if len(ws) > 1 else None
-    torch.cuda.synchronize()
+    sync()
 
     def step_all():
-        """One decode token for every local sequence; sequences are independent, so with more than one
-        each chain goes to its own stream (fork/join around the step)."""
+        """One decode token for every local sequence; unbatched sequences each go to their own stream."""
         if streams is None:
             return w.step()
         cur = torch.cuda.current_stream()
@@ -430,7 +559,7 @@ def main():
             cur.wait_stream(st)
 
     # ---- the step, eager or captured
-    if a.mode in ("graph", "graph-static"):
+    if a.mode in ("graph", "graph-static") and not stub:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -438,8 +567,7 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for wl in ws:
-            if wl.dyn:
-                wl.ctl.sync_device_state()  # the warm-up advanced the device state; start from the prefilled cache
+            wl.sync()  # the warm-up advanced the device state; start from the prefilled cache
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step_all()
@@ -460,17 +588,17 @@ def main():
 
     for _ in range(a.warmup):
         one_step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -478,116 +606,84 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed * 1e3 / a.steps
-    value = world * n_local * a.steps / elapsed  # one token per local sequence per step
+    value = world_seen * n_local * a.steps / elapsed  # one token per local sequence per step
 
     # side figure for N > 1 ("report both with and without the gather"): the same K steps again
     # without the all_gather of token ids; not part of `value`
     ms_no_gather = None
     if dist is not None:
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         t1 = time.perf_counter()
         for _ in range(a.steps):
             run()
-        torch.cuda.synchronize()
+        sync()
         t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_no_gather = float(t.item()) * 1e3 / a.steps
 
     out = None
     if rank == 0:
-        qu = w.qu
-        # per-op timings run on ONE sequence (the first of a batch) through the reference's op sequence
-        ctl = w.ctl.seqs[0] if batched else w.ctl
-        wq = [w.q[l][:1] for l in range(a.layers)] if batched else [w.q[l] for l in range(a.layers)]
-        wk = [w.k1[l][:1] for l in range(a.layers)] if batched else [w.k1[l] for l in range(a.layers)]
-        wv = [w.v1[l][:1] for l in range(a.layers)] if batched else [w.v1[l] for l in range(a.layers)]
         bpl = bytes_per_layer(a)
-        # ---- per-operator launch time with HIP events on the launch stream (steady state of this very step)
-        if w.dyn:
-            ctl.end_forward()
-        ctl.set_page_budget(w.page_budget)
-        ctl.begin_forward(1)
-        ppc, chunks = ctl._decode_handler.plan_info()
-        est0 = [qu.decode_estimate(wq[l], ctl, l) for l in range(a.layers)]
-        for l in range(a.layers):
-            qu.decode_topk(est0[l], ctl)
-        idx = ctl.topk_dindices_buffer
-        reps = 10
-        t_att = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, idx), a.layers, reps)
-        # the dominant kernel by itself (merge launch skipped; partial states stay in the workspace)
-        ctl._decode_handler.set_skip_merge(True)
-        t_att_kernel = time_kernel_loop(lambda l: qu.decode_sparse_attn(wq[l], ctl, l, idx), a.layers, reps)
-        ctl._decode_handler.set_skip_merge(False)
-        t_est = time_kernel_loop(lambda l: qu.decode_estimate(wq[l], ctl, l), a.layers, reps)
-        t_topk = time_kernel_loop(lambda l: qu.decode_topk(est0[l], ctl), a.layers, reps)
-        t_app = time_kernel_loop(lambda l: qu.append_kv(wk[l], wv[l], ctl, l), a.layers, reps)
-        t_ae = time_kernel_loop(lambda l: qu.decode_append_estimate(wq[l], wk[l], wv[l], ctl, l), a.layers, reps)
-        t_ts = time_kernel_loop(lambda l: qu.decode_topk_sparse_attn(wq[l], est0[l], ctl, l, write_topk=False),
-                                a.layers, reps)
-        ctl.end_forward()
-        ops = {"append_us": t_app, "estimate_us": t_est, "topk_us": t_topk, "sparse_attn_plus_merge_us": t_att,
-               "sparse_attn_kernel_only_us": t_att_kernel,
-               "fused_append_estimate_us": t_ae, "fused_topk_sparse_attn_plus_merge_us": t_ts,
-               "chain_us_in_step": ms_per_step * 1e3 / a.layers / n_local,
-               "note": "per launch inside a hipGraph of 32 back-to-back launches (one per layer), "
-                       "dependent-launch boundary included"}
-        dense_us = None
-        if not a.no_dense:
-            ctl.set_page_budget(1 << 20)
-            ctl.begin_forward(1, updateTensor=False)
-            dense_us = time_kernel_loop(
-                lambda l: qu.decode_sparse_attn(wq[l], ctl, l, ctl.kv_indices_without_last), a.layers, 3)
-            ctl.end_forward()
-        achieved = bpl["attn"] / (t_att_kernel * 1e-6) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")  # PMC bytes/launch, filled from rocprofv3 --pmc runs
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("sparse_decode_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
+        us_per_seq_layer = ms_per_step * 1e3 / a.layers / n_local
         out = {
-            "metric": "self-attn decode tokens/s (attention-only), seqlen=32768 token_budget=2048, 1/2/4/8 GPU",
-            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": f"self-attn decode tokens/s (attention-only), seqlen={a.seqlen} token_budget={a.token_budget}, "
+                      "1/2/4/8 GPU",
+            "value": value, "unit": "tokens/s", "n_gpus": world_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: Yarn-Llama-2-7B-128K shapes, {n_local} sequence(s) per GPU, "
-                                   "self-attention chain (append+estimate+top-k+sparse attn) x all layers per token",
-                       "layers": a.layers, "num_qo_heads": a.heads, "num_kv_heads": a.kv_heads,
-                       "head_dim": a.head_dim, "seqlen": a.seqlen, "seqlen_after_run": ctl.kv_cache.seqlen, "page_size": a.page_size,
+            "dtype": "f16", "data": "stub" if stub else "synthetic",
+            "config": {"workload": f"{a.workload_label}; {n_local} sequence(s) per GPU; self-attention chain "
+                                   + ("(append + estimate + top-k + sparse attention)" if bpl["sparse"] else
+                                      "(append + full-KV attention: the page budget covers the cache)")
+                                   + " x all layers per token",
+                       "survey_cfg": a.config, "layers": a.layers, "num_qo_heads": a.heads, "num_kv_heads": a.kv_heads,
+                       "head_dim": a.head_dim, "seqlen": a.seqlen, "page_size": a.page_size,
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
                        "kv_layout": a.layout, "mode": a.mode, "seed": a.seed, "skip_layers": a.skip_layers,
                        "launches_per_layer": "5 (reference op sequence)" if a.unfused else
                        "3 (append+estimate | top-k+sparse attn | merge)",
                        "sequences_per_gpu": n_local,
                        "multi_sequence": ("batched launches, shared pool" if batched else "one stream per sequence")
-                       if n_local > 1 else None, "parallelism": f"sequence-sharded x{world}, all_gather(token ids)"},
-            "roofline": {"bound": "hbm", "kernel": "sparse_decode_kernel (the decode_sparse_attn op without its merge launch; "
-                                                   "op incl. merge: op_us)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bpl["attn"], "launch_us": t_att_kernel, "op_us": t_att,
-                         "op_frac": bpl["attn"] / (t_att * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}},
-            "ops_us": ops,
+                       if n_local > 1 else None,
+                       "world_size_seen": world_seen, "gpus_requested": a.gpus,
+                       "parallelism": f"sequence-sharded x{world_seen}, all_gather(token ids)"},
             "ms_per_step_without_token_gather": ms_no_gather,
-            "selfattn_us_per_layer": ms_per_step * 1e3 / a.layers / n_local,
+            "selfattn_us_per_layer": us_per_seq_layer,
             "chain_bytes_per_layer": bpl["chain"],
-            "chain_frac_of_hbm_peak": bpl["chain"] * n_local / (ms_per_step * 1e-3 / a.layers) / 1e9 / HBM_PEAK_GBS,
+            "chain_frac_of_hbm_peak": bpl["chain"] / (us_per_seq_layer * 1e-6) / 1e9 / HBM_PEAK_GBS,
         }
-        if dense_us is not None:
-            out["dense_full_kv_us"] = dense_us
-            out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
-            out["speedup_vs_dense"] = dense_us / (ms_per_step * 1e3 / a.layers / n_local)
-        if batched:
-            out["batched_ops"] = batched_op_times(w, bpl)
-        if world == 1 and n_local == 1 and not a.no_multi_seq:
-            out["eight_sequences_per_gpu"] = multi_seq_side_measurement(a, dev, bpl, dense_us, mode=a.multi_seq_mode)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a, a.cpu_sample_s)
+        if not stub:
+            ctl0 = w.ctl.seqs[0] if batched else w.ctl
+            out["config"]["seqlen_after_run"] = ctl0.kv_cache.seqlen
+            if w.dyn and not w.dense:
+                ops, roof = step_op_times(w, a, bpl)
+                tp = os.path.join(ROOT, "profiles", "traffic_latest.json")  # PMC bytes/launch from rocprofv3 --pmc runs
+                if os.path.exists(tp):
+                    try:
+                        key = f"cfg{a.config}_seqs{n_local}"
+                        roof["traffic"] = json.load(open(tp)).get("sparse_decode_kernel_bytes_per_launch", {}).get(key)
+                    except Exception:
+                        roof["traffic"] = None
+                out["roofline"], out["ops_us"] = roof, ops
+            ref_ops, dense_us = reference_op_times(w, a, bpl)
+            out["reference_op_sequence_us"] = ref_ops
+            if w.dense and dense_us is not None:  # full-KV config: the dense kernel IS the dominant kernel
+                ach = bpl["dense"] / (dense_us * 1e-6) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": "shared_decode_kernel (full-KV decode, K/V read once per kv head)",
+                                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": None, "algorithmic_bytes_per_launch": bpl["dense"], "launch_us": dense_us}
+            if dense_us is not None:
+                out["dense_full_kv_us"] = dense_us
+                out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
+                out["speedup_vs_dense"] = dense_us / us_per_seq_layer
+            if "ops_us" in out and "batched_dense_full_kv_us_per_sequence" in out["ops_us"]:
+                out["speedup_vs_batched_dense"] = out["ops_us"]["batched_dense_full_kv_us_per_sequence"] / us_per_seq_layer
+            if world_seen == 1 and not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(a, w, a.cpu_sample_s)
+            else:
+                out["cpu_baseline"] = None
         else:
-            out["cpu_baseline"] = None
+            out["roofline"], out["cpu_baseline"] = None, None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

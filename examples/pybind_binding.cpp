@@ -1,10 +1,14 @@
-// The reference-side binding of INTEGRATION.md section B, compilable: a PyBind/torch extension module
-// with the reference's op signatures (quest/ops/csrc/bsk_ops.h:38-52, :70-82) whose bodies only build a
-// quest_paged_kv_t view and call the C ABI of libquest_hip.so.  Built and checked against quest_amd._kernels
-// by scripts/check_cpp_binding.py.  (Three ops are enough to show the mapping; the rest follow the table in
-// INTEGRATION.md.)
+// The reference-side binding of INTEGRATION.md section B, compilable: a PyBind/torch extension module with the
+// reference's op signatures (quest/ops/csrc/bsk_ops.h:23-117) and module definition (bsk_ops.cu:4-20) whose
+// bodies only build a quest_paged_kv_t view and call the C ABI of libquest_hip.so -- this is what a maintainer
+// puts in place of the bodies of quest/ops/csrc/{page,estimate,topk,approx_attn,rms_norm}.cu.
+// prefill_with_paged_kv_cache (batch_prefill.cu) is outside the sparse-decode path and is not bound here.
+// Built by __graft_entry__.build() / scripts/check_cpp_binding.py, checked against quest_amd._kernels on the GPU
+// by tests/test_gpu_cpp_binding.py.
 #include <ATen/hip/HIPContext.h>
 #include <torch/extension.h>
+
+#include <stdexcept>
 
 #include "quest_hip.h"
 
@@ -27,6 +31,32 @@ static quest_paged_kv_t view(const torch::Tensor& data, const torch::Tensor& ind
 
 static quest_stream_t stream() { return (quest_stream_t)at::hip::getCurrentHIPStream().stream(); }
 
+// bsk_ops.h:25-29
+void apply_rope_in_place(torch::Tensor q, torch::Tensor k, unsigned int past_kv_len, float rope_scale,
+                         float rope_theta) {
+    int rc = quest_apply_rope_in_place(q.data_ptr(), k.data_ptr(), q.size(0), past_kv_len, q.size(1), k.size(1),
+                                       q.size(2), rope_scale, rope_theta, stream());
+    TORCH_CHECK(rc == 0, "apply_rope_in_place failed with error code ", quest_error_string(rc));
+}
+
+// bsk_ops.h:31-34; input [1][rows][cols]
+void rms_norm_forward(torch::Tensor input, torch::Tensor weight, torch::Tensor output, float epsilon) {
+    const auto cols = input.size(-1);
+    int rc = quest_rms_norm_forward(input.data_ptr(), weight.data_ptr(), output.data_ptr(), input.numel() / cols, cols,
+                                    epsilon, stream());
+    TORCH_CHECK(rc == 0, "rms_norm_forward failed with error code ", quest_error_string(rc));
+}
+
+// bsk_ops.h:38-43
+void topk_filtering(torch::Tensor estimated_value, torch::Tensor estimated_indices, torch::Tensor d_out,
+                    torch::Tensor indices_out, torch::Tensor buf, unsigned int page_budget) {
+    int rc = quest_topk_filtering(estimated_value.data_ptr(), static_cast<const int32_t*>(estimated_indices.data_ptr()),
+                                  d_out.data_ptr(), static_cast<int32_t*>(indices_out.data_ptr()), buf.data_ptr(),
+                                  estimated_value.size(0), estimated_value.size(1), page_budget, stream());
+    TORCH_CHECK(rc == 0, "topk_filtering failed with error code ", quest_error_string(rc));
+}
+
+// bsk_ops.h:45-52
 void estimate_attn_score(torch::Tensor q, torch::Tensor o, torch::Tensor metadata_data, torch::Tensor metadata_indices,
                          torch::Tensor metadata_indptr, unsigned int metadata_last_page_len,
                          unsigned int metadata_last_page_idx, unsigned int layout) {
@@ -37,6 +67,21 @@ void estimate_attn_score(torch::Tensor q, torch::Tensor o, torch::Tensor metadat
     TORCH_CHECK(rc == 0, "Estimate_attn_score failed with error code ", quest_error_string(rc));
 }
 
+// bsk_ops.h:56-68
+void append_kv_cache_prefill(torch::Tensor k, torch::Tensor v, torch::Tensor kv_data, torch::Tensor kv_indices,
+                             torch::Tensor kv_indptr, unsigned int kv_last_page_len, unsigned int kv_last_page_idx,
+                             torch::Tensor metadata_data, torch::Tensor metadata_indices, torch::Tensor metadata_indptr,
+                             unsigned int metadata_last_page_len, unsigned int metadata_last_page_idx,
+                             unsigned int layout) {
+    int rc = quest_append_kv_cache_prefill(
+        k.data_ptr(), v.data_ptr(), k.size(0), kv_indices.size(0),
+        view(kv_data, kv_indices, kv_indptr, kv_last_page_len, kv_last_page_idx, layout),
+        view(metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len, metadata_last_page_idx, layout),
+        stream());
+    TORCH_CHECK(rc == 0, "Append_kv_cache_prefill failed with error code ", quest_error_string(rc));
+}
+
+// bsk_ops.h:70-82
 void append_kv_cache_decode(torch::Tensor k, torch::Tensor v, torch::Tensor kv_data, torch::Tensor kv_indices,
                             torch::Tensor kv_indptr, unsigned int kv_last_page_len, unsigned int kv_last_page_idx,
                             torch::Tensor metadata_data, torch::Tensor metadata_indices, torch::Tensor metadata_indptr,
@@ -49,16 +94,63 @@ void append_kv_cache_decode(torch::Tensor k, torch::Tensor v, torch::Tensor kv_d
     TORCH_CHECK(rc == 0, "Append_kv_cache_decode failed with error code ", quest_error_string(rc));
 }
 
-void topk_filtering(torch::Tensor estimated_value, torch::Tensor estimated_indices, torch::Tensor d_out,
-                    torch::Tensor indices_out, torch::Tensor buf, unsigned int page_budget) {
-    int rc = quest_topk_filtering(estimated_value.data_ptr(), static_cast<const int32_t*>(estimated_indices.data_ptr()),
-                                  d_out.data_ptr(), static_cast<int32_t*>(indices_out.data_ptr()), buf.data_ptr(),
-                                  estimated_value.size(0), estimated_value.size(1), page_budget, stream());
-    TORCH_CHECK(rc == 0, "topk_filtering failed with error code ", quest_error_string(rc));
-}
+// bsk_ops.h:84-116: the handler class over quest_decode_handler_t
+class BatchDecodeWithPagedKVCachePyTorchWrapper {
+public:
+    static BatchDecodeWithPagedKVCachePyTorchWrapper Create(unsigned int layout) {
+        return BatchDecodeWithPagedKVCachePyTorchWrapper(layout);
+    }
+    BatchDecodeWithPagedKVCachePyTorchWrapper(BatchDecodeWithPagedKVCachePyTorchWrapper&& o) noexcept
+        : h_(o.h_), layout_(o.layout_) {
+        o.h_ = nullptr;
+    }
+    BatchDecodeWithPagedKVCachePyTorchWrapper(const BatchDecodeWithPagedKVCachePyTorchWrapper&) = delete;
+    ~BatchDecodeWithPagedKVCachePyTorchWrapper() { quest_decode_handler_destroy(h_); }
 
-PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-    m.def("estimate_attn_score", &estimate_attn_score);
-    m.def("append_kv_cache_decode", &append_kv_cache_decode);
-    m.def("topk_filtering", &topk_filtering);
+    void BeginForward(torch::Tensor indptr, unsigned int num_qo_heads, unsigned int num_kv_heads, unsigned int head_dim,
+                      unsigned int page_size, torch::Tensor empty_data) {
+        TORCH_CHECK(empty_data.scalar_type() == torch::kHalf, "BatchDecodeWithPagedKVCache failed to dispatch with dtype ",
+                    empty_data.scalar_type());
+        // the planner needs the page count on the host, as the reference's does (decode_attn.cuh:866-873)
+        const torch::Tensor host = indptr.cpu();
+        const int32_t* p = host.data_ptr<int32_t>();
+        int rc = quest_decode_begin_forward(h_, (uint32_t)(p[host.numel() - 1] - p[0]), num_qo_heads, num_kv_heads, head_dim,
+                                            page_size, stream());
+        if (rc == QUEST_EINVAL) throw std::invalid_argument(quest_error_string(rc));  // decode_attn.cuh:1045-1050
+        TORCH_CHECK(rc == 0, "BatchDecodeWithPagedKVCache failed with error code ", quest_error_string(rc));
+    }
+
+    void EndForward() { quest_decode_end_forward(h_); }
+
+    void Forward(torch::Tensor q, torch::Tensor o, torch::Tensor paged_kv_data, torch::Tensor paged_kv_indices,
+                 torch::Tensor paged_kv_indptr, unsigned int paged_kv_last_page_len, unsigned int paged_kv_last_page_idx,
+                 float /*rope_scale*/, float /*rope_theta*/) {  // RotaryMode::kNone on this path (approx_attn.cu:131)
+        int rc = quest_decode_forward(h_, q.data_ptr(), o.data_ptr(),
+                                      view(paged_kv_data, paged_kv_indices, paged_kv_indptr, paged_kv_last_page_len,
+                                           paged_kv_last_page_idx, layout_, paged_kv_indices.size(1)),
+                                      q.size(1), nullptr, stream());
+        TORCH_CHECK(rc == 0, "BatchDecodeWithPagedKVCache failed with error code ", quest_error_string(rc));
+    }
+
+private:
+    explicit BatchDecodeWithPagedKVCachePyTorchWrapper(unsigned int layout) : layout_(layout) {
+        int rc = quest_decode_handler_create(&h_, layout);
+        TORCH_CHECK(rc == 0, "BatchDecodeWithPagedKVCache: ", quest_error_string(rc));
+    }
+    quest_decode_handler_t* h_ = nullptr;
+    unsigned int layout_;
+};
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {  // bsk_ops.cu:4-20 (the reference names the module _kernels)
+    m.def("apply_rope_in_place", &apply_rope_in_place, "Apply RoPE on Q/K in place.");
+    m.def("rms_norm_forward", &rms_norm_forward, "rms_norm_forward");
+    m.def("topk_filtering", &topk_filtering, "Top-k filtering operator");
+    m.def("estimate_attn_score", &estimate_attn_score, "Estimate Attention Score operator");
+    m.def("append_kv_cache_prefill", &append_kv_cache_prefill, "Append KV-Cache Prefill operator");
+    m.def("append_kv_cache_decode", &append_kv_cache_decode, "Append KV-Cache Decode operator");
+    py::class_<BatchDecodeWithPagedKVCachePyTorchWrapper>(m, "BatchDecodeWithPagedKVCachePyTorchWrapper")
+        .def(py::init(&BatchDecodeWithPagedKVCachePyTorchWrapper::Create))
+        .def("begin_forward", &BatchDecodeWithPagedKVCachePyTorchWrapper::BeginForward)
+        .def("end_forward", &BatchDecodeWithPagedKVCachePyTorchWrapper::EndForward)
+        .def("forward", &BatchDecodeWithPagedKVCachePyTorchWrapper::Forward);
 }

@@ -273,6 +273,12 @@ int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_
  * per-workgroup partial states in the handler's workspace (the output tensor is NOT written when the plan has
  * more than one workgroup per head).  Lets a bench time the dominant kernel by itself. */
 int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
+/* Inspection aid for the state-driven / batched fused launches (quest_decode_forward_fused_topk_dyn/_batched), which
+ * otherwise keep the selected pages inside the kernel: while set, every such launch also writes its selection --
+ * values (fp16 scores) to val_out and physical page ids to idx_out, both [n_seqs][num_qo_heads][n_selected_pages of
+ * the plan] (rows of a sequence still shorter than the budget are filled up to its live page count).  NULL
+ * pointers turn it off.  Not an entry the reference has: its top-k output lives in topk_filtering's tensors. */
+int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int32_t* idx_out);
 /* Override the planner (0 = automatic).  Used by tuning sweeps. */
 int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);
 

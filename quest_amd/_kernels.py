@@ -576,6 +576,21 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
     def set_pages_per_chunk(self, ppc: int) -> None:
         check(lib.quest_decode_set_pages_per_chunk(self._h, int(ppc)), "set_pages_per_chunk")
 
+    def set_selection_out(self, val_out, idx_out) -> None:
+        """Inspection aid: the state-driven / batched fused launches also write their selection into
+        ``val_out`` fp16 / ``idx_out`` int32, both ``[n_seqs, Hq, n_selected]`` (None, None: off).  The caller keeps
+        the tensors alive while set."""
+        if idx_out is not None:
+            _check_input(idx_out, "idx_out")
+            _check_eq(idx_out.dtype, torch.int32, "idx_out.scalar_type(), torch::kInt32")
+        if val_out is not None:
+            _check_input(val_out, "val_out")
+            _check_half(val_out, "set_selection_out")
+        self._sel_keepalive = (val_out, idx_out)
+        check(lib.quest_decode_set_selection_out(self._h, val_out.data_ptr() if val_out is not None else None,
+                                                 idx_out.data_ptr() if idx_out is not None else None),
+              "set_selection_out")
+
     def set_skip_merge(self, skip: bool) -> None:
         """Measurement aid: launch only the attention kernel (partial states stay unmerged, ``o`` unwritten)."""
         check(lib.quest_decode_set_skip_merge(self._h, int(bool(skip))), "set_skip_merge")

@@ -8,6 +8,10 @@
 // (1024 workgroups at cfg 3), each streaming 32 KiB with all of its loads in flight at once
 // (8 x 16 B per lane); LDS holds the tile's query vectors and the score transpose.
 //
+// Semantics: the reference's per-feature max of the two fp32 products (decode_attn.cuh:152-156), for ANY
+// caller-supplied metadata -- the K slot need not be >= the V slot (the reference's own gtest fills both with
+// N(0,1), test_max_possible.cu:50-51), entries may be +-inf or NaN.  See the kernel comment for how.
+//
 // Bit-exactness: per lane 8 consecutive features are accumulated left to right in fp32 (as the
 // reference kernel does, decode_attn.cuh:152-156); the 16 lanes of a row are then reduced with the
 // DPP rotation tree of row_allreduce_sum_fast (row_ror 8,4,2,1 -- one VALU op per step instead of an
@@ -38,10 +42,16 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
 // min, and produces EW consecutive scores for each of its HW*G query heads.  Row order inside the tile
 // follows memory: NHD head-fastest, HND entry-fastest.
 //
-//   1. the tile's query vectors are requested first and parked in LDS split as q+ = max(q,0) and
-//      q- = min(q,0) (exact in fp16), so max(q*Kmax, q*Kmin) becomes two FMAs per feature (one product is
-//      an exact zero; fp16 x fp16 is exact in fp32 -> bit-identical to `acc += max(q*Kmax, q*Kmin)`,
-//      decode_attn.cuh:152-156) with both FMA operands taken as fp16 by v_fma_mix_f32;
+//   1. the tile's query vectors are requested first and parked in LDS together with a 16-bit sign mask per
+//      feature (0xffff where q < 0).  For a finite non-zero q, x -> q*x is strictly monotone on the extended
+//      reals and exact in fp32 (fp16 x fp16 has 22 significant bits, |q*x| <= 65504^2), so
+//      max(q*Kmax, q*Kmin) == q * (q > 0 ? max(Kmax,Kmin) : min(Kmax,Kmin)) bit for bit, NaN entries included
+//      (maxNum/minNum drop a NaN operand exactly as fmaxf drops a NaN product).  hi/lo are two packed fp16
+//      instructions per feature PAIR shared by the G query heads of the row, the select is one v_bfi_b32 per
+//      pair and the product-accumulate one v_fma_mix_f32 (both operands read as fp16; the product is exact, so
+//      the FMA rounds like `acc += q*x`).  A tile whose query vectors contain a zero or a non-finite element
+//      (0*inf = NaN breaks the monotonicity argument) takes the literal form instead: two products, fmaxf, add
+//      -- the workgroup-uniform flag is found while staging q;
 //   2. page-table entries, then all 2*kEstIter metadata loads of the wave (streaming, nt) are issued;
 //   3. scores are transposed through LDS and leave as EW-long contiguous runs per query head (the 2-byte
 //      scattered stores of the first version cost 0.7 us at MHA and 1.5 us at GQA-4 in write amplification).
@@ -80,9 +90,10 @@ __global__ __launch_bounds__(kEstWaves* kWave) void estimate_kernel(const half_t
 
     extern __shared__ __attribute__((aligned(16))) unsigned char est_smem[];
     const uint32_t HW = tail.tile_heads, EW = ROWS / HW;
-    half_t* qp_s = reinterpret_cast<half_t*>(est_smem);          // [HW*G][D]  max(q, 0)
-    half_t* qn_s = qp_s + (size_t)HW * G * D;                     // [HW*G][D]  min(q, 0)
-    half_t* out_s = qn_s + (size_t)HW * G * D;                    // [HW*G][EW] scores
+    half_t* q_s = reinterpret_cast<half_t*>(est_smem);                              // [HW*G][D]  q
+    uint16_t* neg_s = reinterpret_cast<uint16_t*>(q_s + (size_t)HW * G * D);        // [HW*G][D]  q < 0 ? 0xffff : 0
+    half_t* out_s = reinterpret_cast<half_t*>(neg_s + (size_t)HW * G * D);          // [HW*G][EW] scores
+    __shared__ uint32_t s_literal[kEstWaves];  // per wave: some staged q element is zero or non-finite
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
@@ -143,40 +154,72 @@ __global__ __launch_bounds__(kEstWaves* kWave) void estimate_kernel(const half_t
     }
 
     // q -> LDS (these loads are older than the metadata loads, so this does not wait for them)
+    bool odd_q = false;  // a zero or non-finite query element among the ones this thread stages
 #pragma unroll
     for (int t = 0; t < QV_PER_THREAD; ++t) {
         const uint32_t vi = threadIdx.x + t * (kEstWaves * kWave);
         if (vi < q_vecs) {
-            half8 pos, neg;
+            const uint4 w = __builtin_bit_cast(uint4, qreg[t]);
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            uint32_t m[4];
 #pragma unroll
-            for (int i = 0; i < kVec; ++i) {
-                const half_t x = qreg[t][i];
-                pos[i] = x > (half_t)0 ? x : (half_t)0;
-                neg[i] = x < (half_t)0 ? x : (half_t)0;
+            for (int i = 0; i < 4; ++i) {
+                m[i] = ((ww[i] >> 15) & 0x00010001u) * 0xffffu;
+                // (|x| bits) - 1 >= 0x7bff  <=>  x is +-0, +-inf or NaN
+                odd_q |= ((ww[i] & 0x7fffu) - 1u >= 0x7bffu) | (((ww[i] >> 16) & 0x7fffu) - 1u >= 0x7bffu);
             }
-            st8(qp_s + (size_t)vi * kVec, pos);
-            st8(qn_s + (size_t)vi * kVec, neg);
+            st8(q_s + (size_t)vi * kVec, qreg[t]);
+            *reinterpret_cast<uint4*>(neg_s + (size_t)vi * kVec) = make_uint4(m[0], m[1], m[2], m[3]);
         }
     }
+    {
+        const unsigned long long any = __ballot(odd_q);
+        if (lane == 0) s_literal[wave] = any != 0ull;
+    }
     __syncthreads();
+    uint32_t literal = 0;
+#pragma unroll
+    for (int w = 0; w < kEstWaves; ++w) literal |= s_literal[w];
+    literal = __builtin_amdgcn_readfirstlane(literal);
 
     // (3) scores
+    if (!literal) {
 #pragma unroll
-    for (int j = 0; j < kEstIter; ++j) {
-        const float8 a = to_f32(mx[j]), b = to_f32(mn[j]);
+        for (int j = 0; j < kEstIter; ++j) {
+            const half8 hi = __builtin_elementwise_max(mx[j], mn[j]), lo = __builtin_elementwise_min(mx[j], mn[j]);
+            const uint4 hb = __builtin_bit_cast(uint4, hi), lb = __builtin_bit_cast(uint4, lo);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const uint32_t qh = hl[j] * G + g;  // query head inside the tile
-            const float8 qp = to_f32(ld8(qp_s + (size_t)qh * D + col * kVec));
-            const float8 qn = to_f32(ld8(qn_s + (size_t)qh * D + col * kVec));
-            float acc = 0.f;
+            for (int g = 0; g < G; ++g) {
+                const uint32_t qh = hl[j] * G + g;  // query head inside the tile
+                const float8 qf = to_f32(ld8(q_s + (size_t)qh * D + col * kVec));
+                const uint4 nm = *reinterpret_cast<const uint4*>(neg_s + (size_t)qh * D + col * kVec);
+                uint4 sb;  // per 16-bit feature: q < 0 ? lo : hi
+                sb.x = (lb.x & nm.x) | (hb.x & ~nm.x);
+                sb.y = (lb.y & nm.y) | (hb.y & ~nm.y);
+                sb.z = (lb.z & nm.z) | (hb.z & ~nm.z);
+                sb.w = (lb.w & nm.w) | (hb.w & ~nm.w);
+                const float8 x = to_f32(__builtin_bit_cast(half8, sb));
+                float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < kVec; ++i) {
-                acc = __builtin_fmaf(qp[i], a[i], acc);
-                acc = __builtin_fmaf(qn[i], b[i], acc);
+                for (int i = 0; i < kVec; ++i) acc = __builtin_fmaf(qf[i], x[i], acc);
+                acc = row_allreduce_sum_fast<LPR>(acc);
+                if (col == 0) out_s[qh * EW + el[j]] = (half_t)acc;
             }
-            acc = row_allreduce_sum_fast<LPR>(acc);
-            if (col == 0) out_s[qh * EW + el[j]] = (half_t)acc;
+        }
+    } else {  // literal form of decode_attn.cuh:152-156 (zero / non-finite query element in the tile)
+#pragma unroll
+        for (int j = 0; j < kEstIter; ++j) {
+            const float8 a = to_f32(mx[j]), b = to_f32(mn[j]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t qh = hl[j] * G + g;
+                const float8 qf = to_f32(ld8(q_s + (size_t)qh * D + col * kVec));
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < kVec; ++i) acc += __builtin_fmaxf(qf[i] * a[i], qf[i] * b[i]);
+                acc = row_allreduce_sum_fast<LPR>(acc);
+                if (col == 0) out_s[qh * EW + el[j]] = (half_t)acc;
+            }
         }
     }
     __syncthreads();

@@ -52,9 +52,9 @@ __device__ __forceinline__ void st8(half_t* p, half8 v) { *reinterpret_cast<half
 
 __device__ __forceinline__ float8 to_f32(half8 h) { return __builtin_convertvector(h, float8); }
 
-// Butterfly sum over the W lanes of a row, offsets W/2 .. 1, every lane ends with the same bits.
-// This is the reduction order of the reference kernels (decode_attn.cuh:101-104, :157-160) and of
-// the CPU oracle, so fp32 results agree bit for bit.
+// Butterfly sum over the W lanes of a row, offsets W/2 .. 1, every lane ends with the same bits: the
+// reduction order of the reference kernels (decode_attn.cuh:101-104, :157-160).  Each step is a
+// ds_bpermute (LDS crossbar) round trip on gfx9; the hot kernels use row_allreduce_sum_fast below.
 template <int W>
 __device__ __forceinline__ float row_allreduce_sum(float x) {
 #pragma unroll
@@ -75,9 +75,10 @@ __device__ __forceinline__ float dpp_f(float x) {
 constexpr int kDppRowShr = 0x110, kDppRowRor = 0x120, kDppHalfMirror = 0x141, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
 constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
 
-// Sum over the W lanes of a row, every lane gets the total.  Association order differs from
-// row_allreduce_sum (rotations instead of the xor butterfly): use where bit-exactness against the
-// oracle is not required (the attention kernel), not in the estimate.
+// Sum over the W lanes of a row, every lane gets the total, by DPP rotations (row_ror 8,4,2,1: one VALU
+// instruction per step).  The association order differs from the xor butterfly above.  The estimate kernel
+// uses THIS tree and the CPU oracle (qo_row_reduce) restates it, so their fp32 sums agree bit for bit; the
+// attention kernels use it too (their parity bar is a tolerance).
 template <int W>
 __device__ __forceinline__ float row_allreduce_sum_fast(float x) {
     static_assert(W == 8 || W == 16 || W == 32, "row width");

@@ -16,11 +16,12 @@
 // time: each 16 B-per-lane load instruction fetches 4 token rows (1 KiB), all 8 loads of a page
 // (4 K + 4 V) are issued before any is consumed and the next page's loads are issued before the
 // current page is reduced (register double buffer, no LDS round trip -- K/V are used once).
-// The 16 lanes of a row reduce q.k with an xor butterfly; every row keeps its own online-softmax
+// The 16 lanes of a row reduce q.k with a DPP rotation tree (row_allreduce_sum_fast); every row keeps its own online-softmax
 // state (m, d, acc[8]/lane), rows merge by shuffles, waves through LDS, chunks by a small second
 // kernel that also normalises and casts (VariableLengthMergeStates' job).
 #include <cstdlib>
 #include <new>
+#include <vector>
 
 #include "topk_select.cuh"
 
@@ -72,6 +73,7 @@ struct DecodeParams {
     uint32_t ids_lds_offset;
     uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
+    uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
 };
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
@@ -170,9 +172,11 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     const SeqView sv = select_sequence(p, gridDim.y, D);
     // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
     // row length comes from the state
-    if (FC == 0 && p.state) {  // no front end (not reachable through the C ABI today): plain up-front read
+    if (FC == 0 && p.state) {  // no front end, state-driven: full-KV decode of shapes the group-shared kernel
+                               // does not cover (shared_entry's fallback); the list is the page table itself
         const quest_step_state_t st = *sv.state;
         p.n_scores = (uint32_t)(st.n_pages - 1);
+        p.n_sel = min(p.n_sel, p.n_scores);
         p.last_page_len = (uint32_t)st.kv_last_page_len;
         p.last_page_idx = st.kv_last_page_idx;
     }
@@ -288,11 +292,12 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             // optional copy of the selection for callers that inspect it: issued after the barrier so no
             // workgroup waits on these stores before it starts fetching K/V
             if (p.sel_idx_out) {
+                const size_t out_row = ((size_t)blockIdx.z * gridDim.y + hq) * p.sel_stride;
 #pragma unroll
                 for (int i = 0; i < FC; ++i)
                     if (mine[i]) {
-                        p.sel_idx_out[(size_t)hq * p.n_sel + my_slot[i]] = s_sel[my_slot[i] - slot_begin];
-                        if (p.sel_val_out) p.sel_val_out[(size_t)hq * p.n_sel + my_slot[i]] = key_to_half_bits(key[i]);
+                        p.sel_idx_out[out_row + my_slot[i]] = s_sel[my_slot[i] - slot_begin];
+                        if (p.sel_val_out) p.sel_val_out[out_row + my_slot[i]] = key_to_half_bits(key[i]);
                     }
             }
         }  // n > 0
@@ -677,11 +682,17 @@ struct quest_decode_handler {
     float* ws = nullptr;
     size_t ws_bytes = 0;
     uint32_t ws_stride = 0;
+    // Workspaces outgrown by a later plan.  Launches captured in a hipGraph hold the workspace pointer BY VALUE
+    // (DecodeParams.ws), so a buffer that any launch was issued on may still be written by a replay: it is
+    // retired, never freed before the handler itself is destroyed.  (A few hundred KiB each.)
+    std::vector<float*> retired_ws;
     uint32_t dec_waves = 4;
     uint32_t shared_ppc = 0, shared_chunks = 0;  // plan of the group-shared kernel (grid.y = kv heads)
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
+    void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
+    int32_t* sel_idx_out = nullptr;
 };
 
 // Workgroups the planner aims for.  One sequence: the kernel is built for 2 workgroups (8 waves) per CU,
@@ -712,6 +723,7 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
 extern "C" void quest_decode_handler_destroy(quest_decode_handler_t* h) {
     if (!h) return;
     if (h->ws) (void)hipFree(h->ws);
+    for (float* w : h->retired_ws) (void)hipFree(w);
     delete h;
 }
 
@@ -724,6 +736,13 @@ extern "C" int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint3
 extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) {
     if (!h) return QUEST_EINVAL;
     h->skip_merge = skip != 0;
+    return 0;
+}
+
+extern "C" int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int32_t* idx_out) {
+    if (!h) return QUEST_EINVAL;
+    h->sel_val_out = val_out;
+    h->sel_idx_out = idx_out;
     return 0;
 }
 
@@ -756,7 +775,9 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
         if (chunks < 1) chunks = 1;
         if (chunks > n_slots) chunks = n_slots;
         ppc = (n_slots + chunks - 1) / chunks;
-        if (h->batch > 1 && ppc > (uint32_t)kFusedMaxPpc) ppc = kFusedMaxPpc;  // keep the fused front end usable
+        // keep the fused front end usable for every plan (it stages one chunk's page ids in LDS): eager callers
+        // can fall back to two launches, the state-driven / batched entries cannot
+        if (ppc > (uint32_t)kFusedMaxPpc) ppc = kFusedMaxPpc;
     }
     if ((n_slots + ppc - 1) / ppc > kMaxChunks) ppc = (n_slots + kMaxChunks - 1) / kMaxChunks;
     h->pages_per_chunk = ppc;
@@ -775,11 +796,18 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     const uint32_t max_chunks = h->n_chunks > h->shared_chunks ? h->n_chunks : h->shared_chunks;
     const size_t need = (size_t)h->batch * num_qo_heads * max_chunks * h->ws_stride * sizeof(float);
     if (max_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
-        if (h->ws) (void)hipFree(h->ws);
-        h->ws = nullptr;
-        h->ws_bytes = 0;
-        hipError_t e = hipMalloc((void**)&h->ws, need);
+        float* bigger = nullptr;
+        hipError_t e = hipMalloc((void**)&bigger, need);
         if (e != hipSuccess) return (int)e;
+        if (h->ws) {
+            try {
+                h->retired_ws.push_back(h->ws);  // a captured graph may still reference it (see retired_ws)
+            } catch (...) {
+                (void)hipFree(bigger);
+                return (int)hipErrorOutOfMemory;
+            }
+        }
+        h->ws = bigger;
         h->ws_bytes = need;
     }
     h->started = true;
@@ -853,8 +881,8 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         // 8191 pages: 33.7 vs 28.2 us) -> tell the caller to take the two-launch path.  State-driven
         // launches pass a capacity, not a length (the work follows the live length), so they are exempt.
         if (!state && n_scores > 8u * 8u * kWave) return QUEST_EUNSUPPORTED;
-    } else if (h->n_sel > 0 && (!kv.indices || kv.page_budget < h->n_sel)) {
-        return QUEST_EINVAL;
+    } else if (h->n_sel > 0 && (!kv.indices || (!state && kv.page_budget < h->n_sel))) {
+        return QUEST_EINVAL;  // (state-driven: one shared list, row stride kv.page_budget == 0)
     }
     if (kv.layout != h->layout || kv.head_dim != h->head_dim || kv.page_size != h->page_size ||
         kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
@@ -881,6 +909,11 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.n_scores = n_scores;
     p.sel_val_out = (uint16_t*)topk_val_out;
     p.sel_idx_out = topk_idx_out;
+    if (fused && state && !topk_idx_out) {  // state-driven launches have no output arguments: handler-level aid
+        p.sel_val_out = (uint16_t*)h->sel_val_out;
+        p.sel_idx_out = h->sel_idx_out;
+    }
+    p.sel_stride = h->n_sel;
     p.ws_stride = h->ws_stride;
     p.score_stride = score_stride ? score_stride : n_scores;
     p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
@@ -949,7 +982,15 @@ static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
         return QUEST_EINVAL;
     if (kv.last_page_len == 0 || kv.last_page_len > kv.page_size) return QUEST_EINVAL;
-    if (kv.page_size != 16 || (kv.head_dim != 64 && kv.head_dim != 128)) return QUEST_EUNSUPPORTED;
+    if (kv.page_size != 16 || (kv.head_dim != 64 && kv.head_dim != 128)) {
+        // outside the group-shared kernel's set.  Eager callers get EUNSUPPORTED and pass the per-head index
+        // tensor to quest_decode_forward; a state-driven launch has no such tensor, so it runs the per-head-list
+        // kernel with every head reading the ONE page table (row stride 0) and the live length from `state`.
+        if (!state) return QUEST_EUNSUPPORTED;
+        kv.page_budget = 0;
+        return decode_entry(h, q, o, kv, num_qo_heads, nullptr, 0, nullptr, nullptr, lse, (hipStream_t)stream, 0,
+                            state, batch);
+    }
     DecodeParams p{};
     p.q = (const half_t*)q;
     p.o = (half_t*)o;

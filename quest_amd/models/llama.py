@@ -158,6 +158,7 @@ class LlamaForCausalLM(nn.Module):
         """llama.py:554-560: release the pages for the next request."""
         assert self.model.iController is not None, "Must quest_init() before quest_clear()."
         self.model.iController.clean_states()
+        self._graph = None  # the captured step addressed the finished request's pages (re-capture after prefill)
 
     def forward(self, input_ids: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None):
         h = self.model(input_ids=input_ids, inputs_embeds=inputs_embeds)
@@ -198,10 +199,14 @@ class LlamaForCausalLM(nn.Module):
         self._graph = torch.cuda.CUDAGraph()
         with torch.inference_mode(), torch.cuda.graph(self._graph):
             self.graph_logits = step()
+        self._graph_epoch = ctl.state_epoch
 
     def decode_graph_step(self, inputs_embeds: Optional[torch.Tensor] = None,
                           input_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Generate one token's logits by replaying the captured step; returns ``self.graph_logits``."""
+        if getattr(self, "_graph", None) is None or self._graph_epoch != self.model.iController.state_epoch:
+            raise RuntimeError("no decode graph for the current request: call capture_decode_graph() after the "
+                               "prompt (quest_clear() / enable_device_state() invalidate a captured graph)")
         if inputs_embeds is None:
             inputs_embeds = self.model.embed_tokens(input_ids)
         self.graph_input.copy_(inputs_embeds.view(1, 1, -1))
@@ -264,9 +269,12 @@ class LlamaForCausalLM(nn.Module):
         self._graph = torch.cuda.CUDAGraph()
         with torch.inference_mode(), torch.cuda.graph(self._graph):
             self.graph_logits = step()
+        self._graph_epoch = b.state_epoch
 
     def decode_graph_step_batched(self, input_ids: torch.Tensor) -> torch.Tensor:
         """One token for every sequence: ``input_ids`` ``[n]`` -> logits ``[n, 1, vocab]`` (the graph's buffer)."""
+        if getattr(self, "_graph", None) is None or self._graph_epoch != self.model.bController.state_epoch:
+            raise RuntimeError("no decode graph for the current batch: call capture_decode_graph_batched()")
         self.graph_input.copy_(self.model.embed_tokens(input_ids.view(-1, 1)))
         self._graph.replay()
         self.model.bController.prepare_metadata(1)

@@ -65,6 +65,12 @@ class InferenceController:
 
         self._indptr_cache: Dict[Tuple[int, int], torch.Tensor] = {}
         self._without_last_pages = -1
+        # top-k output buffers, one pair per distinct width (the model alternates between the full-KV plan of its
+        # first layers and the real budget on every token, llama.py:428-439: keyed by width they are allocated once)
+        self._topk_buffers: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        # device-resident step state (enable_device_state); state_epoch changes whenever graphs captured over it go stale
+        self.kv_table_full = self.meta_table_full = self.step_state = None
+        self.state_epoch = 0
 
     # ------------------------------------------------------------------ budgets
     @property
@@ -115,10 +121,17 @@ class InferenceController:
             self._without_last_pages = n_pages
 
         budget = min(self._page_budget, n_pages)
-        if budget != self.inference_page_budget or self.topk_dout_buffer is None:
-            self.topk_dout_buffer = torch.zeros((self.num_heads, budget - 1), dtype=self.dtype, device=self.device)
-            self.topk_dindices_buffer = torch.zeros((self.num_heads, budget - 1), dtype=torch.int32,
-                                                    device=self.device)
+        # keyed on the buffer WIDTH, not on inference_page_budget (begin_graph_decode sets the latter without
+        # allocating): a buffer narrower than budget - 1 would be written out of bounds by topk_filtering
+        if self.topk_dout_buffer is None or self.topk_dout_buffer.size(1) != budget - 1:
+            pair = self._topk_buffers.get(budget - 1)
+            if pair is None:
+                if len(self._topk_buffers) >= 8:  # a growing dense-regime sequence asks for a new width per page
+                    self._topk_buffers.clear()
+                pair = (torch.zeros((self.num_heads, budget - 1), dtype=self.dtype, device=self.device),
+                        torch.zeros((self.num_heads, budget - 1), dtype=torch.int32, device=self.device))
+                self._topk_buffers[budget - 1] = pair
+            self.topk_dout_buffer, self.topk_dindices_buffer = pair
             if self.topk_buf is None:  # scratch argument of the reference's RAFT call; unused here
                 self.topk_buf = torch.zeros((self.num_heads, 8), dtype=self.dtype, device=self.device)
         self.inference_page_budget = budget
@@ -140,6 +153,7 @@ class InferenceController:
         self.meta_table_full = self.metadata_cache.full_device_table()
         self.max_pages = self.kv_table_full.numel()
         self.step_state = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.state_epoch += 1  # graphs captured before this call are stale
         self.sync_device_state()
 
     def begin_graph_decode(self, dense_layers: bool = False) -> None:
@@ -177,6 +191,13 @@ class InferenceController:
         self.metadata_cache.release()
         self._without_last_pages = -1
         self.inference_page_budget = None
+        # a captured decode graph holds the page tables / step state of the request that just ended: drop them so
+        # that a stale graph cannot be replayed over the next request's pages (callers re-capture after prefill)
+        self.invalidate_device_state()
+
+    def invalidate_device_state(self) -> None:
+        self.kv_table_full = self.meta_table_full = self.step_state = None
+        self.state_epoch += 1
 
 
 class BatchedInferenceController:
@@ -214,6 +235,8 @@ class BatchedInferenceController:
                                          metadata_pool=self.metadata_pool) for _ in range(n_seqs)]
         self._decode_handler = BatchDecodeWithPagedKVCacheWrapper(kv_layout=TensorLayout.FORMAT2STR[self.layout])
         self._dense_handler = None
+        self.kv_tables = self.meta_tables = self.step_states = None
+        self.state_epoch = 0
 
     def kv_layer(self, layer_idx: int) -> torch.Tensor:
         return self.kv_pool.layer(layer_idx)
@@ -231,6 +254,7 @@ class BatchedInferenceController:
         self.meta_tables = torch.stack([c.metadata_cache.full_device_table() for c in self.seqs]).contiguous()
         self.max_pages = self.kv_tables.size(1)
         self.step_states = torch.zeros(self.n_seqs, 8, dtype=torch.int32, device=self.device)
+        self.state_epoch += 1
         self.sync_device_state()
 
     def sync_device_state(self) -> None:
@@ -261,3 +285,5 @@ class BatchedInferenceController:
     def clean_states(self) -> None:
         for c in self.seqs:
             c.clean_states()
+        self.kv_tables = self.meta_tables = self.step_states = None
+        self.state_epoch += 1

@@ -66,3 +66,6 @@ class BatchDecodeWithPagedKVCacheWrapper:
 
     def set_skip_merge(self, skip: bool) -> None:
         self._wrapper.set_skip_merge(skip)
+
+    def set_selection_out(self, val_out, idx_out) -> None:
+        self._wrapper.set_selection_out(val_out, idx_out)

@@ -162,7 +162,9 @@ class KvCache:
     def release(self) -> None:
         self._seqlen = 0
         if self._reserve is None:
-            for idx in self._indicies:
+            # newest page first: the LIFO free list then hands the pages out again in the order they were used,
+            # so the next request sees the same physical order (as the reserved branch below guarantees)
+            for idx in reversed(self._indicies):
                 self._pool.free_block(idx)
         else:  # pages stay reserved for this sequence's next request, to be used in the same order
             self._reserve.extend(reversed(self._indicies))

@@ -1,0 +1,186 @@
+"""BASELINE configs[3] and configs[4] at FULL size on the MI355X (SURVEY cfg 4 and cfg 5):
+
+* cfg 4 -- Llama-3.1-8B GQA shapes, L = 131072 (8192 pages), Hq = 32 / Hkv = 8, budget 4096 tokens = 256 pages.
+  The 8191-long score rows take the routes no small test reaches: the eager path's stand-alone top-k at 8
+  columns per thread + index-tensor attention (the fused front end is refused beyond 4096 pages), and the
+  state-driven (graph) path's fused front end at 16-32 columns per thread.
+* cfg 5 -- 8 independent 32K GQA sequences decoded by ONE batched launch per op over a shared pool.
+
+Checks: metadata == per-page extrema (exact), page scores bit-exact vs the oracle run on the same metadata bytes,
+selected pages (values + ids) bit-exact vs the oracle's top-k with the declared tie rule, attention output vs a
+torch fp32 attention over exactly the selected tokens at the north-star tolerance (rtol = atol = 5e-3).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+PAGE, D = 16, 128
+DEV = "cuda:0"
+U16 = lambda a: np.ascontiguousarray(a).view(np.uint16)
+
+
+def _torch_attention(q, k, v, logical_pages, L):
+    """fp32 attention of q [Hq, D] over the tokens of `logical_pages` [Hq, B-1] (full pages) plus the tokens of
+    the sequence's last page; k, v: [L, Hkv, D]."""
+    Hq, Hkv = q.shape[0], k.shape[1]
+    n_pages = (L + PAGE - 1) // PAGE
+    pages = torch.as_tensor(logical_pages, device=q.device, dtype=torch.long)
+    tok = (pages[:, :, None] * PAGE + torch.arange(PAGE, device=q.device)).reshape(Hq, -1)
+    last = torch.arange((n_pages - 1) * PAGE, L, device=q.device)[None].expand(Hq, -1)
+    tok = torch.cat([tok, last], 1)  # [Hq, T]
+    kv_head = torch.arange(Hq, device=q.device) // (Hq // Hkv)
+    ks = k.float()[tok, kv_head[:, None]]  # [Hq, T, D]
+    vs = v.float()[tok, kv_head[:, None]]
+    p = torch.softmax((ks @ q.float()[:, :, None]).squeeze(-1) / D ** 0.5, dim=-1)
+    return (p[:, None] @ vs).squeeze(1)
+
+
+def _expected(q_np, meta_pool_np, meta_table, meta_last_len, kv_table, budget):
+    """Oracle chain on the device's own metadata bytes: scores, then (values, physical ids) of the top budget-1."""
+    meta = oracle.Paged(meta_pool_np, np.asarray(meta_table, np.int32), meta_last_len, oracle.NHD)
+    est = oracle.estimate(q_np, meta)
+    Hq = q_np.shape[1]
+    table = np.asarray(kv_table, np.int32)
+    assert est.shape[1] == len(table) - 1
+    ev, ei = oracle.topk(est, np.tile(table[:-1], (Hq, 1)), budget - 1)
+    return est, ev, ei
+
+
+def _logical(kv_table, phys):
+    inv = np.full(int(max(kv_table)) + 1, -1, np.int64)
+    inv[np.asarray(kv_table)] = np.arange(len(kv_table))
+    out = inv[phys]
+    assert (out >= 0).all()
+    return out
+
+
+def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
+    import quest_amd.utils as qu
+
+    L, Hq, Hkv, B = 131072, 32, 8, 256
+    n_pages = L // PAGE
+    g = torch.Generator(device=DEV).manual_seed(4)
+    k = torch.randn(L, Hkv, D, generator=g, device=DEV, dtype=torch.float16)
+    v = torch.randn(L, Hkv, D, generator=g, device=DEV, dtype=torch.float16)
+    q = torch.randn(1, Hq, D, generator=g, device=DEV, dtype=torch.float16)
+    ctl = qu.InferenceController(1, Hq, D, PAGE, B, L + 64, torch.float16, torch.device(DEV), num_kv_heads=Hkv,
+                                 shuffle_seed=14)
+    ctl.prepare_metadata(L - 1)
+    ctl.begin_forward(L - 1)
+    qu.append_kv(k[:-1], v[:-1], ctl, 0)
+    ctl.end_forward()
+    ctl.prepare_metadata(1)
+    ctl.begin_forward(1)
+    assert ctl.need_estimate() and ctl.inference_page_budget == B
+    # ---- eager route: fused append+estimate, then (fused front end refused at 8191 columns) top-k + attention
+    est = qu.decode_append_estimate(q, k[-1:], v[-1:], ctl, 0)
+    assert est.shape == (Hq, n_pages - 1)
+    kp = k.view(n_pages, PAGE, Hkv, D)
+    meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]  # [n_meta, 2, S, Hkv, D]
+    assert torch.equal(meta[:, 0].reshape(-1, Hkv, D)[:n_pages], kp.amax(1))
+    assert torch.equal(meta[:, 1].reshape(-1, Hkv, D)[:n_pages], kp.amin(1))
+    q_np = q.cpu().numpy()
+    meta_np = ctl.metadata_cache.buf_layer(0).cpu().numpy()
+    kv_table = list(ctl.kv_cache.indicies)
+    e_est, ev, ei = _expected(q_np, meta_np, ctl.metadata_cache.indicies, ctl.metadata_cache.last_page_len, kv_table, B)
+    assert np.array_equal(U16(est.cpu().numpy()), U16(e_est)), "page scores not bit-exact"
+    o = qu.decode_topk_sparse_attn(q, est, ctl, 0, write_topk=True)
+    assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei), "selected pages differ from the oracle"
+    assert np.array_equal(U16(ctl.topk_dout_buffer.cpu().numpy()), U16(ev))
+    ctl.end_forward()
+    o_ref = _torch_attention(q[0], k, v, _logical(kv_table, ei), L)
+    torch.testing.assert_close(o[0].float(), o_ref, rtol=5e-3, atol=5e-3)
+    # GQA: the 4 query heads of a group score against the same metadata but select their own pages
+    sel = np.sort(ei, axis=1)
+    assert any(not np.array_equal(sel[0], sel[j]) for j in range(1, 4))
+
+    # ---- state-driven (graph) route on the same cache: rewind one token on the device state, decode it again
+    # (appending the same key/value is idempotent on the pools and on the metadata fold)
+    ctl.enable_device_state()
+    st = ctl.step_state.cpu().tolist()
+    assert st[2] == PAGE  # L is a multiple of the page size: the last token did not open a page
+    st[0] -= 1
+    st[2] -= 1
+    ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
+    ctl.begin_graph_decode()
+    sel_v = torch.zeros(1, Hq, B - 1, dtype=torch.float16, device=DEV)
+    sel_i = torch.full((1, Hq, B - 1), -1, dtype=torch.int32, device=DEV)
+    ctl._decode_handler.set_selection_out(sel_v, sel_i)
+    scores = torch.zeros(Hq, ctl.max_pages, dtype=torch.float16, device=DEV)
+    qu.step_advance_dyn(ctl)
+    o2 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
+    ctl._decode_handler.set_selection_out(None, None)
+    assert ctl.step_state.cpu().tolist()[:3] == [L, n_pages, PAGE]
+    assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est))
+    assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
+    torch.testing.assert_close(o2[0].float(), o_ref, rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
+    ctl.end_forward()
+
+    # ---- dense decode of the same cache (the speed-up's baseline): group-shared kernel == torch fp32 full attention
+    ctl.set_page_budget(1 << 20)
+    ctl.begin_forward(1)
+    od = qu.decode_sparse_attn(q, ctl, 0, ctl.kv_indices_without_last)
+    ctl.end_forward()
+    kv_head = torch.arange(Hq, device=DEV) // (Hq // Hkv)
+    logits = torch.einsum("hd,lhd->hl", q[0].float(), k.float()[:, kv_head]) / D ** 0.5
+    od_ref = torch.einsum("hl,lhd->hd", torch.softmax(logits, -1), v.float()[:, kv_head])
+    torch.testing.assert_close(od[0].float(), od_ref, rtol=5e-3, atol=5e-3)
+
+
+def test_cfg5_eight_batched_32k_gqa_sequences():
+    import quest_amd.utils as qu
+
+    n, Hq, Hkv, B = 8, 32, 8, 128
+    # 32K sequences (config 5); a few tokens shorter on some so that last_page_len / page counts differ in the batch
+    lens = [32768, 32768, 32767, 32753, 32768, 32760, 32752, 32768]
+    dev = torch.device(DEV)
+    b = qu.BatchedInferenceController(n, 1, Hq, D, PAGE, B, 32768 + 64, torch.float16, dev, num_kv_heads=Hkv,
+                                      shuffle_seed=55)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ks, vs = [], []
+    for c, L in zip(b.seqs, lens):
+        k = torch.randn(L, Hkv, D, generator=g, device=DEV, dtype=torch.float16)
+        v = torch.randn(L, Hkv, D, generator=g, device=DEV, dtype=torch.float16)
+        c.prepare_metadata(L - 1)
+        c.begin_forward(L - 1)
+        qu.append_kv(k[:-1], v[:-1], c, 0)
+        c.end_forward()
+        ks.append(k)
+        vs.append(v)
+    q = torch.randn(n, Hq, D, generator=g, device=DEV, dtype=torch.float16)
+    k1 = torch.stack([k[-1] for k in ks])  # [n, Hkv, D]: the decode token of every sequence
+    v1 = torch.stack([v[-1] for v in vs])
+    b.enable_device_state()
+    b.begin_graph_decode()
+    sel_v = torch.zeros(n, Hq, B - 1, dtype=torch.float16, device=DEV)
+    sel_i = torch.full((n, Hq, B - 1), -1, dtype=torch.int32, device=DEV)
+    b._decode_handler.set_selection_out(sel_v, sel_i)
+    scores = torch.zeros(n, Hq, b.max_pages, dtype=torch.float16, device=DEV)
+    qu.step_advance_batched(b)
+    o = qu.decode_layer_batched(q, k1, v1, b, 0, scores)
+    b._decode_handler.set_selection_out(None, None)
+    b.prepare_metadata(1)  # host mirror
+    torch.cuda.synchronize()
+    ppc, chunks = b._decode_handler.plan_info()
+    assert chunks == 1  # 8 x 32 (sequence, head) pairs fill the chip: one workgroup per head, no merge launch
+    meta_np = b.metadata_layer(0).cpu().numpy()
+    states = b.step_states.cpu().tolist()
+    for i, (c, L) in enumerate(zip(b.seqs, lens)):
+        n_pages = (L + PAGE - 1) // PAGE
+        kv_table = list(c.kv_cache.indicies)
+        assert states[i][:3] == [L, n_pages, (L - 1) % PAGE + 1] and len(kv_table) == n_pages
+        e_est, ev, ei = _expected(q[i:i + 1].cpu().numpy(), meta_np, c.metadata_cache.indicies,
+                                  c.metadata_cache.last_page_len, kv_table, B)
+        assert np.array_equal(U16(scores[i, :, : n_pages - 1].cpu().numpy()), U16(e_est)), f"sequence {i}: scores"
+        assert np.array_equal(sel_i[i].cpu().numpy(), ei), f"sequence {i}: selected pages"
+        assert np.array_equal(U16(sel_v[i].cpu().numpy()), U16(ev))
+        o_ref = _torch_attention(q[i], ks[i], vs[i], _logical(kv_table, ei), L)
+        torch.testing.assert_close(o[i].float(), o_ref, rtol=5e-3, atol=5e-3)
+        # the new token landed in the cache and was folded into its page's metadata
+        last = c.kv_cache.indicies[-1]
+        slot = (L - 1) % PAGE
+        assert torch.equal(b.kv_layer(0)[last, 0, slot], ks[i][-1]) and torch.equal(b.kv_layer(0)[last, 1, slot], vs[i][-1])

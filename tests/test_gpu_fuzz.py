@@ -21,7 +21,7 @@ def _cases(n, seed):
         G = int(rng.choice([1, 1, 2, 4, 8]))
         if Hkv * G > 16:
             continue
-        page = int(rng.choice([16, 16, 16, 4, 8, 32, 5]))
+        page = int(rng.choice([16, 16, 16, 4, 8, 32, 5, 1, 7]))  # incl. the reference sweep's 1 and 7
         n_pages = int(rng.integers(2, 60))
         L = (n_pages - 1) * page + int(rng.integers(1, page + 1))
         B = int(rng.integers(2, n_pages + 3))  # sometimes >= pages: the full-attention branch
@@ -29,7 +29,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(36, 2024), ids=lambda c: "Hq%d_Hkv%d_D%d_S%d_L%d_B%d_lay%d" % c[:7])
+@pytest.mark.parametrize("case", _cases(48, 2025), ids=lambda c: "Hq%d_Hkv%d_D%d_S%d_L%d_B%d_lay%d" % c[:7])
 def test_random_shape_chain_matches_oracle(case):
     import quest_amd.utils as qu
 
@@ -76,8 +76,13 @@ def test_random_shape_chain_matches_oracle(case):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl.begin_graph_decode()
         scores = torch.zeros(Hq, ctl.max_pages, dtype=torch.float16, device="cuda:0")
+        sel_i = torch.full((1, Hq, budget - 1), -1, dtype=torch.int32, device="cuda:0")
+        sel_v = torch.zeros(1, Hq, budget - 1, dtype=torch.float16, device="cuda:0")
+        ctl._decode_handler.set_selection_out(sel_v, sel_i)
         qu.step_advance_dyn(ctl)
         o3 = qu.decode_layer_dyn(qd, cuda(k[L - 1:L]), cuda(v[L - 1:L]), ctl, 0, scores)
+        ctl._decode_handler.set_selection_out(None, None)
+        assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
         n_out = len(table) - 1
         assert np.array_equal(U16(scores[:, :n_out].cpu().numpy()), U16(e_est))
         assert pools_match(ctl, kv_o, meta_o, L)

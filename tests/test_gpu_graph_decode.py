@@ -253,3 +253,147 @@ def test_graph_decode_from_short_context_into_the_sparse_regime(L0):
         a = ea.kv_cache.buf_layer(l)[ia].reshape(-1, 2, PAGE, Hkv, D).transpose(0, 1).reshape(2, -1, Hkv, D)[:, :L]
         b = gr.kv_cache.buf_layer(l)[ia].reshape(-1, 2, PAGE, Hkv, D).transpose(0, 1).reshape(2, -1, Hkv, D)[:, :L]
         assert torch.equal(a, b)
+
+
+def test_captured_graph_survives_replanning_of_its_handler():
+    """A captured step holds the handler's partial-state workspace BY VALUE.  An eager begin_forward with a
+    larger plan on the same handler (what bench.py and a server mixing graph and eager steps do) must not
+    free that buffer under the graph: replays before and after the re-plan give the same bits."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    Hq, Hkv, D, B, L0, steps = 4, 4, 128, 6, 16 * 60 + 5, 12
+    _, k0, v0 = inputs(5, L0, Hq, Hkv, D)
+    g = torch.Generator(device=dev).manual_seed(8)
+    new_q = torch.randn(steps, 1, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    def run(disturb):
+        ctl = make_controller(L0 + steps + 40, Hq, Hkv, D, PAGE, B, shuffle_seed=3, max_seq_len=L0 + steps + 40)
+        ctl.prepare_metadata(L0)
+        ctl.begin_forward(L0)
+        qu.append_kv(cuda(k0), cuda(v0), ctl, 0)
+        ctl.end_forward()
+        ctl.enable_device_state()
+        ctl.begin_graph_decode()  # small plan: 6 slots
+        qb, kb, vb = new_q[0].clone(), new_k[0].clone(), new_v[0].clone()
+        scores = torch.empty(Hq, ctl.max_pages, device=dev, dtype=torch.float16)
+        ob = [None]
+
+        def step():
+            qu.step_advance_dyn(ctl)
+            ob[0] = qu.decode_layer_dyn(qb, kb, vb, ctl, 0, scores)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ctl.sync_device_state()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        outs = []
+        for t in range(steps):
+            qb.copy_(new_q[t]); kb.copy_(new_k[t]); vb.copy_(new_v[t])
+            graph.replay()
+            ctl.prepare_metadata(1)
+            outs.append(ob[0].clone())
+            if disturb and t % 3 == 1:
+                # eager full-KV decode on the SAME handler: a plan over all ~62 pages needs a far larger workspace
+                ctl.end_forward()
+                ctl.set_page_budget(1 << 20)
+                ctl.begin_forward(1)
+                for ppc in (1, 2):  # per-head-list kernel with many chunks, then the shared kernel
+                    ctl._decode_handler.set_pages_per_chunk(ppc)
+                    ctl.begin_forward(1, updateTensor=False)
+                    junk = qu.decode_sparse_attn(new_q[t], ctl, 0, ctl.kv_indices_without_last.clone())
+                ctl._decode_handler.set_pages_per_chunk(0)
+                ctl.end_forward()
+                ctl.set_page_budget(B)
+                assert torch.isfinite(junk.float()).all()
+        torch.cuda.synchronize()
+        return torch.stack(outs)
+
+    a, b = run(False), run(True)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D,page", [(256, 16), (128, 8), (64, 32)])
+def test_dense_state_driven_layer_outside_the_shared_kernels_set(D, page):
+    """decode_layer_dense_dyn on shapes the group-shared kernel does not cover (head_dim 256, page_size != 16)
+    runs the per-head-list kernel over the one page table with the live length from the state; result ==
+    the eager full-KV decode, token after token while the sequence grows."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    Hq, Hkv, L0, steps = 4, 2, 5 * page + 3, 2 * page + 3
+    _, k0, v0 = inputs(17, L0, Hq, Hkv, D)
+    g = torch.Generator(device=dev).manual_seed(2)
+    new_q = torch.randn(steps, 1, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    def prefilled():
+        ctl = make_controller(L0 + steps + 2 * page, Hq, Hkv, D, page, 1 << 20, shuffle_seed=1,
+                              max_seq_len=L0 + steps + 2 * page)
+        ctl.prepare_metadata(L0)
+        ctl.begin_forward(L0)
+        qu.append_kv(cuda(k0), cuda(v0), ctl, 0)
+        ctl.end_forward()
+        return ctl
+
+    ea, gr = prefilled(), prefilled()
+    gr.enable_device_state()
+    gr.begin_graph_decode(dense_layers=True)
+    for t in range(steps):
+        ea.prepare_metadata(1)
+        ea.begin_forward(1)
+        assert not ea.need_estimate()
+        qu.append_kv(new_k[t], new_v[t], ea, 0)
+        o_e = qu.decode_sparse_attn(new_q[t], ea, 0, ea.kv_indices_without_last)
+        ea.end_forward()
+        qu.step_advance_dyn(gr)
+        o_g = qu.decode_layer_dense_dyn(new_q[t], new_k[t], new_v[t], gr, 0)
+        gr.prepare_metadata(1)
+        torch.testing.assert_close(o_g.float(), o_e.float(), rtol=2e-3, atol=2e-3)
+    assert gr.kv_cache.seqlen == ea.kv_cache.seqlen == L0 + steps
+
+
+def test_stale_decode_graph_is_refused_after_quest_clear():
+    """quest_clear() ends the request: the captured step addressed its pages, so replaying it must fail loudly
+     until capture_decode_graph() runs again; and a released single-sequence cache hands its pages
+    out in the same order for the next request."""
+    from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
+
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig(vocab_size=128, hidden_size=256, intermediate_size=512, num_hidden_layers=3,
+                      num_attention_heads=2, num_key_value_heads=2)
+    torch.manual_seed(3)
+    with torch.device(dev):
+        m = LlamaForCausalLM(cfg).half()
+    for p_ in m.parameters():
+        p_.data.normal_(0, 0.05)
+    m.quest_init(16, 256, token_budget=64)
+    prompt = (torch.arange(90, device=dev)[None] * 5) % 128
+
+    def generate(n):
+        with torch.inference_mode():
+            tok = m(input_ids=prompt).argmax(-1)
+            m.capture_decode_graph()
+            toks = []
+            for _ in range(n):
+                toks.append(int(tok))
+                tok = m.decode_graph_step(input_ids=tok.view(1, 1)).argmax(-1)
+        return toks
+
+    first = generate(20)
+    order_1 = list(m.model.iController.kv_cache.indicies)
+    m.quest_clear()
+    with pytest.raises(RuntimeError, match="capture_decode_graph"):
+        m.decode_graph_step(input_ids=torch.zeros(1, 1, dtype=torch.long, device=dev))
+    second = generate(20)  # same prompt, same weights: same tokens, same physical pages in the same order
+    assert second == first
+    assert list(m.model.iController.kv_cache.indicies) == order_1

@@ -515,39 +515,91 @@ def test_error_paths_raise_like_the_reference():
         qu.rms_norm_forward(x, torch.zeros(100, dtype=torch.float16, device=dev), 1e-5)
 
 
-def test_quest_attention_module_decode_matches_unfused():
-    """The module (fused launches) and its fused=False form (reference op order) give the same output,
-    and the decode step matches a torch reference built from the same projections."""
+def _rope_fp32(x, pos0, theta=1e4, scale=1.0):
+    """Rotate-half RoPE in torch fp32 (the formula of HF's apply_rotary_pos_emb, which the reference's rope test
+    uses as its oracle, quest/tests/test_rope.py:17-30); x: [N, H, D], row i at position pos0 + i."""
+    N, H, D = x.shape
+    inv = theta ** (-torch.arange(0, D, 2, device=x.device, dtype=torch.float32) / D)
+    ang = (torch.arange(pos0, pos0 + N, device=x.device, dtype=torch.float32) / scale)[:, None] * inv[None]
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1)[:, None], torch.cat([ang.sin(), ang.sin()], -1)[:, None]
+    xf = x.float()
+    rot = torch.cat([-xf[..., D // 2:], xf[..., : D // 2]], -1)
+    return xf * cos + rot * sin
+
+
+@pytest.mark.parametrize("Hq,Hkv,L,B,rope_scaling", [(8, 8, 700, 9, None), (8, 2, 1500, 17, {"type": "linear", "factor": 4.0}),
+                                                      (4, 4, 100, 64, None)])
+def test_quest_attention_module_decode_vs_torch_reference(Hq, Hkv, L, B, rope_scaling):
+    """QuestAttention (quest/models/QuestAttention.py:99-157) end to end: prefill L tokens, decode one.
+    (1) the fused-launch module and its fused=False form (the reference's op order) give the same bits;
+    (2) the cache holds rope(k_proj(x)) / v_proj(x);
+    (3) the decode output equals o_proj(fp32 attention over the pages the ORACLE selects from the device's own
+        metadata with the module's query) -- or over all pages when the budget covers the cache -- at 5e-3."""
     from types import SimpleNamespace
     from quest_amd.models import QuestAttention
 
     qu = _qu()
     dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    cfg = SimpleNamespace(hidden_size=1024, num_attention_heads=8, num_key_value_heads=8, max_position_embeddings=4096,
-                          rope_scaling=None)
-    L, B = 700, 9
+    hid, D = Hq * 128, 128
+    cfg = SimpleNamespace(hidden_size=hid, num_attention_heads=Hq, num_key_value_heads=Hkv, max_position_embeddings=4096,
+                          rope_scaling=rope_scaling)
+    scale = 1.0 if rope_scaling is None else rope_scaling["factor"]
     outs = []
     for fused in (True, False):
         torch.manual_seed(1)
         m = QuestAttention(cfg, layer_idx=0, fused=fused).to(dev).half()
-        ctl = qu.InferenceController(1, 8, 128, PAGE, B, L + 64, torch.float16, dev)
+        ctl = qu.InferenceController(1, Hq, D, PAGE, B, L + 64, torch.float16, dev, num_kv_heads=Hkv, shuffle_seed=6)
         g = torch.Generator(device=dev).manual_seed(2)
-        hs = torch.randn(1, L, 1024, generator=g, device=dev, dtype=torch.float16) * 0.3
+        hs = torch.randn(1, L, hid, generator=g, device=dev, dtype=torch.float16) * 0.3
+        h1 = torch.randn(1, 1, hid, generator=g, device=dev, dtype=torch.float16) * 0.3
         with torch.inference_mode():
             ctl.prepare_metadata(L)
             ctl.begin_forward(L)
             m(hs, iController=ctl)
             ctl.end_forward()
-            h1 = torch.randn(1, 1, 1024, generator=g, device=dev, dtype=torch.float16) * 0.3
             ctl.prepare_metadata(1)
             ctl.begin_forward(1)
-            assert ctl.need_estimate()
+            sparse = ctl.need_estimate()
+            assert sparse == (L // PAGE + 1 > B)
             out, _, _ = m(h1, iController=ctl)
             ctl.end_forward()
         outs.append(out.float().cpu())
-    assert outs[0].shape == (1, 1, 1024)
+    assert outs[0].shape == (1, 1, hid)
     assert torch.equal(outs[0], outs[1])
+
+    # ---- reference for the last (fused=False) module / controller
+    with torch.inference_mode():
+        n_tok = L + 1
+        n_pages = (n_tok + PAGE - 1) // PAGE
+        table = torch.tensor(ctl.kv_cache.indicies, device=dev)
+        pool = ctl.kv_cache.buf_layer(0)[table]  # [n_pages, 2, S, Hkv, D]
+        k_cache = pool[:, 0].reshape(-1, Hkv, D)[:n_tok]
+        v_cache = pool[:, 1].reshape(-1, Hkv, D)[:n_tok]
+        x_all = torch.cat([hs, h1], 1)[0]
+        k_ref = _rope_fp32(m.k_proj(x_all).view(n_tok, Hkv, D), 0, scale=scale)
+        torch.testing.assert_close(k_cache.float(), k_ref, rtol=5e-3, atol=5e-3)
+        torch.testing.assert_close(v_cache.float(), m.v_proj(x_all).view(n_tok, Hkv, D).float(), rtol=2e-3, atol=2e-3)
+        q = m.q_proj(h1).view(1, Hq, D).clone()
+        k_tmp = m.k_proj(h1).view(1, Hkv, D).clone()
+        qu.apply_rope_in_place(q, k_tmp, L, rope_scale=scale)  # the module's query, bit for bit
+        torch.testing.assert_close(q.float(), _rope_fp32(m.q_proj(h1).view(1, Hq, D), L, scale=scale), rtol=5e-3, atol=5e-3)
+        if sparse:
+            meta = oracle.Paged(ctl.metadata_cache.buf_layer(0).cpu().numpy(), np.array(ctl.metadata_cache.indicies, np.int32),
+                                ctl.metadata_cache.last_page_len, 0)
+            e_est = oracle.estimate(q.cpu().numpy(), meta)
+            cols = np.tile(np.arange(n_pages - 1, dtype=np.int32), (Hq, 1))
+            _, logical = oracle.topk(e_est, cols, B - 1)  # logical page numbers
+            pages = torch.from_numpy(logical.astype(np.int64)).to(dev)
+        else:
+            pages = torch.arange(n_pages - 1, device=dev)[None].expand(Hq, -1)
+        tok = (pages[:, :, None] * PAGE + torch.arange(PAGE, device=dev)).reshape(Hq, -1)
+        tok = torch.cat([tok, torch.arange((n_pages - 1) * PAGE, n_tok, device=dev)[None].expand(Hq, -1)], 1)
+        kvh = torch.arange(Hq, device=dev) // (Hq // Hkv)
+        ks, vs = k_cache.float()[tok, kvh[:, None]], v_cache.float()[tok, kvh[:, None]]
+        p = torch.softmax((ks @ q[0].float()[:, :, None]).squeeze(-1) / D ** 0.5, dim=-1)
+        attn = (p[:, None] @ vs).squeeze(1)  # [Hq, D] fp32
+        out_ref = attn.reshape(1, 1, hid) @ m.o_proj.weight.float().t()
+    torch.testing.assert_close(outs[1].to(dev), out_ref, rtol=5e-3, atol=1e-3)  # |out| ~ 0.05: well below 5e-3 abs
 
 
 def test_llama_model_decode_runs_with_layer_skip():

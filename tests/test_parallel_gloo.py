@@ -61,3 +61,49 @@ def test_shard_partitions():
     assert sorted(sum(parts, [])) == list(range(6))
     loads = [sum([5, 1, 1, 1, 4, 4][i] for i in p) for p in parts]
     assert abs(loads[0] - loads[1]) <= 1
+
+
+def test_bench_launcher_starts_n_ranks_and_reports_world_size():
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start 2 rank processes by itself and
+    print ONE JSON line carrying n_gpus == the world size the ranks actually saw.  QUEST_BENCH_STUB=1 swaps the
+    GPU workload for a trivial CPU step (gloo), so the launcher, rendezvous, per-step token gather,
+    max-over-ranks timing and JSON contract run on a CPU-only box."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["QUEST_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--config", "5"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size_seen"] == 2 and out["config"]["gpus_requested"] == 2
+    assert out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak" and out["data"] == "stub"
+    assert out["config"]["sequences_per_gpu"] == 8 and out["config"]["num_kv_heads"] == 8
+    assert "configs[4]" in out["config"]["workload"]
+    assert out["value"] > 0 and out["ms_per_step_without_token_gather"] is not None
+    # value = tokens of ALL ranks / max-over-ranks time
+    assert abs(out["value"] - 2 * 8 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-6
+
+
+def test_bench_config_labels_follow_the_arguments():
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.parse([])
+    assert (a.seqlen, a.token_budget, a.heads, a.kv_heads, a.seqs_per_gpu) == (32768, 2048, 32, 32, 1)
+    assert a.workload_label.startswith("BASELINE configs[2]")
+    a = bench.parse(["--config", "4"])
+    assert (a.seqlen, a.token_budget, a.kv_heads) == (131072, 4096, 8) and "configs[3]" in a.workload_label
+    a = bench.parse(["--seqlen", "4096"])
+    assert a.workload_label.startswith("custom") and "seqlen=4096" in a.workload_label
+    b = bench.bytes_per_layer(bench.parse(["--config", "3"]))
+    assert b["attn"] == 128 * 16 * 2 * 32 * 128 * 2 + 32 * 128 * 2 + 32 * 127 * 4 + 32 * 128 * 2 and b["sparse"]
+    assert not bench.bytes_per_layer(bench.parse(["--config", "2"]))["sparse"]
