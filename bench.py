@@ -171,7 +171,7 @@ class Workload:
             if a.pages_per_chunk:
                 ctl._decode_handler.set_pages_per_chunk(a.pages_per_chunk)
             ctl.begin_graph_decode(dense_layers=self.dense)
-            self.scores = torch.empty(a.heads, ctl.max_pages, dtype=torch.float16, device=dev)
+            self.scores = qu.score_scratch(ctl)
         else:
             ctl.prepare_metadata(1)
 
@@ -261,7 +261,7 @@ class BatchedWorkload:
         if a.pages_per_chunk:
             self.ctl._decode_handler.set_pages_per_chunk(a.pages_per_chunk)
         self.ctl.begin_graph_decode()
-        self.scores = torch.empty(n_seqs, a.heads, self.ctl.max_pages, dtype=torch.float16, device=dev)
+        self.scores = qu.score_scratch(self.ctl)
 
     def step(self):
         qu, b, a = self.qu, self.ctl, self.a

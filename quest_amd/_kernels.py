@@ -576,6 +576,10 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
     def set_pages_per_chunk(self, ppc: int) -> None:
         check(lib.quest_decode_set_pages_per_chunk(self._h, int(ppc)), "set_pages_per_chunk")
 
+    def set_front_end(self, generation: int) -> None:
+        """Tuning / test aid: force the fused launches' top-k front end (0 = by row length, 1, 2)."""
+        check(lib.quest_decode_set_front_end(self._h, int(generation)), "set_front_end")
+
     def set_selection_out(self, val_out, idx_out) -> None:
         """Inspection aid: the state-driven / batched fused launches also write their selection into
         ``val_out`` fp16 / ``idx_out`` int32, both ``[n_seqs, Hq, n_selected]`` (None, None: off).  The caller keeps

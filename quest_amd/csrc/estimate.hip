@@ -24,6 +24,14 @@ namespace quest {
 
 constexpr int kEstIter = 4;   // load instructions per tensor per wave, all in flight together
 constexpr int kEstWaves = 4;  // waves per workgroup
+#ifndef QUEST_EST_ITER_GQA
+#define QUEST_EST_ITER_GQA 4
+#endif
+#ifndef QUEST_EST_MIN_WAVES
+#define QUEST_EST_MIN_WAVES 1
+#endif
+template <int G>
+constexpr int est_iter() { return G >= 2 ? QUEST_EST_ITER_GQA : kEstIter; }
 
 struct AppendTail {  // optional decode-append riding in the same launch (blocks >= est_blocks)
     quest_paged_kv_t kv;
@@ -56,11 +64,12 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
 //   3. scores are transposed through LDS and leave as EW-long contiguous runs per query head (the 2-byte
 //      scattered stores of the first version cost 0.7 us at MHA and 1.5 us at GQA-4 in write amplification).
 template <int D, int G, bool HND>
-__global__ __launch_bounds__(kEstWaves* kWave) void estimate_kernel(const half_t* __restrict__ q, half_t* __restrict__ o,
+__global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimate_kernel(const half_t* __restrict__ q, half_t* __restrict__ o,
                                                                     quest_paged_kv_t meta, uint32_t n_out,
                                                                     AppendTail tail) {
     constexpr int LPR = D / kVec;   // lanes per row
     constexpr int R = kWave / LPR;  // rows per load instruction
+    constexpr int kEstIter = est_iter<G>();  // (shadows the namespace constant: GQA instantiations may differ)
     constexpr int ROWS = kEstWaves * kEstIter * R;
     // n_out as passed bounds every address (state-driven launches pass the largest n_out the graph will
     // see; page tables and pools cover it); the live n_out comes from the state further down.
@@ -247,7 +256,7 @@ template <int D, int G>
 static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, AppendTail tail,
                            hipStream_t s, uint32_t n_seqs) {
     constexpr int R = kWave / (D / kVec);
-    constexpr uint32_t ROWS = kEstWaves * kEstIter * R;
+    constexpr uint32_t ROWS = kEstWaves * est_iter<G>() * R;
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
     if (!tail.state) tail.o_stride = n_out;
     const uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec), ew = ROWS / hw;

@@ -23,7 +23,7 @@
 #include <new>
 #include <vector>
 
-#include "topk_select.cuh"
+#include "topk_bitmap.cuh"
 
 // Developer aid (scripts/timeline.py): -DQUEST_TIMELINE makes one workgroup of sparse_decode_kernel write
 // clock stamps of its phases into the `lse` buffer instead of the log-sum-exp.
@@ -74,6 +74,7 @@ struct DecodeParams {
     uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
+    uint32_t vec_front;   // fused front end, second generation (topk_bitmap.cuh): score rows are 8-byte aligned
 };
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
@@ -199,6 +200,15 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
         const uint32_t n_cap = p.n_scores;  // as launched: the longest row this launch may see (buffers cover it)
+        constexpr int NT = NW * kWave;
+        __shared__ uint32_t s_bm[2][kBmWords];
+        extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
+        const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
+        Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
+        if (p.vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
+            fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
+            fe2_clear<NT>(sm);
+        }
         if (p.state) {  // live lengths
             const quest_step_state_t st = *sv.state;
             p.n_scores = (uint32_t)(st.n_pages - 1);
@@ -209,14 +219,27 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
         }
         const uint32_t n = p.n_scores;
-        constexpr int NT = NW * kWave;
-        if (n > 0) {  // block-uniform; a one-page sequence has no row to select from (only the current page)
+        if (n > 0 && p.vec_front) {
+            QUEST_STAMP(1);
+            const size_t out_row = ((size_t)blockIdx.z * gridDim.y + hq) * p.sel_stride;
+            fe2_select<NT, FC>(sm, s_bm, raw, srow, sv.indices,
+                               p.stage_ids && fe2_has_ids(FC) ? reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset) : nullptr,
+                               n_cap, n,
+                               p.n_sel, slot_begin, slot_end, s_sel, p.sel_val_out ? p.sel_val_out + out_row : nullptr,
+                               p.sel_idx_out ? p.sel_idx_out + out_row : nullptr
+#ifdef QUEST_TIMELINE
+                               , sub_out
+#endif
+            );
+            QUEST_STAMP(4);
+            __syncthreads();
+            QUEST_STAMP(5);
+        } else if (FC <= 16 && n > 0) {  // first-generation front end (unaligned score rows; rows <= 4096 columns)
+            // block-uniform; a one-page sequence has no row to select from (only the current page)
             // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n).
             const uint32_t cpt = p.cpt;
             const uint32_t c0 = threadIdx.x * cpt;
-            const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
             const int32_t* table = sv.indices;
-            extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
             uint16_t* keys_s = reinterpret_cast<uint16_t*>(fe_dyn);
             const bool stage_ids = p.stage_ids != 0;
             int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
@@ -691,6 +714,7 @@ struct quest_decode_handler {
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
+    int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
 };
@@ -736,6 +760,12 @@ extern "C" int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint3
 extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) {
     if (!h) return QUEST_EINVAL;
     h->skip_merge = skip != 0;
+    return 0;
+}
+
+extern "C" int quest_decode_set_front_end(quest_decode_handler_t* h, int generation) {
+    if (!h || generation < 0 || generation > 2) return QUEST_EINVAL;
+    h->front_end = generation;
     return 0;
 }
 
@@ -832,7 +862,7 @@ template <int D, int FC>
 static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t waves,
                             hipStream_t s, uint32_t n_seqs) {
     dim3 grid(h->n_chunks, num_qo_heads, n_seqs);
-    const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)p.n_scores * 4 : 0) : 0;
+    const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 3u) & ~3u) * 4 : 0) : 0;
     if (p.page_size == 16 && waves == 8)
         hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), lds, s, p);
     else if (p.page_size == 16)
@@ -918,6 +948,30 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.score_stride = score_stride ? score_stride : n_scores;
     p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
+    p.vec_front = 0;
+    if (fused) {
+        // second-generation front end (topk_bitmap.cuh): 8-byte loads of 4 scores straight from the row -> the rows
+        // must be 8-byte aligned and readable up to the next multiple of 4 columns (the row stride covers it)
+        // Measured on MI355X (state-driven launches, us per launch gen 1 -> gen 2): cfg 3 (2047 columns, 16 workgroups
+        // per head) 12.7 -> 13.6, 8 x cfg 3 batched 47.9 -> 50.1, cfg 4 (8191 columns) 28.6 -> 21.9.  The second
+        // generation has fewer barriers but its per-wave scans are redundant work on an issue-bound CU (4 waves per
+        // SIMD), which costs more than it saves on short rows -> gen 2 from 4097 columns up (gen 1 spills there).
+        // quest_decode_set_front_end / QUEST_FRONT_END=1 / 2 force a generation where it is applicable (tuning, tests).
+        static const int env_forced = [] { const char* e = getenv("QUEST_FRONT_END"); return e ? atoi(e) : 0; }();
+        const int forced = h->front_end ? h->front_end : env_forced;
+        const uint32_t stride = p.score_stride;
+        const bool want_gen2 = forced == 2 || (forced != 1 && n_scores > 4096u);
+        if (want_gen2 && ((uintptr_t)scores & 7u) == 0 && stride % 4u == 0 && stride >= ((n_scores + 3u) & ~3u)) {
+            p.vec_front = 1;
+            p.ids_lds_offset = 0;  // no key staging
+            // page ids are staged with 16-byte loads: the table(s) must be 16-byte aligned
+            if (((uintptr_t)kv.indices & 15u) != 0 || (batch.n_seqs > 1 && batch.kv_table_stride % 4u != 0)) p.stage_ids = 0;
+            // (the kernel stages ids only in the instantiations with <= 16 keys per thread: rows <= 4096 columns)
+        }
+    }
+    // rows beyond 4096 columns are served by the second-generation front end only (the first one spills there):
+    // state-driven callers own the score scratch and give it an 8-byte aligned row stride (a multiple of 4 columns)
+    if (fused && !p.vec_front && n_scores > 4096u) return QUEST_EUNSUPPORTED;
     p.state = state;
     p.table_stride = batch.kv_table_stride;
     // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor

@@ -177,7 +177,7 @@ class LlamaForCausalLM(nn.Module):
         ctl.enable_device_state()
         ctl.begin_graph_decode(dense_layers=m._quest_skip_layer > 0)
         self.graph_input = torch.zeros(1, 1, self.config.hidden_size, dtype=self.lm_head.weight.dtype, device=dev)
-        self._graph_scores = torch.empty(self.config.num_attention_heads, ctl.max_pages, dtype=torch.float16, device=dev)
+        self._graph_scores = qutils.score_scratch(ctl)
 
         def step():
             return self.lm_head(m.forward_decode_dyn(self.graph_input, self._graph_scores))
@@ -248,8 +248,7 @@ class LlamaForCausalLM(nn.Module):
         b.begin_graph_decode(dense_layers=m._quest_skip_layer > 0)
         n = b.n_seqs
         self.graph_input = torch.zeros(n, 1, self.config.hidden_size, dtype=self.lm_head.weight.dtype, device=dev)
-        self._graph_scores = torch.empty(n, self.config.num_attention_heads, b.max_pages, dtype=torch.float16,
-                                         device=dev)
+        self._graph_scores = qutils.score_scratch(b)
 
         def step():
             return self.lm_head(m.forward_decode_batched(self.graph_input, self._graph_scores))

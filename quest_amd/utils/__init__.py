@@ -32,6 +32,7 @@ __all__ = [
     "decode_topk_sparse_attn",
     # state-driven forms for hipGraph replay across tokens
     "step_advance_dyn",
+    "score_scratch",
     "decode_layer_dyn",
     "decode_layer_dense_dyn",
     # batched state-driven forms: n sequences per launch
@@ -162,6 +163,19 @@ def decode_topk_sparse_attn(q: torch.Tensor, estimated_attn_score: torch.Tensor,
 #         step_advance_dyn(ctl)                                # device-side prepare_metadata(1)
 #         for layer: o[layer] = decode_layer_dyn(q[layer], k[layer], v[layer], ctl, layer, scores)
 #     per token:  fill q/k/v buffers; g.replay(); ctl.prepare_metadata(1)   # host mirror only
+
+def score_scratch(controller) -> torch.Tensor:
+    """The fp16 page-score scratch of the state-driven launches: ``[Hq, stride]`` for an ``InferenceController``,
+    ``[n_seqs, Hq, stride]`` for a ``BatchedInferenceController``, with ``stride`` = the pool capacity in pages rounded
+    up to 8 columns -- 16-byte aligned rows let the attention launch read a thread's 4 scores with one 8-byte
+    load (second-generation top-k front end, csrc/topk_bitmap.cuh).  Any ``[.., >= max_pages]`` fp16 tensor works;
+    other strides take the first-generation front end (rows up to 4096 pages)."""
+    stride = (controller.max_pages + 7) // 8 * 8
+    shape = (controller.num_heads, stride)
+    if isinstance(controller, BatchedInferenceController):
+        shape = (controller.n_seqs,) + shape
+    return torch.empty(shape, dtype=torch.float16, device=controller.device)
+
 
 def step_advance_dyn(iController: InferenceController) -> None:
     _kernels.step_state_advance(iController.step_state, iController.kv_table_full, iController.meta_table_full,

@@ -67,5 +67,8 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def set_skip_merge(self, skip: bool) -> None:
         self._wrapper.set_skip_merge(skip)
 
+    def set_front_end(self, generation: int) -> None:
+        self._wrapper.set_front_end(generation)
+
     def set_selection_out(self, val_out, idx_out) -> None:
         self._wrapper.set_selection_out(val_out, idx_out)

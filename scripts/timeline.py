@@ -43,7 +43,7 @@ a2.mode, a2.layers = "graph", a.layers
 w2 = bench.Workload(a2, dev)
 c2 = w2.ctl
 qu.step_advance_dyn(c2)
-sc2 = [torch.empty(a.heads, c2.max_pages, dtype=torch.float16, device=dev) for _ in range(a.layers)]
+sc2 = [qu.score_scratch(c2) for _ in range(a.layers)]
 for l in range(a.layers):
     _kernels.append_estimate_dyn(w2.k1[l], w2.v1[l], c2.kv_cache.buf_layer(l), c2.kv_table_full, w2.q[l], sc2[l],
                                  c2.metadata_cache.buf_layer(l), c2.meta_table_full, c2.step_state, c2.max_pages - 1,
@@ -82,7 +82,12 @@ for fused in ("dyn", True, False):
           f"{cyc_per_us:.0f} cycles/us, workgroup lifetime {float(t[9]) / cyc_per_us:.2f} us")
     for i, nme in enumerate(names):
         print(f"  {float(t[i]) / cyc_per_us:6.2f} us  {nme}")
-    if fused:
+    if fused == "dyn":
+        subn = ["keys + range published", "barrier A", "hist atomics issued", "barrier B", "threshold (per wave)",
+                "bitmaps written", "barrier D", "ranks scanned", "-"]
+        for i, nme in enumerate(subn[:8]):
+            print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  fe2_select: {nme}")
+    elif fused:
         subn = ["hist1 atomics issued", "barrier", "bins read + summed", "block scan", "threshold bin published (barrier)",
                 "hist2 + barrier", "exact T (wave 0) + barrier", "gt/eq counted", "block scan 2"]
         for i, nme in enumerate(subn):

@@ -91,11 +91,14 @@ def test_batched_decode_matches_single_sequence(Hq, Hkv, layout, lens, same_spli
     b.enable_device_state()
     if same_split:
         b._decode_handler.set_pages_per_chunk(2)
+    b._decode_handler.set_front_end(2)  # second-generation front end (aligned score rows below) vs the reference's first
     b.begin_graph_decode()
     qbuf = torch.empty(layers, n, Hq, D, device=dev, dtype=torch.float16)
     kbuf = torch.empty(layers, n, Hkv, D, device=dev, dtype=torch.float16)
     vbuf = torch.empty(layers, n, Hkv, D, device=dev, dtype=torch.float16)
-    scores = torch.zeros(layers, n, Hq, b.max_pages, device=dev, dtype=torch.float16)
+    # rows padded to 16 bytes -> second-generation front end; the single-sequence reference above uses its pool's own
+    # page count as the stride (first generation unless that happens to be a multiple of 4): a cross-check of the two
+    scores = torch.zeros(layers, n, Hq, (b.max_pages + 7) // 8 * 8, device=dev, dtype=torch.float16)
     obuf = torch.empty(layers, n, Hq, D, device=dev, dtype=torch.float16)
 
     def step():

@@ -109,7 +109,7 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     sel_v = torch.zeros(1, Hq, B - 1, dtype=torch.float16, device=DEV)
     sel_i = torch.full((1, Hq, B - 1), -1, dtype=torch.int32, device=DEV)
     ctl._decode_handler.set_selection_out(sel_v, sel_i)
-    scores = torch.zeros(Hq, ctl.max_pages, dtype=torch.float16, device=DEV)
+    scores = qu.score_scratch(ctl).zero_()  # aligned rows: the only front end that serves 8191-column rows
     qu.step_advance_dyn(ctl)
     o2 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
     ctl._decode_handler.set_selection_out(None, None)
@@ -136,7 +136,7 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
 
     n, Hq, Hkv, B = 8, 32, 8, 128
     # 32K sequences (config 5); a few tokens shorter on some so that last_page_len / page counts differ in the batch
-    lens = [32768, 32768, 32767, 32753, 32768, 32760, 32752, 32768]
+    lens = [32768, 32768, 32767, 32755, 32768, 32760, 32752, 32768]
     dev = torch.device(DEV)
     b = qu.BatchedInferenceController(n, 1, Hq, D, PAGE, B, 32768 + 64, torch.float16, dev, num_kv_heads=Hkv,
                                       shuffle_seed=55)
@@ -159,10 +159,21 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
     sel_v = torch.zeros(n, Hq, B - 1, dtype=torch.float16, device=DEV)
     sel_i = torch.full((n, Hq, B - 1), -1, dtype=torch.int32, device=DEV)
     b._decode_handler.set_selection_out(sel_v, sel_i)
-    scores = torch.zeros(n, Hq, b.max_pages, dtype=torch.float16, device=DEV)
+    scores = qu.score_scratch(b).zero_()
     qu.step_advance_batched(b)
     o = qu.decode_layer_batched(q, k1, v1, b, 0, scores)
     b._decode_handler.set_selection_out(None, None)
+    # the same step through the other front-end generation (the append is idempotent): same pages, same bits
+    states_after = b.step_states.clone()
+    b.step_states[:, 0] -= 1   # seq_len
+    b.step_states[:, 2] -= 1   # kv_last_page_len (every sequence's last page holds >= 2 tokens here)
+    assert bool((b.step_states[:, 2] >= 1).all())
+    b._decode_handler.set_front_end(2)
+    qu.step_advance_batched(b)
+    o_gen2 = qu.decode_layer_batched(q, k1, v1, b, 0, qu.score_scratch(b).zero_())
+    b._decode_handler.set_front_end(0)
+    assert torch.equal(b.step_states, states_after)
+    assert torch.equal(o_gen2, o)
     b.prepare_metadata(1)  # host mirror
     torch.cuda.synchronize()
     ppc, chunks = b._decode_handler.plan_info()

@@ -75,15 +75,22 @@ def test_random_shape_chain_matches_oracle(case):
         st[0] -= 1; st[2] -= 1
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl.begin_graph_decode()
-        scores = torch.zeros(Hq, ctl.max_pages, dtype=torch.float16, device="cuda:0")
-        sel_i = torch.full((1, Hq, budget - 1), -1, dtype=torch.int32, device="cuda:0")
-        sel_v = torch.zeros(1, Hq, budget - 1, dtype=torch.float16, device="cuda:0")
-        ctl._decode_handler.set_selection_out(sel_v, sel_i)
-        qu.step_advance_dyn(ctl)
-        o3 = qu.decode_layer_dyn(qd, cuda(k[L - 1:L]), cuda(v[L - 1:L]), ctl, 0, scores)
-        ctl._decode_handler.set_selection_out(None, None)
-        assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
         n_out = len(table) - 1
-        assert np.array_equal(U16(scores[:, :n_out].cpu().numpy()), U16(e_est))
-        assert pools_match(ctl, kv_o, meta_o, L)
-        np.testing.assert_allclose(o3.cpu().numpy().astype(np.float32), eo.astype(np.float32), rtol=2e-3, atol=2e-3)
+        # both top-k front ends of the fused launch: 16-byte aligned score rows take the second generation
+        # (csrc/topk_bitmap.cuh), an odd row stride the first (csrc/topk_select.cuh)
+        for gen, scores in ((2, qu.score_scratch(ctl).zero_()),
+                            (1, torch.zeros(Hq, ctl.max_pages | 1, dtype=torch.float16, device="cuda:0")),
+                            (0, qu.score_scratch(ctl).zero_())):
+            ctl._decode_handler.set_front_end(gen)
+            ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
+            sel_i = torch.full((1, Hq, budget - 1), -1, dtype=torch.int32, device="cuda:0")
+            sel_v = torch.zeros(1, Hq, budget - 1, dtype=torch.float16, device="cuda:0")
+            ctl._decode_handler.set_selection_out(sel_v, sel_i)
+            qu.step_advance_dyn(ctl)
+            o3 = qu.decode_layer_dyn(qd, cuda(k[L - 1:L]), cuda(v[L - 1:L]), ctl, 0, scores)
+            ctl._decode_handler.set_selection_out(None, None)
+            assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
+            assert np.array_equal(U16(scores[:, :n_out].cpu().numpy()), U16(e_est))
+            assert pools_match(ctl, kv_o, meta_o, L)
+            np.testing.assert_allclose(o3.cpu().numpy().astype(np.float32), eo.astype(np.float32), rtol=2e-3, atol=2e-3)
+            assert torch.equal(o3, o)  # same pages in the same order as the eager fused launch: same bits

@@ -56,7 +56,9 @@ def test_graph_replay_matches_eager_over_growing_sequence(Hq, Hkv, layout, L0, s
     qbuf = torch.empty(layers, 1, Hq, D, device=dev, dtype=torch.float16)
     kbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     vbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
-    scores = torch.empty(Hq, gr.max_pages, device=dev, dtype=torch.float16)
+    # first case: 16-byte aligned score rows (second-generation front end), second: odd stride (first generation)
+    scores = qu.score_scratch(gr) if layout == 0 else torch.empty(Hq, gr.max_pages | 1, device=dev, dtype=torch.float16)
+    gr._decode_handler.set_front_end(2 if layout == 0 else 1)
     obuf = [None] * layers
 
     def step():
@@ -219,7 +221,7 @@ def test_graph_decode_from_short_context_into_the_sparse_regime(L0):
     qbuf = torch.empty(layers, 1, Hq, D, device=dev, dtype=torch.float16)
     kbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     vbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
-    scores = torch.empty(Hq, gr.max_pages, device=dev, dtype=torch.float16)
+    scores = qu.score_scratch(gr)
     obuf = [None] * layers
 
     def step():
