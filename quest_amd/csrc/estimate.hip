@@ -22,8 +22,14 @@
 
 namespace quest {
 
-constexpr int kEstIter = 4;   // load instructions per tensor per wave, all in flight together
-constexpr int kEstWaves = 4;  // waves per workgroup
+#ifndef QUEST_EST_ITER
+#define QUEST_EST_ITER 4
+#endif
+#ifndef QUEST_EST_WAVES
+#define QUEST_EST_WAVES 4
+#endif
+constexpr int kEstIter = QUEST_EST_ITER;    // load instructions per tensor per wave, all in flight together
+constexpr int kEstWaves = QUEST_EST_WAVES;  // waves per workgroup
 #ifndef QUEST_EST_ITER_GQA
 #define QUEST_EST_ITER_GQA 4
 #endif
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimat
         }
         // The appended token only touches the CURRENT page's KV entry and metadata entry (index n_out),
         // which the estimate excludes (e < n_out), so the two halves of the launch share no byte.
-        append_decode_body(tail.kv, meta, tail.key, tail.value, (blockIdx.x - tail.est_blocks) * 256 + threadIdx.x);
+        append_decode_body(tail.kv, meta, tail.key, tail.value, (blockIdx.x - tail.est_blocks) * (kEstWaves * kWave) + threadIdx.x);
         return;
     }
 
@@ -263,7 +269,7 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     tail.tile_heads = hw;
     tail.est_blocks = ((n_out + ew - 1) / ew) * (meta.num_heads / hw);
     uint32_t blocks = tail.est_blocks;
-    if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + 255) / 256;
+    if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + kEstWaves * kWave - 1) / (kEstWaves * kWave);
     if (blocks == 0) return 0;
     dim3 grid(blocks, n_seqs);
     const size_t lds = (size_t)hw * G * (2 * D + ew) * sizeof(half_t);

@@ -104,6 +104,14 @@ __device__ __forceinline__ uint32_t lowest_bits(uint32_t x, uint32_t keep) {
 // Selection proper.  n = live row length (<= n_cap), k = pages to select (<= n).  Writes the physical page of every
 // output slot in [slot_begin, slot_end) to s_sel[slot - slot_begin]; the caller's next barrier publishes them.
 // bm: two bitmaps of kBmWords words.  ids_s: LDS copy of the page table (filled here) or nullptr (read from `table`).
+// SOLO: the two scans (threshold over the histogram, ranks over the bitmaps) are done by wave 0 alone and published
+// through LDS (one more barrier) instead of by every wave redundantly.
+#ifdef QUEST_FE2_SOLO
+constexpr bool kFe2Solo = true;
+#else
+constexpr bool kFe2Solo = false;
+#endif
+
 template <int NT, int FC>
 __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][kBmWords],
                                            const Fe2Raw<fe2_has_ids(FC)> (&raw)[FC / 4],
@@ -174,21 +182,33 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
     // rotated by the lane number so that the 32 lanes of a read group hit 32 different banks.
     uint32_t T, need;
     {
-        const uint32_t base = kBins1 - 32u * (lane + 1u);
-        uint32_t tot = 0;
+        uint32_t thr_bin = 0, above = 0;
+        if (!kFe2Solo || wave == 0) {
+            const uint32_t base = kBins1 - 32u * (lane + 1u);
+            uint32_t tot = 0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) tot += sm.hist1[base + ((j + lane) & 31u)];
-        const uint32_t incl = wave_scan_incl_dpp(tot);
-        const unsigned long long m1 = __ballot(incl >= k);
-        const uint32_t L = (uint32_t)__builtin_ctzll(m1);  // m1 != 0: the row holds n >= k keys
-        const uint32_t above_l = (uint32_t)__builtin_amdgcn_readlane((int)(incl - tot), (int)L);
-        const uint32_t base_l = kBins1 - 32u * (L + 1u);
-        const uint32_t c = lane < 32u ? sm.hist1[base_l + 31u - lane] : 0u;  // bins of lane L, descending
-        const uint32_t incl2 = wave_scan_incl_dpp(c);
-        const unsigned long long m2 = __ballot(lane < 32u && above_l + incl2 >= k);
-        const uint32_t I = (uint32_t)__builtin_ctzll(m2);
-        const uint32_t thr_bin = base_l + 31u - I;
-        const uint32_t above = above_l + (uint32_t)__builtin_amdgcn_readlane((int)(incl2 - c), (int)I);
+            for (int j = 0; j < 32; ++j) tot += sm.hist1[base + ((j + lane) & 31u)];
+            const uint32_t incl = wave_scan_incl_dpp(tot);
+            const unsigned long long m1 = __ballot(incl >= k);
+            const uint32_t L = (uint32_t)__builtin_ctzll(m1);  // m1 != 0: the row holds n >= k keys
+            const uint32_t above_l = (uint32_t)__builtin_amdgcn_readlane((int)(incl - tot), (int)L);
+            const uint32_t base_l = kBins1 - 32u * (L + 1u);
+            const uint32_t c = lane < 32u ? sm.hist1[base_l + 31u - lane] : 0u;  // bins of lane L, descending
+            const uint32_t incl2 = wave_scan_incl_dpp(c);
+            const unsigned long long m2 = __ballot(lane < 32u && above_l + incl2 >= k);
+            const uint32_t I = (uint32_t)__builtin_ctzll(m2);
+            thr_bin = base_l + 31u - I;
+            above = above_l + (uint32_t)__builtin_amdgcn_readlane((int)(incl2 - c), (int)I);
+            if (kFe2Solo && lane == 0) {
+                sm.misc[0] = thr_bin;
+                sm.misc[1] = above;
+            }
+        }
+        if (kFe2Solo) {
+            __syncthreads();  // C: threshold bin published
+            thr_bin = sm.misc[0];
+            above = sm.misc[1];
+        }
         if (shift == 0) {  // a bin IS a key value (the usual case: one or two binades of fp16 scores)
             T = kmin + thr_bin;
             need = k - above;
@@ -212,7 +232,6 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
             need = k - (above + (uint32_t)__builtin_amdgcn_readlane((int)(incl3 - c3), (int)J));
         }
     }
-
     QUEST_SUBSTAMP(4);
     // ---- bitmaps in column order: bit (c & 31) of word (c >> 5) for column c.  A granule is a nibble; the 8 lanes
     // of an octet own 8 consecutive granules of a round = one word.
@@ -239,54 +258,74 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
     __syncthreads();  // D: bitmaps complete
     QUEST_SUBSTAMP(6);
 
-    // ---- ranks: every wave scans the whole bitmap (a few words per lane), then extracts the slots of this
-    // workgroup's chunk from the lanes it is responsible for (lane % waves == wave)
+    // ---- ranks: a wave scans the whole bitmap (a few words per lane) and extracts the slots of this workgroup's
+    // chunk from the lanes it is responsible for (redundant form: lane % waves == wave; solo form: wave 0, all lanes)
+    if (kFe2Solo && wave != 0) return;
     const uint32_t W = (n + 31u) >> 5, wpl = (W + 63u) >> 6;  // words per lane, <= 8
     uint32_t sel[8], eqc = 0;
     uint32_t eqw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint32_t wi = lane * wpl + (uint32_t)j;
-        const bool on = (uint32_t)j < wpl && wi < W;
-        sel[j] = on ? bm[0][wi] : 0u;
-        eqw[j] = on ? bm[1][wi] : 0u;
-        eqc += (uint32_t)__builtin_popcount(eqw[j]);
+        sel[j] = eqw[j] = 0u;
+        if ((uint32_t)j < wpl) {  // wave-uniform
+            const uint32_t wi = lane * wpl + (uint32_t)j;
+            if (wi < W) {
+                sel[j] = bm[0][wi];
+                eqw[j] = bm[1][wi];
+            }
+            eqc += (uint32_t)__builtin_popcount(eqw[j]);
+        }
     }
     int allowed = (int)need - (int)(wave_scan_incl_dpp(eqc) - eqc);  // ties still wanted when this lane's words begin
     uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t c = (uint32_t)__builtin_popcount(eqw[j]);
-        if (eqw[j]) sel[j] |= lowest_bits(eqw[j], (uint32_t)(allowed > 0 ? allowed : 0));
-        allowed -= (int)c;
-        cnt += (uint32_t)__builtin_popcount(sel[j]);
-    }
+    for (int j = 0; j < 8; ++j)
+        if ((uint32_t)j < wpl) {
+            const uint32_t c = (uint32_t)__builtin_popcount(eqw[j]);
+            if (eqw[j]) sel[j] |= lowest_bits(eqw[j], (uint32_t)(allowed > 0 ? allowed : 0));
+            allowed -= (int)c;
+            cnt += (uint32_t)__builtin_popcount(sel[j]);
+        }
     uint32_t rank = wave_scan_incl_dpp(cnt) - cnt;  // output slot of this lane's first selected column
     QUEST_SUBSTAMP(7);
-    if ((lane % NWV) == wave && rank < slot_end && rank + cnt > slot_begin) {
+    if ((kFe2Solo || (lane % NWV) == wave) && rank < slot_end && rank + cnt > slot_begin) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            if ((uint32_t)j >= wpl) break;
             uint32_t x = sel[j];
             while (x) {
                 const uint32_t b = (uint32_t)__builtin_ctz(x);
                 x &= x - 1u;
                 if (rank >= slot_begin && rank < slot_end) {
                     const uint32_t col = 32u * (lane * wpl + (uint32_t)j) + b;
-                    int32_t pg;
-                    if (ids_s) {
-                        pg = ids_s[col];
-                    } else {
-                        pg = table[col];
-                        asm volatile("" : "+v"(pg));  // keep the two loads apart (see sparse_attn.hip)
-                    }
-                    s_sel[rank - slot_begin] = pg;
-                    if (sel_idx_row) {
-                        sel_idx_row[rank] = pg;
+                    // without an LDS copy of the page table the COLUMN is recorded here and fe2_resolve_pages turns
+                    // the chunk's columns into pages with one parallel round trip (a dependent global load per
+                    // selected bit inside this loop serialised them: 3.7 us at 8191 columns)
+                    s_sel[rank - slot_begin] = ids_s ? ids_s[col] : (int32_t)col;
+                    if (ids_s && sel_idx_row) {
+                        sel_idx_row[rank] = ids_s[col];
                         if (sel_val_row) sel_val_row[rank] = srow[col];
                     }
                 }
                 ++rank;
             }
+        }
+    }
+}
+
+// Second half of the extraction when the page ids are not staged in LDS: call after the barrier that follows
+// fe2_select, follow with another barrier.  s_sel[i] holds a column on entry, the physical page on exit.
+__device__ __forceinline__ void fe2_resolve_pages(const uint16_t* srow, const int32_t* table, uint32_t slot_begin,
+                                                  uint32_t slot_end, uint32_t k, int32_t* s_sel, uint16_t* sel_val_row,
+                                                  int32_t* sel_idx_row) {
+    const uint32_t slot = slot_begin + threadIdx.x;
+    if (slot < slot_end && slot < k) {
+        const uint32_t col = (uint32_t)s_sel[threadIdx.x];
+        const int32_t pg = table[col];
+        s_sel[threadIdx.x] = pg;
+        if (sel_idx_row) {
+            sel_idx_row[slot] = pg;
+            if (sel_val_row) sel_val_row[slot] = srow[col];
         }
     }
 }

@@ -22,8 +22,9 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
+cfg_args = ["--config", os.environ.get("TL_CONFIG", "3")]
 sys.argv = [sys.argv[0]]
-a = bench.parse()
+a = bench.parse(cfg_args)
 a.mode, a.layers = "graph-static", 4
 dev = torch.device("cuda", 0)
 w = bench.Workload(a, dev)
@@ -38,7 +39,7 @@ names = ["entry", "loads issued+hist cleared", "scores arrived, keys in LDS", "b
          "page list in LDS (barrier)", "all K/V folded", "row butterfly + LDS write", "barrier", "partial written"]
 h = ctl._decode_handler._wrapper
 # state-driven twin of the same sequence (8-wave workgroups, lengths from the device state)
-a2 = bench.parse()
+a2 = bench.parse(cfg_args)
 a2.mode, a2.layers = "graph", a.layers
 w2 = bench.Workload(a2, dev)
 c2 = w2.ctl
@@ -49,7 +50,7 @@ for l in range(a.layers):
                                  c2.metadata_cache.buf_layer(l), c2.meta_table_full, c2.step_state, c2.max_pages - 1,
                                  c2.layout)
 h2 = c2._decode_handler._wrapper
-for fused in ("dyn", True, False):
+for fused in (("dyn",) if a.seqlen > 65536 else ("dyn", True, False)):
     acc = torch.zeros(a.layers * 4, 32, device=dev)
     for rep in range(4):
         for l in range(a.layers):
@@ -85,6 +86,8 @@ for fused in ("dyn", True, False):
     if fused == "dyn":
         subn = ["keys + range published", "barrier A", "hist atomics issued", "barrier B", "threshold (per wave)",
                 "bitmaps written", "barrier D", "ranks scanned", "-"]
+        if os.environ.get("QUEST_FRONT_END") == "3":
+            subn = ["keys + range", "hist atomics issued", "threshold", "rounds counted / ranked", "-", "-", "-", "-", "-"]
         for i, nme in enumerate(subn[:8]):
             print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  fe2_select: {nme}")
     elif fused:

@@ -168,12 +168,19 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
     b.step_states[:, 0] -= 1   # seq_len
     b.step_states[:, 2] -= 1   # kv_last_page_len (every sequence's last page holds >= 2 tokens here)
     assert bool((b.step_states[:, 2] >= 1).all())
-    b._decode_handler.set_front_end(2)
-    qu.step_advance_batched(b)
-    o_gen2 = qu.decode_layer_batched(q, k1, v1, b, 0, qu.score_scratch(b).zero_())
+    rewound = b.step_states.clone()
+    for gen in (1, 2, 3):
+        b.step_states.copy_(rewound)
+        b._decode_handler.set_front_end(gen)
+        sel_i2 = torch.full_like(sel_i, -1)
+        b._decode_handler.set_selection_out(None, sel_i2)
+        qu.step_advance_batched(b)
+        o_gen = qu.decode_layer_batched(q, k1, v1, b, 0, qu.score_scratch(b).zero_())
+        b._decode_handler.set_selection_out(None, None)
+        assert torch.equal(b.step_states, states_after)
+        assert torch.equal(sel_i2, sel_i), f"front end {gen}: page lists differ"
+        assert torch.equal(o_gen, o), f"front end {gen}"
     b._decode_handler.set_front_end(0)
-    assert torch.equal(b.step_states, states_after)
-    assert torch.equal(o_gen2, o)
     b.prepare_metadata(1)  # host mirror
     torch.cuda.synchronize()
     ppc, chunks = b._decode_handler.plan_info()
