@@ -280,8 +280,8 @@ int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
  * pointers turn it off.  Not an entry the reference has: its top-k output lives in topk_filtering's tensors. */
 int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int32_t* idx_out);
 /* Which top-k front end the fused launches use: 0 = chosen by row length (default), 1 = first generation
- * (csrc/topk_select.cuh; rows up to 4096 pages), 2 = second generation (csrc/topk_bitmap.cuh), 3 = third (csrc/topk_wave.cuh; rows up to 4096
- * pages); 2 and 3 need 8-byte aligned score rows.  Both implement the same selection (bit-identical page lists); tuning / test aid. */
+ * (csrc/topk_select.cuh; rows up to 4096 pages), 2 = second generation (csrc/topk_bitmap.cuh; needs 8-byte aligned
+ * score rows).  Both implement the same selection (bit-identical page lists); tuning / test aid. */
 int quest_decode_set_front_end(quest_decode_handler_t* h, int generation);
 /* Override the planner (0 = automatic).  Used by tuning sweeps. */
 int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);

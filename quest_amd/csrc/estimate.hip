@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimat
         for (int j = 0; j < kEstIter; ++j) {
             const half8 hi = __builtin_elementwise_max(mx[j], mn[j]), lo = __builtin_elementwise_min(mx[j], mn[j]);
             const uint4 hb = __builtin_bit_cast(uint4, hi), lb = __builtin_bit_cast(uint4, lo);
+            float accs[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t qh = hl[j] * G + g;  // query head inside the tile
@@ -217,8 +218,19 @@ __global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimat
                 float acc = 0.f;
 #pragma unroll
                 for (int i = 0; i < kVec; ++i) acc = __builtin_fmaf(qf[i], x[i], acc);
-                acc = row_allreduce_sum_fast<LPR>(acc);
-                if (col == 0) out_s[qh * EW + el[j]] = (half_t)acc;
+                accs[g] = acc;
+            }
+            if constexpr (LPR == 16 && G > 1) {
+                // the G row sums share one reduction tree walk (same association order as below, hence the same bits)
+                int g_mine;
+                const float total = row_segmented_sum16<G>(accs, col, g_mine);
+                if ((col & (16 / G - 1)) == 0) out_s[(hl[j] * G + g_mine) * EW + el[j]] = (half_t)total;
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float total = row_allreduce_sum_fast<LPR>(accs[g]);
+                    if (col == 0) out_s[(hl[j] * G + g) * EW + el[j]] = (half_t)total;
+                }
             }
         }
     } else {  // literal form of decode_attn.cuh:152-156 (zero / non-finite query element in the tile)

@@ -96,6 +96,60 @@ __device__ __forceinline__ float row_allreduce_sum_fast(float x) {
     return x;
 }
 
+// G per-lane values, each to be summed over the 16 lanes of a row (D = 128), in the SAME association order as
+// row_allreduce_sum_fast<16> (pairs at lane distance 8, then 4, 2, 1 -- fp32 addition is commutative bit for bit, so
+// only the tree matters), but computing every node of the G trees once instead of on all 16 lanes: at the first
+// log2(G) levels a lane keeps half of its values and hands the other half to its partner.  Returns the finished
+// sum of value `which` in the lanes with (lane & (16/G - 1)) == 0, where `which` is made of the lane's high bits.
+// 12 VALU instructions for G = 4 instead of 16.
+constexpr int kDppRowShl = 0x100;
+template <int G>
+__device__ __forceinline__ float row_segmented_sum16(const float (&v)[G], int col, int& which) {
+    static_assert(G == 2 || G == 4 || G == 8, "group size");
+    const bool b3 = (col & 8) != 0, b2 = (col & 4) != 0, b1 = (col & 2) != 0;
+    // level 8: partner = col ^ 8 (row_ror 8 is symmetric)
+    float w[G / 2];
+#pragma unroll
+    for (int i = 0; i < G / 2; ++i) {
+        const float keep = b3 ? v[G / 2 + i] : v[i], send = b3 ? v[i] : v[G / 2 + i];
+        w[i] = keep + dpp_f<kDppRowRor + 8>(send);
+    }
+    // level 4: partner = col ^ 4 = col - 4 where bit 2 is set (row_shr 4), col + 4 where it is not (row_shl 4).  (After
+    // the first split the two 8-lane halves of the row hold different values: a rotation would mix them.)
+    float x;
+    if constexpr (G == 2) {
+        x = w[0];
+        const float from_lo = dpp_f<kDppRowShr + 4>(x), from_hi = dpp_f<kDppRowShl + 4>(x);
+        x += b2 ? from_lo : from_hi;
+        x += dpp_f<kDppQuadXor2>(x);
+        x += dpp_f<kDppQuadXor1>(x);
+        which = b3 ? 1 : 0;
+        return x;
+    } else {
+        float y[G / 4];
+#pragma unroll
+        for (int i = 0; i < G / 4; ++i) {
+            const float keep = b2 ? w[G / 4 + i] : w[i], send = b2 ? w[i] : w[G / 4 + i];
+            const float from_lo = dpp_f<kDppRowShr + 4>(send), from_hi = dpp_f<kDppRowShl + 4>(send);
+            y[i] = keep + (b2 ? from_lo : from_hi);
+        }
+        if constexpr (G == 4) {
+            x = y[0];
+            x += dpp_f<kDppQuadXor2>(x);
+            x += dpp_f<kDppQuadXor1>(x);
+            which = (b3 ? 2 : 0) + (b2 ? 1 : 0);
+            return x;
+        } else {
+            // level 2: partner = col ^ 2 (quad permutation)
+            const float keep = b1 ? y[1] : y[0], send = b1 ? y[0] : y[1];
+            x = keep + dpp_f<kDppQuadXor2>(send);
+            x += dpp_f<kDppQuadXor1>(x);
+            which = (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+            return x;
+        }
+    }
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave in 7 DPP adds.
 __device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t x) {
     int v = (int)x;

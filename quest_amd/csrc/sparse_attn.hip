@@ -23,7 +23,7 @@
 #include <new>
 #include <vector>
 
-#include "topk_wave.cuh"
+#include "topk_bitmap.cuh"
 
 // Developer aid (scripts/timeline.py): -DQUEST_TIMELINE makes one workgroup of sparse_decode_kernel write
 // clock stamps of its phases into the `lse` buffer instead of the log-sum-exp.
@@ -74,8 +74,8 @@ struct DecodeParams {
     uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
-    uint32_t vec_front;   // fused front end generation: 0 = first (topk_select.cuh); 2 (topk_bitmap.cuh) and 3
-                          // (topk_wave.cuh) need 8-byte aligned score rows
+    uint32_t vec_front;   // fused front end generation: 0 = first (topk_select.cuh), 2 = second (topk_bitmap.cuh;
+                          // needs 8-byte aligned score rows)
 };
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
@@ -198,8 +198,6 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     RowState<D> st;
 
     __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
-    bool cols_in_sel = false;         // third front end: s_sel holds COLUMN numbers, the page ids are in fe_ids (LDS)
-    const int32_t* fe_ids = nullptr;
     if constexpr (FC > 0) {
         __shared__ TopkSmem<NW * kWave> sm;
         const uint32_t n_cap = p.n_scores;  // as launched: the longest row this launch may see (buffers cover it)
@@ -208,14 +206,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
         Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
-        Fe3Raw raw3;
-        int32_t* const ids_lds = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
-        fe_ids = ids_lds;
-        if (FC == 8 && p.vec_front == 3) {  // (hosted by the FC = 8 instantiations only: it does not depend on FC)
-            // wave 0 selects, the other waves bring the page table into LDS
-            if (wave == 0) fe3_issue(srow, n_cap, raw3);
-            else if (p.stage_ids) fe3_stage_ids<NT>(sv.indices, n_cap + 1u, ids_lds);
-        } else if (p.vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
+        if (p.vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
             fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
             fe2_clear<NT>(sm);
         }
@@ -229,26 +220,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
         }
         const uint32_t n = p.n_scores;
-        if (FC == 8 && n > 0 && p.vec_front == 3) {
-            QUEST_STAMP(1);
-            if (wave == 0) fe3_select<NT>(sm, raw3, n, p.n_sel, slot_begin, slot_end, s_sel
-#ifdef QUEST_TIMELINE
-                                          , sub_out
-#endif
-            );
-            QUEST_STAMP(4);
-            __syncthreads();  // the only barrier of this front end: column list + LDS page table complete
-            cols_in_sel = p.stage_ids != 0;
-            if (!cols_in_sel || p.sel_idx_out) {  // block-uniform: no LDS table (or the selection is wanted in memory)
-                const size_t out_row = ((size_t)blockIdx.z * gridDim.y + hq) * p.sel_stride;
-                fe2_resolve_pages(srow, sv.indices, slot_begin, slot_end, p.n_sel, s_sel,
-                                  p.sel_val_out ? p.sel_val_out + out_row : nullptr,
-                                  p.sel_idx_out ? p.sel_idx_out + out_row : nullptr);
-                cols_in_sel = false;
-                __syncthreads();
-            }
-            QUEST_STAMP(5);
-        } else if (n > 0 && p.vec_front) {
+        if (n > 0 && p.vec_front) {
             QUEST_STAMP(1);
             const size_t out_row = ((size_t)blockIdx.z * gridDim.y + hq) * p.sel_stride;
             const bool ids_staged = p.stage_ids && fe2_has_ids(FC);
@@ -364,7 +336,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
     auto slot_page = [&](uint32_t slot) -> int32_t {
         if (slot >= p.n_sel) return p.last_page_idx;
-        if constexpr (FC > 0) return cols_in_sel ? fe_ids[s_sel[slot - slot_begin]] : s_sel[slot - slot_begin];
+        if constexpr (FC > 0) return s_sel[slot - slot_begin];
         else return idx_row[slot];
     };
 
@@ -798,7 +770,7 @@ extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) 
 }
 
 extern "C" int quest_decode_set_front_end(quest_decode_handler_t* h, int generation) {
-    if (!h || generation < 0 || generation > 3) return QUEST_EINVAL;
+    if (!h || generation < 0 || generation > 2) return QUEST_EINVAL;
     h->front_end = generation;
     return 0;
 }
@@ -999,7 +971,6 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         int gen = 1;
         if (aligned) {
             if (forced == 2 || (forced == 0 && n_scores > 4096u)) gen = 2;
-            else if (forced == 3 && n_scores <= kFe3MaxRow) gen = 3;
         }
         if (gen != 1) {
             p.vec_front = (uint32_t)gen;
@@ -1026,7 +997,6 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
         const uint32_t per_thread = (n_scores + nt - 1) / nt;
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
-        if (p.vec_front == 3) fc = 8;  // the single-wave front end lives in the FC = 8 instantiations
         // ownership chunk: a multiple of 4 columns when the register capacity allows, so a thread's keys are one
         // 8/16-byte LDS read (topk_load_keys)
         const uint32_t r4 = (per_thread + 3) / 4 * 4;

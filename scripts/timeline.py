@@ -86,8 +86,6 @@ for fused in (("dyn",) if a.seqlen > 65536 else ("dyn", True, False)):
     if fused == "dyn":
         subn = ["keys + range published", "barrier A", "hist atomics issued", "barrier B", "threshold (per wave)",
                 "bitmaps written", "barrier D", "ranks scanned", "-"]
-        if os.environ.get("QUEST_FRONT_END") == "3":
-            subn = ["keys + range", "hist atomics issued", "threshold", "rounds counted / ranked", "-", "-", "-", "-", "-"]
         for i, nme in enumerate(subn[:8]):
             print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  fe2_select: {nme}")
     elif fused:

@@ -169,7 +169,7 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
     b.step_states[:, 2] -= 1   # kv_last_page_len (every sequence's last page holds >= 2 tokens here)
     assert bool((b.step_states[:, 2] >= 1).all())
     rewound = b.step_states.clone()
-    for gen in (1, 2, 3):
+    for gen in (1, 2):
         b.step_states.copy_(rewound)
         b._decode_handler.set_front_end(gen)
         sel_i2 = torch.full_like(sel_i, -1)

@@ -76,9 +76,9 @@ def test_random_shape_chain_matches_oracle(case):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl.begin_graph_decode()
         n_out = len(table) - 1
-        # all three top-k front ends of the fused launch: block-wide first generation (csrc/topk_select.cuh; any row
-        # stride), block-wide second (topk_bitmap.cuh) and single-wave third (topk_wave.cuh), both on aligned rows
-        for gen, scores in ((2, qu.score_scratch(ctl).zero_()), (3, qu.score_scratch(ctl).zero_()),
+        # both top-k front ends of the fused launch: first generation (csrc/topk_select.cuh; any row stride) and
+        # second (csrc/topk_bitmap.cuh; 8-byte aligned rows), then the default choice
+        for gen, scores in ((2, qu.score_scratch(ctl).zero_()),
                             (1, torch.zeros(Hq, ctl.max_pages | 1, dtype=torch.float16, device="cuda:0")),
                             (0, qu.score_scratch(ctl).zero_())):
             ctl._decode_handler.set_front_end(gen)

@@ -222,7 +222,7 @@ def test_graph_decode_from_short_context_into_the_sparse_regime(L0):
     kbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     vbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     scores = qu.score_scratch(gr)
-    gr._decode_handler.set_front_end(3)  # single-wave front end, from a one-page sequence into the sparse regime
+    gr._decode_handler.set_front_end(2)  # second-generation front end, from a one-page sequence into the sparse regime
     obuf = [None] * layers
 
     def step():
