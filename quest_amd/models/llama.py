@@ -38,6 +38,37 @@ class LlamaConfig:
         if self.num_key_value_heads is None:
             self.num_key_value_heads = self.num_attention_heads
 
+    # ---- Hugging Face config.json <-> LlamaConfig (the fields the Quest path reads; quest/models/llama.py takes the
+    # whole HF LlamaConfig, of which it uses exactly these)
+    @classmethod
+    def from_hf_dict(cls, d: dict) -> "LlamaConfig":
+        if d.get("model_type", "llama") != "llama":
+            raise ValueError(f"not a Llama checkpoint: model_type = {d.get('model_type')!r}")
+        rope = d.get("rope_parameters") or {}        # transformers >= 5 nests theta / scaling here
+        scaling = d.get("rope_scaling")
+        if scaling is None and rope.get("rope_type", "default") not in ("default", None):
+            scaling = {k: v for k, v in rope.items() if k != "rope_theta"}
+        if d.get("attention_bias") or d.get("mlp_bias"):
+            raise ValueError("bias terms are not part of the reference's Llama fork")
+        head_dim = d.get("head_dim")
+        if head_dim is not None and head_dim * d["num_attention_heads"] != d["hidden_size"]:
+            raise ValueError("head_dim * num_attention_heads != hidden_size is not supported (QuestAttention.py:24-29)")
+        return cls(vocab_size=d["vocab_size"], hidden_size=d["hidden_size"], intermediate_size=d["intermediate_size"],
+                   num_hidden_layers=d["num_hidden_layers"], num_attention_heads=d["num_attention_heads"],
+                   num_key_value_heads=d.get("num_key_value_heads"), rms_norm_eps=d.get("rms_norm_eps", 1e-5),
+                   max_position_embeddings=d.get("max_position_embeddings", 32768), rope_scaling=scaling,
+                   rope_theta=float(d.get("rope_theta", rope.get("rope_theta", 1e4))))
+
+    def to_hf_dict(self, dtype: str = "float16", tie_word_embeddings: bool = False) -> dict:
+        return {"architectures": ["LlamaForCausalLM"], "model_type": "llama", "hidden_act": "silu",
+                "attention_bias": False, "mlp_bias": False, "torch_dtype": dtype, "dtype": dtype,
+                "vocab_size": self.vocab_size, "hidden_size": self.hidden_size,
+                "intermediate_size": self.intermediate_size, "num_hidden_layers": self.num_hidden_layers,
+                "num_attention_heads": self.num_attention_heads, "num_key_value_heads": self.num_key_value_heads,
+                "rms_norm_eps": self.rms_norm_eps, "max_position_embeddings": self.max_position_embeddings,
+                "rope_scaling": self.rope_scaling, "rope_theta": self.rope_theta,
+                "tie_word_embeddings": tie_word_embeddings}
+
 
 class LlamaRMSNorm(nn.Module):
     def __init__(self, hidden_size: int, eps: float):
@@ -140,6 +171,94 @@ class LlamaForCausalLM(nn.Module):
         self.config = config
         self.model = LlamaModel(config, fused)
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+
+    # ------------------------------------------------------------------ Hugging Face checkpoint format
+    @classmethod
+    def from_pretrained(cls, path: str, device=torch.device("cuda:0"), dtype=torch.float16,
+                        fused: bool = True) -> "LlamaForCausalLM":
+        """Load a Hugging Face Llama checkpoint directory -- ``config.json`` + ``model.safetensors`` or the sharded
+        ``model-0000x-of-0000y.safetensors`` + ``model.safetensors.index.json`` -- the way the reference does with
+        ``LlamaForCausalLM.from_pretrained(...)`` (scripts/bench_textgen.py:53-58, evaluation/*).  Parameter names
+        are HF's (``model.layers.N.self_attn.q_proj.weight`` ...), so tensors are copied by name, shard by shard,
+        straight to ``device``."""
+        import json
+        import os
+
+        from safetensors import safe_open
+
+        with open(os.path.join(path, "config.json")) as f:
+            hf = json.load(f)
+        cfg = LlamaConfig.from_hf_dict(hf)
+        with torch.device(device):
+            model = cls(cfg, fused=fused).to(dtype)
+        index = os.path.join(path, "model.safetensors.index.json")
+        if os.path.exists(index):
+            with open(index) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+        else:
+            files = ["model.safetensors"]
+        params = dict(model.state_dict())
+        seen = set()
+        with torch.no_grad():
+            for fn in files:
+                with safe_open(os.path.join(path, fn), framework="pt", device=str(device)) as sf:
+                    for name in sf.keys():
+                        if name.endswith("rotary_emb.inv_freq"):  # buffer of older HF exports; recomputed by the rope kernel
+                            continue
+                        if name not in params:
+                            raise KeyError(f"{fn}: unexpected tensor {name!r} (not a Llama decoder parameter)")
+                        t = sf.get_tensor(name)
+                        if t.shape != params[name].shape:
+                            raise ValueError(f"{name}: checkpoint shape {tuple(t.shape)} != model {tuple(params[name].shape)}")
+                        params[name].copy_(t)
+                        seen.add(name)
+        missing = set(params) - seen
+        if missing == {"lm_head.weight"} and hf.get("tie_word_embeddings", False):
+            model.lm_head.weight = model.model.embed_tokens.weight
+            missing = set()
+        if missing:
+            raise KeyError(f"checkpoint lacks {sorted(missing)[:5]}{' ...' if len(missing) > 5 else ''}")
+        return model
+
+    def save_pretrained(self, path: str, max_shard_bytes: int = 4 << 30) -> None:
+        """Write ``config.json`` + safetensors shard(s) in the Hugging Face layout (tensor names = HF's), so that
+        ``transformers.LlamaForCausalLM.from_pretrained(path)`` -- or ``from_pretrained`` above -- reads it."""
+        import json
+        import os
+
+        from safetensors.torch import save_file
+
+        os.makedirs(path, exist_ok=True)
+        sd = self.state_dict()
+        tied = self.lm_head.weight.data_ptr() == self.model.embed_tokens.weight.data_ptr()
+        if tied:
+            sd.pop("lm_head.weight")
+        dt = {torch.float16: "float16", torch.bfloat16: "bfloat16", torch.float32: "float32"}[self.lm_head.weight.dtype]
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.config.to_hf_dict(dt, tied), f, indent=1)
+        shards, cur, size = [], {}, 0
+        for name, t in sd.items():
+            nbytes = t.numel() * t.element_size()
+            if cur and size + nbytes > max_shard_bytes:
+                shards.append(cur)
+                cur, size = {}, 0
+            cur[name] = t
+            size += nbytes
+        shards.append(cur)
+        if len(shards) == 1:
+            save_file({k: v.detach().contiguous().cpu() for k, v in shards[0].items()},
+                      os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+            return
+        weight_map, total = {}, 0
+        for i, shard in enumerate(shards):
+            fn = f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file({k: v.detach().contiguous().cpu() for k, v in shard.items()}, os.path.join(path, fn),
+                      metadata={"format": "pt"})
+            for k, v in shard.items():
+                weight_map[k] = fn
+                total += v.numel() * v.element_size()
+        with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
+            json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
 
     def quest_init(self, page_size: int, max_seq_len: int, token_budget: int = 512, dtype=torch.float16,
                    device=torch.device("cuda:0")) -> None:

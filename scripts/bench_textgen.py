@@ -104,6 +104,15 @@ def main():
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--seqs", type=int, default=1, help="sequences decoded together (batched launches)")
+    ap.add_argument("--checkpoint", default=None,
+                    help="Hugging Face Llama checkpoint directory (config.json + safetensors) to load instead of "
+                         "random-initialising; shapes come from its config.json")
+    ap.add_argument("--make-checkpoint", default=None,
+                    help="first WRITE a random-weight checkpoint of the given shape in HF layout to this directory "
+                         "(save_pretrained), then load it back with from_pretrained and bench that model")
+    ap.add_argument("--generate", type=int, default=0,
+                    help="also generate this many tokens greedily by graph replay from the synthetic cache and report "
+                         "ms/token over the whole run (host loop included)")
     a = ap.parse_args()
     from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
     import quest_amd.utils as qu
@@ -112,6 +121,30 @@ def main():
     torch.manual_seed(0)
     cfg = LlamaConfig(vocab_size=a.vocab, hidden_size=a.hidden, intermediate_size=a.inter, num_hidden_layers=a.layers,
                       num_attention_heads=a.heads, num_key_value_heads=a.kv_heads, max_position_embeddings=a.ctx + 1024)
+    ckpt_info = None
+    if a.make_checkpoint:
+        import time
+        t0 = time.perf_counter()
+        with torch.device(dev):
+            tmp = LlamaForCausalLM(cfg).half()
+        for p in tmp.parameters():
+            p.data.normal_(0, 0.02)
+        for m in tmp.modules():
+            if hasattr(m, "variance_epsilon"):
+                m.weight.data.fill_(1.0)
+        tmp.save_pretrained(a.make_checkpoint)
+        del tmp
+        torch.cuda.empty_cache()
+        a.checkpoint = a.make_checkpoint
+        ckpt_info = {"written_s": time.perf_counter() - t0}
+    if a.checkpoint:
+        with open(os.path.join(a.checkpoint, "config.json")) as f:
+            cfg = LlamaConfig.from_hf_dict(json.load(f))
+        a.layers, a.hidden, a.heads, a.kv_heads = (cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads,
+                                                   cfg.num_key_value_heads)
+        ckpt_info = dict(ckpt_info or {}, path=a.checkpoint,
+                         files=sorted(f for f in os.listdir(a.checkpoint) if f.endswith((".safetensors", ".json"))),
+                         bytes=sum(os.path.getsize(os.path.join(a.checkpoint, f)) for f in os.listdir(a.checkpoint)))
     if a.seqs > 1:
         q_ms = time_batched(cfg, a, False, dev)
         d_ms = time_batched(cfg, a, True, dev)
@@ -122,15 +155,22 @@ def main():
                           "tokens_per_s_full_kv": a.seqs / (d_ms * 1e-3), "speedup": d_ms / q_ms}))
         return
     results = {}
+    gen_ms = {}
     for name, budget in (("quest", a.token_budget), ("dense", 1 << 24)):
-        with torch.device(dev):
-            model = LlamaForCausalLM(cfg).half()
-        for p in model.parameters():
-            p.data.normal_(0, 0.02)
-        for m in model.modules():
-            if hasattr(m, "variance_epsilon"):
-                m.weight.data.fill_(1.0)
-        model.quest_init(16, a.ctx + 256, budget)
+        if a.checkpoint:
+            import time
+            t0 = time.perf_counter()
+            model = LlamaForCausalLM.from_pretrained(a.checkpoint, device=dev)
+            ckpt_info["load_s"] = time.perf_counter() - t0
+        else:
+            with torch.device(dev):
+                model = LlamaForCausalLM(cfg).half()
+            for p in model.parameters():
+                p.data.normal_(0, 0.02)
+            for m in model.modules():
+                if hasattr(m, "variance_epsilon"):
+                    m.weight.data.fill_(1.0)
+        model.quest_init(16, a.ctx + 256 + a.generate, budget)
         ctl = model.model.iController
         g = torch.Generator(device=dev).manual_seed(1)
         D = a.hidden // a.heads
@@ -146,6 +186,20 @@ def main():
         del k, v
         emb = torch.randn(1, 1, a.hidden, generator=g, device=dev, dtype=torch.float16) * 0.1
         results[name] = time_decode(model, ctl, emb, a.reps)
+        if a.generate:
+            # greedy generation by one graph replay per token (device-resident lengths; the host only feeds the token)
+            import time
+            model.capture_decode_graph()
+            tok = torch.zeros(1, 1, dtype=torch.long, device=dev)
+            with torch.inference_mode():
+                for _ in range(3):
+                    tok = model.decode_graph_step(input_ids=tok).argmax(-1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.generate):
+                    tok = model.decode_graph_step(input_ids=tok).argmax(-1)
+                torch.cuda.synchronize()
+            gen_ms[name] = (time.perf_counter() - t0) * 1e3 / a.generate
         del model, ctl
         torch.cuda.empty_cache()
     out = {"bench": "e2e decode latency, random-weight Llama", "ctx": a.ctx, "token_budget": a.token_budget,
@@ -154,6 +208,13 @@ def main():
            "ms_per_token_quest": results["quest"], "ms_per_token_full_kv": results["dense"],
            "speedup": results["dense"] / results["quest"],
            "reference_published": "RTX 6000 Ada, ctx 32768 FP16: 36.8 ms -> 21.2 ms @ budget 2048 (1.74x)"}
+    if gen_ms:
+        out["generated_tokens"] = a.generate
+        out["ms_per_generated_token_quest"] = gen_ms["quest"]
+        out["ms_per_generated_token_full_kv"] = gen_ms["dense"]
+    if ckpt_info:
+        out["checkpoint"] = ckpt_info
+        out["bench"] = "e2e decode latency, Llama checkpoint in Hugging Face layout loaded with from_pretrained"
     print(json.dumps(out))
 
 

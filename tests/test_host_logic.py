@@ -274,3 +274,49 @@ def test_bench_byte_accounting_matches_survey():
     bg = bench.bytes_per_layer(g)
     assert abs(bg["estimate"] / MiB - 32.5) < 0.1 and abs(bg["attn"] / MiB - 64.05) < 0.05
     assert abs(bg["dense"] / MiB - 512) < 2             # GQA: every kv head read once
+
+
+def test_hf_checkpoint_round_trip_and_hf_interop(tmp_path):
+    """quest_amd.models.llama reads and writes the Hugging Face checkpoint layout (config.json + safetensors shards
+    + index, tensor names of quest/models/llama.py's HF fork): our export loads back bit for bit, transformers
+    reads it, and a checkpoint written BY transformers loads into our model tensor for tensor.  (CPU: IO only.)"""
+    import torch
+
+    from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(vocab_size=64, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+                      num_key_value_heads=1, rope_scaling={"type": "linear", "factor": 2.0}, rope_theta=5e5)
+    torch.manual_seed(0)
+    m = LlamaForCausalLM(cfg).half()
+    d = str(tmp_path / "ours")
+    m.save_pretrained(d, max_shard_bytes=600_000)  # forces several shards + model.safetensors.index.json
+    assert os.path.exists(os.path.join(d, "model.safetensors.index.json"))
+    m2 = LlamaForCausalLM.from_pretrained(d, device=torch.device("cpu"))
+    assert m2.config == cfg
+    for (ka, a), (kb, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
+    transformers = pytest.importorskip("transformers")
+    hf = transformers.LlamaForCausalLM.from_pretrained(d)
+    assert torch.equal(hf.state_dict()["model.layers.2.self_attn.k_proj.weight"].half(),
+                       m.state_dict()["model.layers.2.self_attn.k_proj.weight"])
+    # the other direction: a checkpoint exported by transformers itself (single file, rope_parameters nesting)
+    hcfg = transformers.LlamaConfig(vocab_size=96, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                    num_attention_heads=1, num_key_value_heads=1, max_position_embeddings=512,
+                                    tie_word_embeddings=True)
+    torch.manual_seed(1)
+    h2 = transformers.LlamaForCausalLM(hcfg).half()
+    d2 = str(tmp_path / "theirs")
+    h2.save_pretrained(d2, safe_serialization=True)
+    m3 = LlamaForCausalLM.from_pretrained(d2, device=torch.device("cpu"))
+    assert m3.config.num_hidden_layers == 2 and m3.config.rope_theta == 10000.0 and m3.config.rope_scaling is None
+    assert m3.lm_head.weight.data_ptr() == m3.model.embed_tokens.weight.data_ptr()  # tied embeddings honoured
+    hs = h2.state_dict()
+    for k, v in m3.state_dict().items():
+        assert torch.equal(v, hs[k]), k
+    # a tensor the decoder does not have is an error, not silently dropped
+    from safetensors.torch import load_file, save_file
+    sd = load_file(os.path.join(d2, "model.safetensors"))
+    sd["model.layers.0.self_attn.q_proj.bias"] = torch.zeros(128, dtype=torch.float16)
+    save_file(sd, os.path.join(d2, "model.safetensors"), metadata={"format": "pt"})
+    with pytest.raises(KeyError, match="unexpected tensor"):
+        LlamaForCausalLM.from_pretrained(d2, device=torch.device("cpu"))
