@@ -655,15 +655,21 @@ def main():
         if not stub:
             ctl0 = w.ctl.seqs[0] if batched else w.ctl
             out["config"]["seqlen_after_run"] = ctl0.kv_cache.seqlen
+            def pmc_traffic():
+                # HBM bytes (read + write) per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
+                # very command (profiles/r02_*_pmc_traffic.json, gfx950 FETCH_SIZE correction applied); None for shapes
+                # that were not profiled
+                tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+                if "custom" in a.workload_label and not (a.config == 3 and n_local == 8):
+                    return None
+                try:
+                    return json.load(open(tp))["sparse_decode_kernel_bytes_per_launch"].get(f"cfg{a.config}_seqs{n_local}")
+                except Exception:
+                    return None
+
             if w.dyn and not w.dense:
                 ops, roof = step_op_times(w, a, bpl)
-                tp = os.path.join(ROOT, "profiles", "traffic_latest.json")  # PMC bytes/launch from rocprofv3 --pmc runs
-                if os.path.exists(tp):
-                    try:
-                        key = f"cfg{a.config}_seqs{n_local}"
-                        roof["traffic"] = json.load(open(tp)).get("sparse_decode_kernel_bytes_per_launch", {}).get(key)
-                    except Exception:
-                        roof["traffic"] = None
+                roof["traffic"] = pmc_traffic()
                 out["roofline"], out["ops_us"] = roof, ops
             ref_ops, dense_us = reference_op_times(w, a, bpl)
             out["reference_op_sequence_us"] = ref_ops
@@ -671,7 +677,8 @@ def main():
                 ach = bpl["dense"] / (dense_us * 1e-6) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": "shared_decode_kernel (full-KV decode, K/V read once per kv head)",
                                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                   "traffic": None, "algorithmic_bytes_per_launch": bpl["dense"], "launch_us": dense_us}
+                                   "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": bpl["dense"],
+                                   "launch_us": dense_us}
             if dense_us is not None:
                 out["dense_full_kv_us"] = dense_us
                 out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
