@@ -15,7 +15,9 @@ layer of the model against that layer's own KV / metadata pools (so consecutive 
 different memory and the 256 MiB Infinity Cache cannot hold the working set).  Everything goes
 through the C ABI of libquest_hip.so; tokens/s is attention-only (no weights offline).
 Sequences are independent, so GPUs never exchange data inside a step; with N > 1 each step ends
-with one RCCL all_gather of the sampled token ids (weak scaling: the same sequences per GPU).
+with one RCCL all_gather of the sampled token ids (weak scaling: the same sequences per GPU).  (Measured
+over RCCL, world size 1: +1 % per step; issuing the gather asynchronously behind the next step was
+tried and is slower, +16 % -- the RCCL kernel then runs beside the step's kernels.)
 
 One JSON line on stdout (rank 0).  Extra objects: "roofline" (the dominant kernel OF THE TIMED STEP:
 sparse_decode_kernel with its top-k front end; algorithmic bytes / HIP-event launch time) and
