@@ -142,12 +142,12 @@ private:
 };
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {  // bsk_ops.cu:4-20 (the reference names the module _kernels)
-    m.def("apply_rope_in_place", &apply_rope_in_place, "Apply RoPE on Q/K in place.");
-    m.def("rms_norm_forward", &rms_norm_forward, "rms_norm_forward");
-    m.def("topk_filtering", &topk_filtering, "Top-k filtering operator");
-    m.def("estimate_attn_score", &estimate_attn_score, "Estimate Attention Score operator");
-    m.def("append_kv_cache_prefill", &append_kv_cache_prefill, "Append KV-Cache Prefill operator");
-    m.def("append_kv_cache_decode", &append_kv_cache_decode, "Append KV-Cache Decode operator");
+    m.def("apply_rope_in_place", &apply_rope_in_place, "rotate q and k rows in place (HIP)");
+    m.def("rms_norm_forward", &rms_norm_forward, "row-wise RMS normalisation (HIP)");
+    m.def("topk_filtering", &topk_filtering, "deterministic per-head top-k page selection (HIP)");
+    m.def("estimate_attn_score", &estimate_attn_score, "page criticality scores from (max, min) metadata (HIP)");
+    m.def("append_kv_cache_prefill", &append_kv_cache_prefill, "append many tokens + fold page metadata (HIP)");
+    m.def("append_kv_cache_decode", &append_kv_cache_decode, "append one token + fold page metadata (HIP)");
     py::class_<BatchDecodeWithPagedKVCachePyTorchWrapper>(m, "BatchDecodeWithPagedKVCachePyTorchWrapper")
         .def(py::init(&BatchDecodeWithPagedKVCachePyTorchWrapper::Create))
         .def("begin_forward", &BatchDecodeWithPagedKVCachePyTorchWrapper::BeginForward)

@@ -50,11 +50,20 @@ struct DecodeParams {
     const int32_t* indices;
     const uint16_t* scores;           // fused front end: [Hq][n_scores] fp16 estimate output
     const quest_step_state_t* state;  // optional device-resident lengths / current page (graph replay)
+    // dwords 10-15, still preloaded: what the first loads of the fused front end need besides the pointers (row
+    // stride and capacity of the score rows, table stride of a batch, which loads to issue)
+    uint32_t n_scores;      // fused top-k front end (FC > 0): `indices` is then the sequence's page table [n_scores + 1]
+    uint32_t score_stride;  // row stride of `scores`
+    uint32_t table_stride;  // batched launches (blockIdx.z = sequence): entries between page tables
+    uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
+    uint32_t vec_front;     // fused front end generation: 0 = first (topk_select.cuh), 2 = second (topk_bitmap.cuh;
+                            // needs 8-byte aligned score rows)
+    uint32_t idx_stride;
+    // ---- beyond the preloaded block (one scalar load of the argument segment)
     half_t* o;
     float* ws;  // [Hq][n_chunks][ws_stride] fp32 partial (acc[D], m, d)
     float* lse;
     PoolStrides st;
-    uint32_t idx_stride;
     uint32_t n_sel;
     uint32_t last_page_len;
     int32_t last_page_idx;
@@ -63,19 +72,12 @@ struct DecodeParams {
     uint32_t pages_per_chunk;
     uint32_t n_chunks;
     float scale_log2;  // 1/sqrt(D) * log2(e)
-    // fused top-k front end (FC > 0): `indices` is then the sequence's page table [n_scores + 1]
-    uint32_t n_scores;
     uint16_t* sel_val_out;   // optional [Hq][n_sel]
     int32_t* sel_idx_out;    // optional [Hq][n_sel]
     uint32_t ws_stride;  // floats per partial record (>= D + 2, multiple of 32 -> records own whole 128 B lines)
-    uint32_t score_stride;  // row stride of `scores`
-    uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
     uint32_t ids_lds_offset;
-    uint32_t table_stride;            // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
-    uint32_t vec_front;   // fused front end generation: 0 = first (topk_select.cuh), 2 = second (topk_bitmap.cuh;
-                          // needs 8-byte aligned score rows)
 };
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
@@ -924,7 +926,7 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
         return QUEST_EINVAL;
     if (kv.last_page_len == 0 || kv.last_page_len > kv.page_size) return QUEST_EINVAL;
-    DecodeParams p;
+    DecodeParams p{};
     p.q = (const half_t*)q;
     p.o = (half_t*)o;
     p.lse = lse;
