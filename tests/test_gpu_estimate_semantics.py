@@ -154,3 +154,22 @@ def test_ordered_metadata_unchanged_vs_append_built():
     ctl.end_forward()
     _, meta_o = oracle_pools(ctl, k, v)
     assert np.array_equal(U16(got), U16(oracle.estimate(q, meta_o)))
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(8, 8), (16, 4)])
+def test_fp16_denormal_metadata_and_queries(Hq, Hkv):
+    """fp16 subnormals (|x| < 6.1e-5) in the metadata and in q must not be flushed anywhere on the way (packed fp16
+    max/min, fp16 -> fp32 operands of the mixed FMA): pages whose entries are all subnormal give scores around
+    1e-4 that differ bit-wise if an input is flushed to zero."""
+    D, S, n_pages = 128, 16, 200
+    meta = _raw_meta(55 + Hq, n_pages, S, Hkv, D, 0)
+    rng = np.random.default_rng(Hq)
+    sub = (rng.integers(1, 1024, meta.data.shape).astype(np.uint16)            # subnormal magnitudes, random sign
+           | (rng.integers(0, 2, meta.data.shape).astype(np.uint16) << 15)).view(np.float16)
+    meta.data[meta.indices[::2]] = sub[meta.indices[::2]]                       # every other metadata page: all subnormal
+    q = np.random.default_rng(1).standard_normal((1, Hq, D), dtype=np.float32).astype(np.float16)
+    q[0, 1, ::3] = sub.reshape(-1)[: len(q[0, 1, ::3])]                         # subnormal (non-zero) query elements
+    got, exp = _run(q, meta), oracle.estimate(q, meta)
+    tiny = np.abs(exp.astype(np.float32)) < 1e-2
+    assert tiny.any() and (exp[tiny] != 0).any(), "the case must produce small non-zero scores"
+    _same(got, exp)
