@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/quest_hip.h"
 
 namespace quest {
@@ -74,6 +76,35 @@ __device__ __forceinline__ float dpp_f(float x) {
 }
 constexpr int kDppRowShr = 0x110, kDppRowRor = 0x120, kDppHalfMirror = 0x141, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
 constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
+
+// The value of the lane OFF lanes away (lane ^ OFF) without an LDS-crossbar trip: OFF = 8 is a DPP rotation inside
+// the 16-lane row; 16 and 32 use gfx950's row-swap instructions (v_permlane16_swap / v_permlane32_swap exchange the
+// odd 16- / 32-lane rows of one register with the even rows of another: with both operands = x, one of the two
+// results holds the partner's value in every lane).  ds_bpermute (what __shfl_xor compiles to) costs an LDS round
+// trip per call; these are one or two VALU instructions.
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float x, int lane) {
+    static_assert(OFF == 8 || OFF == 16 || OFF == 32, "lane distance");
+    if constexpr (OFF == 8) {
+        return dpp_f<kDppRowRor + 8>(x);
+    } else {
+        const unsigned xb = __builtin_bit_cast(unsigned, x);
+        uint2v r;
+        if constexpr (OFF == 16) r = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+        else r = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+        // r[0]: own even rows kept, odd rows replaced by the even rows; r[1]: the odd rows everywhere
+        return __builtin_bit_cast(float, (lane & OFF) ? r[0] : r[1]);
+    }
+}
+// Apply f(integral_constant<int, OFF>) for OFF = FROM, 2 FROM, ... < 64 (compile-time lane distances).
+template <int FROM, typename F>
+__device__ __forceinline__ void for_each_row_distance(F&& f) {
+    if constexpr (FROM < 64) {
+        f(std::integral_constant<int, FROM>{});
+        for_each_row_distance<FROM * 2>(f);
+    }
+}
 
 // Sum over the W lanes of a row, every lane gets the total, by DPP rotations (row_ror 8,4,2,1: one VALU
 // instruction per step).  The association order differs from the xor butterfly above.  The estimate kernel

@@ -407,16 +407,16 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
 
     QUEST_STAMP(6);
     // rows of the wave -> one state (xor butterfly across rows; both partners get the same bits)
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) {
-        const float m_o = __shfl_xor(st.m, off, kWave), d_o = __shfl_xor(st.d, off, kWave);
+    for_each_row_distance<LPR>([&](auto off_c) {
+        constexpr int OFF = decltype(off_c)::value;
+        const float m_o = lane_xor<OFF>(st.m, lane), d_o = lane_xor<OFF>(st.d, lane);
         const float m_n = __builtin_fmaxf(st.m, m_o);
         const float a = __builtin_amdgcn_exp2f(st.m - m_n), b = __builtin_amdgcn_exp2f(m_o - m_n);
         st.d = st.d * a + d_o * b;
 #pragma unroll
-        for (int i = 0; i < kVec; ++i) st.acc[i] = st.acc[i] * a + __shfl_xor(st.acc[i], off, kWave) * b;
+        for (int i = 0; i < kVec; ++i) st.acc[i] = st.acc[i] * a + lane_xor<OFF>(st.acc[i], lane) * b;
         st.m = m_n;
-    }
+    });
 
     // waves -> workgroup through LDS
     __shared__ float s_acc[NW][D];
@@ -551,16 +551,16 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
     __shared__ float s_md[NW][GS][2];
 #pragma unroll
     for (int g = 0; g < GS; ++g) {
-#pragma unroll
-        for (int off = LPR; off < kWave; off <<= 1) {  // rows of the wave -> one state
-            const float m_o = __shfl_xor(st[g].m, off, kWave), d_o = __shfl_xor(st[g].d, off, kWave);
+        for_each_row_distance<LPR>([&](auto off_c) {  // rows of the wave -> one state
+            constexpr int OFF = decltype(off_c)::value;
+            const float m_o = lane_xor<OFF>(st[g].m, lane), d_o = lane_xor<OFF>(st[g].d, lane);
             const float m_n = __builtin_fmaxf(st[g].m, m_o);
             const float a = __builtin_amdgcn_exp2f(st[g].m - m_n), b = __builtin_amdgcn_exp2f(m_o - m_n);
             st[g].d = st[g].d * a + d_o * b;
 #pragma unroll
-            for (int i = 0; i < kVec; ++i) st[g].acc[i] = st[g].acc[i] * a + __shfl_xor(st[g].acc[i], off, kWave) * b;
+            for (int i = 0; i < kVec; ++i) st[g].acc[i] = st[g].acc[i] * a + lane_xor<OFF>(st[g].acc[i], lane) * b;
             st[g].m = m_n;
-        }
+        });
         if (row == 0) {
 #pragma unroll
             for (int i = 0; i < kVec; ++i) s_acc[wave][g][col * kVec + i] = st[g].acc[i];

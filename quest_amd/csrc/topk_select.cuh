@@ -47,8 +47,9 @@ __device__ __forceinline__ void topk_publish_range(TopkSmem<NT>& sm, uint32_t mm
     v = (int)pk_max_u16((uint32_t)v, (uint32_t)dpp_i<kDppRowRor + 4>(v));
     v = (int)pk_max_u16((uint32_t)v, (uint32_t)dpp_i<kDppRowRor + 2>(v));
     v = (int)pk_max_u16((uint32_t)v, (uint32_t)dpp_i<kDppRowRor + 1>(v));
-    v = (int)pk_max_u16((uint32_t)v, (uint32_t)__shfl_xor(v, 16, kWave));
-    v = (int)pk_max_u16((uint32_t)v, (uint32_t)__shfl_xor(v, 32, kWave));
+    const int lane = threadIdx.x & 63;
+    v = (int)pk_max_u16((uint32_t)v, __builtin_bit_cast(uint32_t, lane_xor<16>(__builtin_bit_cast(float, v), lane)));
+    v = (int)pk_max_u16((uint32_t)v, __builtin_bit_cast(uint32_t, lane_xor<32>(__builtin_bit_cast(float, v), lane)));
     if ((threadIdx.x & 63) == 0) sm.wave_mm[threadIdx.x >> 6] = (uint32_t)v;
 }
 
