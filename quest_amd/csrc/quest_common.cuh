@@ -106,6 +106,25 @@ __device__ __forceinline__ void for_each_row_distance(F&& f) {
     }
 }
 
+// All-reduce over the 64 lanes of a wave (every lane gets the result) in six VALU steps: quad permutations for the
+// distances 1 and 2, half-row mirror for 4 (the quads are uniform by then), row rotation for 8, row swaps for 16, 32.
+template <typename Op>
+__device__ __forceinline__ float wave_allreduce(float x, int lane, Op op) {
+    x = op(x, dpp_f<kDppQuadXor1>(x));
+    x = op(x, dpp_f<kDppQuadXor2>(x));
+    x = op(x, dpp_f<kDppHalfMirror>(x));
+    x = op(x, dpp_f<kDppRowRor + 8>(x));
+    x = op(x, lane_xor<16>(x, lane));
+    x = op(x, lane_xor<32>(x, lane));
+    return x;
+}
+__device__ __forceinline__ float wave_allreduce_max(float x, int lane) {
+    return wave_allreduce(x, lane, [](float a, float b) { return __builtin_fmaxf(a, b); });
+}
+__device__ __forceinline__ float wave_allreduce_sum(float x, int lane) {
+    return wave_allreduce(x, lane, [](float a, float b) { return a + b; });
+}
+
 // Sum over the W lanes of a row, every lane gets the total, by DPP rotations (row_ror 8,4,2,1: one VALU
 // instruction per step).  The association order differs from the xor butterfly above.  The estimate kernel
 // uses THIS tree and the CPU oracle (qo_row_reduce) restates it, so their fp32 sums agree bit for bit; the

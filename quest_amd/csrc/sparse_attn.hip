@@ -627,18 +627,16 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
         // c's (m, d) -- so the only workgroup barrier is the final cross-group sum.
         const uint32_t lane = tid & 63, lc = lane < n_chunks ? lane : n_chunks - 1;
         const float m_c = w[(size_t)lc * ws_stride + D], d_c = w[(size_t)lc * ws_stride + D + 1];
-        float Mw = lane < n_chunks ? m_c : kNegFloor;
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) Mw = __builtin_fmaxf(Mw, __shfl_xor(Mw, off, kWave));
+        const float Mw = wave_allreduce_max(lane < n_chunks ? m_c : kNegFloor, (int)lane);
         const float e_c = lane < n_chunks ? __builtin_amdgcn_exp2f(m_c - Mw) : 0.f;
-        float dn = e_c * d_c;
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) dn += __shfl_xor(dn, off, kWave);
+        const float dn = wave_allreduce_sum(e_c * d_c, (int)lane);
         float a = 0.f;
+        const uint32_t g_u = __builtin_amdgcn_readfirstlane(g);  // a wave lies inside one group (D >= 64)
 #pragma unroll
         for (int j = 0; j < kPre; ++j) {
-            const uint32_t c = g + j * kMergeGroups;  // wave-uniform (a wave lies inside one group: D >= 64)
-            const float wc = __shfl(e_c, (int)(c < n_chunks ? c : 0), kWave);
+            const uint32_t c = g_u + j * kMergeGroups;  // wave-uniform: the chunk weight is a scalar broadcast
+            const float wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_c),
+                                                                               (int)(c < n_chunks ? c : 0)));
             if (c < n_chunks) a += wc * pre[j];
         }
         s_red[g][f] = a;
@@ -655,8 +653,7 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
     // pass 1: chunk maxima -> M, weights, denominator
     float M = kNegFloor;
     for (uint32_t c = tid; c < n_chunks; c += blockDim.x) M = __builtin_fmaxf(M, w[(size_t)c * ws_stride + D]);
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) M = __builtin_fmaxf(M, __shfl_xor(M, off, kWave));
+    M = wave_allreduce_max(M, (int)(tid & 63));
     if ((tid & 63) == 0) s_red[0][tid >> 6] = M;
     __syncthreads();
     if (tid == 0) {
@@ -683,8 +680,7 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
 #pragma unroll 8
     for (uint32_t c = g + kPre * kMergeGroups; c < n_chunks; c += kMergeGroups)
         acc += s_w[c] * w[(size_t)c * ws_stride + f];
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) den += __shfl_xor(den, off, kWave);
+    den = wave_allreduce_sum(den, (int)(tid & 63));
     s_red[g][f] = acc;
     __shared__ float s_den[16];
     if ((tid & 63) == 0) s_den[tid >> 6] = den;
