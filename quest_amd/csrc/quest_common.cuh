@@ -141,7 +141,7 @@ __device__ __forceinline__ float row_allreduce_sum_fast(float x) {
         x += dpp_f<kDppRowRor + 4>(x);
         x += dpp_f<kDppRowRor + 2>(x);
         x += dpp_f<kDppRowRor + 1>(x);
-        if constexpr (W == 32) x += __shfl_xor(x, 16, kWave);
+        if constexpr (W == 32) x += lane_xor<16>(x, (int)(threadIdx.x & 63));
     }
     return x;
 }
