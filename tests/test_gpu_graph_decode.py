@@ -171,8 +171,8 @@ def test_state_advance_stops_at_pool_capacity():
         ctl.prepare_metadata(1)
 
 
-@pytest.mark.parametrize("L0", [5, 16, 40])
-def test_graph_decode_from_short_context_into_the_sparse_regime(L0):
+@pytest.mark.parametrize("L0,cap", [(5, 0), (16, 0), (40, 0), (23, 72000)])
+def test_graph_decode_from_short_context_into_the_sparse_regime(L0, cap):
     """ONE graph captured while the sequence is still shorter than the page budget (down to a single page):
     it attends all pages (the reference's full-attention branch) and slides into the sparse regime as the
     sequence grows.  Reference: the eager host-planned path, which switches branches by itself."""
@@ -187,7 +187,10 @@ def test_graph_decode_from_short_context_into_the_sparse_regime(L0):
     new_v = torch.randn(steps, layers, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
 
     def prefilled():
-        ctl = make_controller(L0 + steps + 40, Hq, Hkv, D, PAGE, B, num_layers=layers, max_seq_len=L0 + steps + 40)
+        # cap: a pool sized for a long request (4500 pages of capacity -> the state-driven launch is dispatched for
+        # 4499-column rows, i.e. the second-generation front end by default) holding a very short live sequence
+        ctl = make_controller(L0 + steps + 40, Hq, Hkv, D, PAGE, B, num_layers=layers,
+                              max_seq_len=max(cap, L0 + steps + 40))
         ctl.prepare_metadata(L0)
         ctl.begin_forward(L0)
         for l in range(layers):
@@ -222,7 +225,9 @@ def test_graph_decode_from_short_context_into_the_sparse_regime(L0):
     kbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     vbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     scores = qu.score_scratch(gr)
-    gr._decode_handler.set_front_end(2)  # second-generation front end, from a one-page sequence into the sparse regime
+    # second-generation front end, from a one-page sequence into the sparse regime (forced for the small pools; the
+    # long-capacity case takes it by default)
+    gr._decode_handler.set_front_end(0 if cap else 2)
     obuf = [None] * layers
 
     def step():
