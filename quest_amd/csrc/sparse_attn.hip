@@ -56,8 +56,8 @@ struct DecodeParams {
     uint32_t score_stride;  // row stride of `scores`
     uint32_t table_stride;  // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
-    uint32_t vec_front;     // fused front end generation: 0 = first (topk_select.cuh), 2 = second (topk_bitmap.cuh;
-                            // needs 8-byte aligned score rows)
+    uint32_t vec_front;     // fused front end: 0 = first generation (topk_select.cuh), 1 = the same fed by 8/16-byte
+                            // granule loads, 2 = second generation (topk_bitmap.cuh); 1 and 2 need aligned score rows
     uint32_t idx_stride;
     // ---- beyond the preloaded block (one scalar load of the argument segment)
     half_t* o;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
         }
         const uint32_t n = p.n_scores;
-        if (n > 0 && p.vec_front) {
+        if (n > 0 && p.vec_front == 2) {
             QUEST_STAMP(1);
             const size_t out_row = ((size_t)blockIdx.z * gridDim.y + hq) * p.sel_stride;
             const bool ids_staged = p.stage_ids && fe2_has_ids(FC);
@@ -252,6 +252,12 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             const bool stage_ids = p.stage_ids != 0;
             int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
             uint32_t key[FC];
+            uint32_t mm = kMmNeutral;
+            if (p.vec_front == 1) {
+                // aligned score rows: the granule loads issued at the top of the kernel (fe2_issue) feed the staging arrays
+                if constexpr (fe2_has_ids(FC)) mm = fe1_stage_vector<NT, FC / 4>(raw, keys_s, stage_ids ? ids_s : nullptr, n_cap, n);
+                QUEST_STAMP(1);
+            } else {
             // coalesced loads (element t + i*NT), parked in LDS as keys (+ page ids when they fit)
             uint16_t kraw[FC];
             int32_t iraw[FC];
@@ -272,7 +278,6 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             }
             topk_clear<NT>(sm);  // overlaps the score / page-id loads above
             QUEST_STAMP(1);
-            uint32_t mm = kMmNeutral;
 #pragma unroll
             for (int i = 0; i < FC; ++i) {
                 const uint32_t e = threadIdx.x + i * NT;
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                     keys_s[e] = (uint16_t)kk;
                     if (stage_ids) ids_s[e] = iraw[i];
                 }
+            }
             }
             topk_publish_range<NT>(sm, mm);
             QUEST_STAMP(2);
@@ -971,11 +977,13 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
             if (forced == 2 || (forced == 0 && n_scores > 4096u)) gen = 2;
         }
         if (gen != 1) {
-            p.vec_front = (uint32_t)gen;
+            p.vec_front = 2;
             p.ids_lds_offset = 0;  // no key staging
             // page ids are staged with 16-byte loads: the table(s) must be 16-byte aligned
             if (!table_aligned) p.stage_ids = 0;
             // (gen 2 stages ids only in the instantiations with <= 16 keys per thread: rows <= 4096 columns)
+        } else if (aligned && table_aligned && p.stage_ids && forced != 1) {
+            p.vec_front = 1;  // generation 1 with its staging arrays filled by the granule loads (8 / 16 bytes per lane)
         }
     }
     // rows beyond 4096 columns are served by the second-generation front end only (the first one spills there):

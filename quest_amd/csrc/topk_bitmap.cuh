@@ -87,6 +87,41 @@ __device__ __forceinline__ uint32_t key_at(const uint32_t (&key2)[N], int i) {
     return (i & 1) ? key2[i >> 1] >> 16 : key2[i >> 1] & 0xffffu;
 }
 
+// First-generation front end fed by the vector loads of fe2_issue (aligned score rows): converts the granules to keys,
+// parks keys (8 bytes per granule) and page ids (16 bytes) in the LDS staging arrays topk_select.cuh reads its
+// contiguous ownership from, and returns the thread's packed (max, 0xffff - min) key range.  2 load rounds instead of
+// the 5 scalar ones at 2179 columns of capacity x 512 threads.
+template <int NT, int RMAX>
+__device__ __forceinline__ uint32_t fe1_stage_vector(const Fe2Raw<true> (&raw)[RMAX], uint16_t* keys_s, int32_t* ids_s,
+                                                     uint32_t n_cap, uint32_t n) {
+    const uint32_t rounds = (n_cap + 4 * NT - 1) / (4 * NT);
+    uint32_t pmax = 0u, pmin = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+        if ((uint32_t)r < rounds) {
+            const uint32_t c0 = 4u * (threadIdx.x + (uint32_t)r * NT);
+            if (c0 < n_cap) {
+                const uint32_t k0 = half_key2(raw[r].k.x), k1 = half_key2(raw[r].k.y);
+                *reinterpret_cast<uint2*>(keys_s + c0) = make_uint2(k0, k1);
+                if (ids_s) *reinterpret_cast<uint4*>(ids_s + c0) = raw[r].ids;
+                if (c0 + 3u < n) {
+                    pmax = pk_max_u16(pmax, pk_max_u16(k0, k1));
+                    pmin = pk_min_u16(pmin, pk_min_u16(k0, k1));
+                } else {
+                    const uint32_t kk[4] = {k0 & 0xffffu, k0 >> 16, k1 & 0xffffu, k1 >> 16};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (c0 + i < n) {
+                            pmax = pk_max_u16(pmax, kk[i]);
+                            pmin = pk_min_u16(pmin, kk[i] | 0xffff0000u);
+                        }
+                }
+            }
+        }
+    const uint32_t xl = pmax & 0xffffu, xh = pmax >> 16, nl = pmin & 0xffffu, nh = pmin >> 16;
+    return ((xl > xh ? xl : xh) << 16) | (0xffffu - (nl < nh ? nl : nh));
+}
+
 // OR over the 8 lanes of an aligned lane octet; every lane of the octet gets the result.
 __device__ __forceinline__ uint32_t octet_or(uint32_t x) {
     x |= (uint32_t)dpp_i<kDppQuadXor1>((int)x);
