@@ -56,10 +56,13 @@ struct DecodeParams {
     uint32_t score_stride;  // row stride of `scores`
     uint32_t table_stride;  // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
-    uint32_t vec_front;     // fused front end: 0 = first generation (topk_select.cuh), 1 = the same fed by 8/16-byte
-                            // granule loads, 2 = second generation (topk_bitmap.cuh); 1 and 2 need aligned score rows
-    uint32_t idx_stride;
+    uint32_t vec_front;     // fused front end: 0 = first generation (topk_select.cuh); 1 = the same, staging arrays fed by
+                            // 8/16-byte granule loads; 3 = the same, each thread loads its OWN cpt (4 or 8) columns and
+                            // page ids straight into registers (no LDS staging); 2 = second generation
+                            // (topk_bitmap.cuh).  1-3 need aligned score rows
+    uint32_t cpt;           // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
     // ---- beyond the preloaded block (one scalar load of the argument segment)
+    uint32_t idx_stride;
     half_t* o;
     float* ws;  // [Hq][n_chunks][ws_stride] fp32 partial (acc[D], m, d)
     float* lse;
@@ -76,7 +79,6 @@ struct DecodeParams {
     int32_t* sel_idx_out;    // optional [Hq][n_sel]
     uint32_t ws_stride;  // floats per partial record (>= D + 2, multiple of 32 -> records own whole 128 B lines)
     uint32_t ids_lds_offset;
-    uint32_t cpt;     // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
 };
 
@@ -208,7 +210,33 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
         Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
-        if (p.vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
+        uint4 own_keys = make_uint4(0u, 0u, 0u, 0u), own_ids[2] = {own_keys, own_keys};  // vec_front == 3
+        if (FC == 8 && p.vec_front == 3) {
+            // the thread's own contiguous columns: 16 bytes of scores per lane (8 at 4 columns per thread) -- a coalesced
+            // sweep of the row -- and their page ids, all of it kept in registers
+            const uint32_t c0 = threadIdx.x * p.cpt, cc = c0 < n_cap ? c0 : 0u, table_len = n_cap + 1u;
+            if (p.cpt == 8) {
+                own_keys = *reinterpret_cast<const uint4*>(srow + cc);
+            } else {
+                const uint2 k2 = *reinterpret_cast<const uint2*>(srow + cc);
+                own_keys.x = k2.x, own_keys.y = k2.y;
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if ((uint32_t)(4 * g) < p.cpt) {
+                    const uint32_t c = cc + 4u * g;
+                    if (c + 4u <= table_len) {
+                        own_ids[g] = *reinterpret_cast<const uint4*>(sv.indices + c);
+                    } else {  // tail of a table whose length is not a multiple of 4
+                        const uint32_t last = table_len - 1u;
+                        own_ids[g].x = (uint32_t)sv.indices[c < last ? c : last];
+                        own_ids[g].y = (uint32_t)sv.indices[c + 1u < last ? c + 1u : last];
+                        own_ids[g].z = (uint32_t)sv.indices[c + 2u < last ? c + 2u : last];
+                        own_ids[g].w = (uint32_t)sv.indices[c + 3u < last ? c + 3u : last];
+                    }
+                }
+            fe2_clear<NT>(sm);
+        } else if (p.vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
             fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
             fe2_clear<NT>(sm);
         }
@@ -253,7 +281,16 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
             uint32_t key[FC];
             uint32_t mm = kMmNeutral;
-            if (p.vec_front == 1) {
+            const bool direct = FC == 8 && p.vec_front == 3;  // keys / ids already in this thread's registers
+            if (direct) {
+                const uint32_t w[4] = {own_keys.x, own_keys.y, own_keys.z, own_keys.w};
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    key[i] = i < 8 ? half_key((uint16_t)((i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu)) : 0u;
+                    if ((uint32_t)i < cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
+                }
+                QUEST_STAMP(1);
+            } else if (p.vec_front == 1) {
                 // aligned score rows: the granule loads issued at the top of the kernel (fe2_issue) feed the staging arrays
                 if constexpr (fe2_has_ids(FC)) mm = fe1_stage_vector<NT, FC / 4>(raw, keys_s, stage_ids ? ids_s : nullptr, n_cap, n);
                 QUEST_STAMP(1);
@@ -293,7 +330,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             QUEST_STAMP(2);
             __syncthreads();
             QUEST_STAMP(3);
-            topk_load_keys<FC>(keys_s, c0, n, cpt, key);
+            if (!direct) topk_load_keys<FC>(keys_s, c0, n, cpt, key);
 #ifdef QUEST_TIMELINE
             long long sub[9] = {};
             TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, sub);
@@ -315,7 +352,10 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                     // two separate loads: a select between an LDS and a global ADDRESS becomes one flat load
                     // whose address-space cast this compiler miscompiles (illegal v_cmp on src_shared_base)
                     int32_t pg;
-                    if (stage_ids) {
+                    if (direct) {
+                        const uint4 q4 = own_ids[(i >> 2) & 1];
+                        pg = (int32_t)((i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w);
+                    } else if (stage_ids) {
                         pg = ids_s[c0 + i];
                     } else {
                         pg = table[c0 + i];
@@ -1007,6 +1047,16 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         // 8/16-byte LDS read (topk_load_keys)
         const uint32_t r4 = (per_thread + 3) / 4 * 4;
         p.cpt = r4 <= (uint32_t)fc ? r4 : per_thread;
+        // rows of <= 8 columns per thread with vector-loadable chunks: each thread takes its own columns and page ids
+        // straight into registers (no staging arrays).  Measured (us per launch, staged -> direct): cfg 3 12.79 ->
+        // 12.38; 8 sequences batched 48.6 -> 48.85, cfg 5 51.2 -> 51.2 -> single-sequence launches only.
+        // QUEST_FE1_DIRECT=0 keeps the staged variant, =2 takes the direct one for batches too (tuning, tests).
+        static const int direct_env = [] { const char* e = getenv("QUEST_FE1_DIRECT"); return e ? atoi(e) : 1; }();
+        const bool direct_ok = direct_env == 2 || (direct_env == 1 && batch.n_seqs == 1);
+        if (p.vec_front == 1 && fc == 8 && direct_ok &&
+            (p.cpt == 4 || (p.cpt == 8 && ((uintptr_t)scores & 15u) == 0 && p.score_stride % 8u == 0 &&
+                            p.score_stride >= ((n_scores + 7u) & ~7u))))
+            p.vec_front = 3;
     }
     switch (kv.head_dim) {
         case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
