@@ -203,6 +203,25 @@ int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q
                                         uint32_t max_n_scores, const quest_step_state_t* state, float* lse,
                                         quest_stream_t stream);
 
+/* Chained launch: quest_append_estimate_dyn + quest_decode_forward_fused_topk_dyn of one sequence as ONE grid (plus the
+ * merge launch): the attention workgroups of a head group start as soon as that group's scores are complete, while the
+ * metadata of the other groups is still streaming (sparse_attn.hip, chain_kernel).  Same operands and the same results,
+ * bit for bit, as the two calls: the ops it chains are quest/ops/csrc/page.cu:86-148 (append_kv_cache_decode),
+ * estimate.cu:5-45, topk.cu:5-38 and approx_attn.cu:100-147.  `scores` is the [num_qo_heads][score_stride] fp16
+ * scratch (written, then read, inside the launch).  Page size 16, head_dim 128, group size 1 or 4, rows of more than
+ * 1024 pages; QUEST_EUNSUPPORTED otherwise (callers then issue the two calls). */
+int quest_chain_decode_dyn(quest_decode_handler_t* h, const void* k, const void* v, quest_paged_kv_t kv, const void* q,
+                           void* scores, uint32_t score_stride, uint32_t max_n_out, quest_paged_kv_t metadata, void* o,
+                           uint32_t num_qo_heads, const quest_step_state_t* state, float* lse, quest_stream_t stream);
+/* Tuning aid: head groups whose estimate is dispatched ahead of the first attention group (0 = default). */
+int quest_decode_set_chain_lead(quest_decode_handler_t* h, int lead);
+/* 1 if a chained launch on this handler ever gave up waiting for its producers (never expected; synchronises). */
+int quest_chain_error(quest_decode_handler_t* h);
+
+/* Developer aid: per-workgroup wall-clock stamps of the last chained launch (4 int64 per workgroup: role << 32 | group,
+ * start, past the wait / work done, end); QUEST_EUNSUPPORTED unless the library was built with -DQUEST_CHAIN_TRACE. */
+int quest_chain_trace(quest_decode_handler_t* h, long long* out, uint32_t n_blocks);
+
 /* quest_append_kv_cache_decode with lengths / last-page ids from `state` (dense layers of a replayed step). */
 int quest_append_kv_cache_decode_dyn(const void* k, const void* v, quest_paged_kv_t kv, quest_paged_kv_t metadata,
                                      const quest_step_state_t* state, quest_stream_t stream);

@@ -23,6 +23,7 @@
 #include <new>
 #include <vector>
 
+#include "estimate_device.cuh"
 #include "topk_bitmap.cuh"
 
 // Developer aid (scripts/timeline.py): -DQUEST_TIMELINE makes one workgroup of sparse_decode_kernel write
@@ -95,8 +96,9 @@ struct SeqView {
     float* ws;
     const quest_step_state_t* state;
 };
-__device__ __forceinline__ SeqView select_sequence(const DecodeParams& p, uint32_t num_qo_heads, uint32_t head_dim) {
-    const size_t seq = blockIdx.z, row = seq * num_qo_heads;
+__device__ __forceinline__ SeqView select_sequence(const DecodeParams& p, uint32_t num_qo_heads, uint32_t head_dim,
+                                                   uint32_t seq_index) {
+    const size_t seq = seq_index, row = seq * num_qo_heads;
     SeqView v;
     v.q = p.q + row * head_dim;
     v.o = p.o + row * head_dim;
@@ -150,6 +152,79 @@ __device__ __forceinline__ void fold_groups(RowState<D>& st, const float8& qv, c
     st.m = m_new;
 }
 
+constexpr uint32_t kChainReplicas = 16, kChainLineWords = 32;  // see ChainWait
+#ifdef QUEST_CHAIN_TRACE  // developer aid (scripts/chain_trace.py): per workgroup {role/group, start, past the wait, end} wall-clock stamps
+constexpr uint32_t kChainTraceBlocks = 4096;
+constexpr uint32_t kChainMaxGroups = 32, kChainCounterWords = kChainMaxGroups * kChainReplicas * kChainLineWords, kChainSyncWords = kChainCounterWords + 2 + 8 * kChainTraceBlocks;
+#define QUEST_CHAIN_STAMP(slot)                                                                          \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < kChainTraceBlocks)                                          \
+            reinterpret_cast<long long*>(cw.error + 2)[4 * blockIdx.x + (slot)] = wall_clock64();        \
+    } while (0)
+#define QUEST_CHAIN_ROLE(role, group)                                                                    \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < kChainTraceBlocks)                                          \
+            reinterpret_cast<long long*>(cw.error + 2)[4 * blockIdx.x] = ((long long)(role) << 32) | (group); \
+    } while (0)
+#else
+constexpr uint32_t kChainMaxGroups = 32, kChainCounterWords = kChainMaxGroups * kChainReplicas * kChainLineWords, kChainSyncWords = kChainCounterWords + 2;
+#define QUEST_CHAIN_STAMP(slot) \
+    do { } while (0)
+#define QUEST_CHAIN_ROLE(role, group) \
+    do { } while (0)
+#endif
+
+// Chained launch (chain_kernel below): the estimate and the attention of a step run in ONE grid.  Workgroups are
+// dispatched in index order; the estimate (and append) workgroups of a head group come before the attention
+// workgroups that consume their scores and never wait for anything.  Hand-off, built from what was measured on MI355X
+// (scripts/chain_trace.py):
+//   * a device-scope RELEASE fence writes back the XCD's whole L2 (`buffer_wbl2 sc1`): ~8 us per workgroup, serialised
+//     -> 28 us per launch.  So the producers' data (scores; the appended token) leave by write-through stores
+//     (relaxed agent-scope atomic stores, `sc1`), each wave waits for its own stores to complete (`s_waitcnt`), the
+//     workgroup meets at a barrier, and only then are the counters bumped (relaxed, no fence);
+//   * several hundred workgroups polling ONE word queue up behind each other at its memory channel (4-6 us per poll,
+//     and the estimate's own loads to that channel wait in the same queue) -> every group's counter exists in
+//     kChainReplicas copies on separate 128-byte lines; producers bump all of them, a consumer polls one;
+//   * a consumer's first thread polls (bounded: a stuck grid sets *error and carries on instead of hanging the GPU),
+//     then an ACQUIRE fence (`buffer_inv sc1`, cheap) and a workgroup barrier;
+//   * the counters are re-armed by the merge launch that follows (kernel boundary), so nothing is counted twice.
+struct ChainWait {
+    uint32_t* done;      // [groups][kChainReplicas] counters, one 128-byte line each
+    uint32_t* error;     // set to 1 when a wait timed out
+    uint32_t target;     // producers per group (estimate workgroups of the group + append workgroups)
+};
+#ifndef QUEST_CHAIN_SLEEP
+#define QUEST_CHAIN_SLEEP 4  // x 64 cycles between two polls of the counter
+#endif
+constexpr long long kChainTimeoutTicks = 5000000;  // 50 ms of the 100 MHz wall clock
+
+__device__ __forceinline__ uint32_t* chain_counter(const ChainWait& cw, uint32_t group, uint32_t replica) {
+    return cw.done + ((size_t)group * kChainReplicas + replica) * kChainLineWords;
+}
+// all threads of a producer workgroup, after their last write-through store
+__device__ __forceinline__ void chain_signal(const ChainWait& cw, uint32_t group_begin, uint32_t group_end) {
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have completed (device-wide: they are write-through)
+    __syncthreads();
+    if (threadIdx.x < kChainReplicas)
+        for (uint32_t g = group_begin; g < group_end; ++g)
+            __hip_atomic_fetch_add(chain_counter(cw, g, threadIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_wait(const ChainWait& cw, uint32_t group) {
+    if (threadIdx.x == 0) {
+        uint32_t* flag = chain_counter(cw, group, blockIdx.x % kChainReplicas);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cw.target) {
+            __builtin_amdgcn_s_sleep(QUEST_CHAIN_SLEEP);
+            if (wall_clock64() - t0 > kChainTimeoutTicks) {
+                *cw.error = 1u;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
 // S_T = compile-time page size (16) or 0 for the generic run-time path.
 //
 // Addressing: the (page, kv head) tile base is wave-uniform (page id through readfirstlane -> SGPR
@@ -162,20 +237,24 @@ __device__ __forceinline__ void fold_groups(RowState<D>& st, const float8& qv, c
 // kernel, hence the same pages), and the columns whose output slot falls in this workgroup's chunk
 // drop their physical page id into LDS.  All workgroups of a head repeat the (cheap, L2-resident)
 // selection instead of waiting for one another.
-template <int D, int S_T, int FC, int NW>
-__global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(DecodeParams p) {
+//
+// The body is a device function so that the chained launch can run it as one role of a larger grid: (chunk, hq, seq)
+// are the workgroup's coordinates, CHAIN = wait for the head group's scores (chain_wait) before touching them.
+template <int D, int S_T, int FC, int NW, bool CHAIN>
+__device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_t chunk, const uint32_t hq, const uint32_t seq,
+                                                   const uint32_t num_qo_heads, const ChainWait& cw, const uint32_t wait_group) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
     // wave index as an SGPR so per-wave control flow below is scalar branching
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
-    const uint32_t chunk = blockIdx.x, hq = blockIdx.y, hk = hq / p.group;
+    const uint32_t hk = hq / p.group;
 #ifdef QUEST_TIMELINE
     long long tl[10] = {};
     long long sub_out[9] = {};
     const long long wall0 = wall_clock64();
     QUEST_STAMP(0);
 #endif
-    const SeqView sv = select_sequence(p, gridDim.y, D);
+    const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
     // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
     // row length comes from the state
     if (FC == 0 && p.state) {  // no front end, state-driven: full-KV decode of shapes the group-shared kernel
@@ -211,20 +290,16 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
         Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
         uint4 own_keys = make_uint4(0u, 0u, 0u, 0u), own_ids[2] = {own_keys, own_keys};  // vec_front == 3
-        if (FC == 8 && p.vec_front == 3) {
-            // the thread's own contiguous columns: 16 bytes of scores per lane (8 at 4 columns per thread) -- a coalesced
-            // sweep of the row -- and their page ids, all of it kept in registers
-            const uint32_t c0 = threadIdx.x * p.cpt, cc = c0 < n_cap ? c0 : 0u, table_len = n_cap + 1u;
-            if (p.cpt == 8) {
-                own_keys = *reinterpret_cast<const uint4*>(srow + cc);
-            } else {
-                const uint2 k2 = *reinterpret_cast<const uint2*>(srow + cc);
-                own_keys.x = k2.x, own_keys.y = k2.y;
-            }
+        const bool own_cols = FC == 8 && p.vec_front == 3;
+        // the thread's own contiguous columns (vec_front 3): their page ids (1-2 x 16 bytes) and 16 bytes of scores per
+        // lane (8 at 4 columns per thread) -- a coalesced sweep of the row -- all of it kept in registers
+        const uint32_t own_c0 = threadIdx.x * p.cpt, own_cc = own_c0 < n_cap ? own_c0 : 0u;
+        if (own_cols) {
+            const uint32_t table_len = n_cap + 1u;
 #pragma unroll
             for (int g = 0; g < 2; ++g)
                 if ((uint32_t)(4 * g) < p.cpt) {
-                    const uint32_t c = cc + 4u * g;
+                    const uint32_t c = own_cc + 4u * g;
                     if (c + 4u <= table_len) {
                         own_ids[g] = *reinterpret_cast<const uint4*>(sv.indices + c);
                     } else {  // tail of a table whose length is not a multiple of 4
@@ -235,6 +310,21 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
                         own_ids[g].w = (uint32_t)sv.indices[c + 3u < last ? c + 3u : last];
                     }
                 }
+        }
+        // chained launch: everything above is independent of the estimate; the score row (and the appended token's
+        // K/V further down) is not
+        if constexpr (CHAIN) {
+            QUEST_CHAIN_STAMP(1);
+            chain_wait(cw, wait_group);
+            QUEST_CHAIN_STAMP(2);
+        }
+        if (own_cols) {
+            if (p.cpt == 8) {
+                own_keys = *reinterpret_cast<const uint4*>(srow + own_cc);
+            } else {
+                const uint2 k2 = *reinterpret_cast<const uint2*>(srow + own_cc);
+                own_keys.x = k2.x, own_keys.y = k2.y;
+            }
             fe2_clear<NT>(sm);
         } else if (p.vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
             fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
@@ -252,7 +342,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
         const uint32_t n = p.n_scores;
         if (n > 0 && p.vec_front == 2) {
             QUEST_STAMP(1);
-            const size_t out_row = ((size_t)blockIdx.z * gridDim.y + hq) * p.sel_stride;
+            const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
             const bool ids_staged = p.stage_ids && fe2_has_ids(FC);
             uint16_t* val_row = p.sel_val_out ? p.sel_val_out + out_row : nullptr;
             int32_t* idx_row_out = p.sel_idx_out ? p.sel_idx_out + out_row : nullptr;
@@ -281,7 +371,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             int32_t* ids_s = reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset);
             uint32_t key[FC];
             uint32_t mm = kMmNeutral;
-            const bool direct = FC == 8 && p.vec_front == 3;  // keys / ids already in this thread's registers
+            const bool direct = own_cols;  // keys / ids already in this thread's registers
             if (direct) {
                 const uint32_t w[4] = {own_keys.x, own_keys.y, own_keys.z, own_keys.w};
 #pragma unroll
@@ -369,7 +459,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
             // optional copy of the selection for callers that inspect it: issued after the barrier so no
             // workgroup waits on these stores before it starts fetching K/V
             if (p.sel_idx_out) {
-                const size_t out_row = ((size_t)blockIdx.z * gridDim.y + hq) * p.sel_stride;
+                const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
 #pragma unroll
                 for (int i = 0; i < FC; ++i)
                     if (mine[i]) {
@@ -504,13 +594,111 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(Decode
     }
 #ifdef QUEST_TIMELINE
     QUEST_STAMP(9);
-    if (p.lse && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && threadIdx.x == 0) {
+    if (p.lse && chunk == p.n_chunks / 2 && hq == num_qo_heads / 2 && seq == 0 && threadIdx.x == 0) {
         for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
         if constexpr (FC > 0)
             for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
         p.lse[10] = (float)(wall_clock64() - wall0);  // 100 MHz ticks over the same span as tl[9] - tl[0]
     }
 #endif
+}
+
+template <int D, int S_T, int FC, int NW>
+__global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(DecodeParams p) {
+    sparse_decode_body<D, S_T, FC, NW, false>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, ChainWait{}, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chained launch: append + estimate + top-k + attention of one decode step of one sequence in ONE grid (the merge
+// stays a second launch).  The idea: a dependent kernel boundary costs ~1.5 us + ~1.3 us until the next kernel's first
+// data arrives, and after it every workgroup of the attention launch does its page selection at the same time, with the
+// HBM idle.  Here the workgroups are laid out in dispatch order as
+//     append | estimate of head groups 0..L-1 | attention g0, estimate gL | attention g1, estimate gL+1 | ... |
+//     attention of the remaining groups
+// (a head group = the kv heads of one estimate tile column, `tile_heads` of them), so the attention of a group can start
+// as soon as ITS scores are complete.  See ChainWait for the hand-off.  Page size 16, 8 waves per workgroup; an estimate
+// workgroup runs two 4-wave tiles.
+// MEASURED (profiles/r02_chain_trace_cfg3.log): bit-identical to the two launches, and not faster -- cfg 3
+// 25.9 us per layer against 23.5.  The hand-off itself is down to ~1 us, but at 115 VGPRs only two 8-wave workgroups fit a
+// CU, so estimate and attention cannot be resident together: L < groups only parks waiting attention workgroups in slots
+// the estimate needs.  Kept as an opt-in (QUEST_CHAIN=1) with its parity tests.
+struct ChainPlan {
+    uint32_t n_app;        // append workgroups (first in the grid)
+    uint32_t n_groups;     // head groups = num_kv_heads / tile_heads
+    uint32_t lead;         // estimate groups dispatched ahead of the first attention group (1..n_groups)
+    uint32_t est_blocks;   // estimate workgroups per group
+    uint32_t attn_blocks;  // attention workgroups per group = tile_heads * group size * chunks
+    uint32_t entry_tiles;  // estimate tiles per group along the entries
+};
+
+constexpr int kChainWaves = 8, kChainTiles = 2;  // waves per workgroup; estimate tiles per workgroup
+
+template <int D, int G, bool HND, int FC>
+__global__ __launch_bounds__(kChainWaves* kWave, kChainWaves / 2) void chain_kernel(const half_t* __restrict__ q, half_t* scores,
+                                                                                     quest_paged_kv_t meta, uint32_t n_out,
+                                                                                     AppendTail tail, DecodeParams p, ChainPlan cp,
+                                                                                     ChainWait cw) {
+    constexpr int NT = kChainWaves * kWave, EWV = kChainWaves / kChainTiles;
+    uint32_t b = blockIdx.x;
+    if (b < cp.n_app) {  // ---- append: the current page's K/V entry and metadata entry
+        const quest_step_state_t st = *tail.state;
+        meta.last_page_len = (uint32_t)st.meta_last_page_len;
+        meta.last_page_idx = st.meta_last_page_idx;
+        tail.kv.last_page_len = (uint32_t)st.kv_last_page_len;
+        tail.kv.last_page_idx = st.kv_last_page_idx;
+        QUEST_CHAIN_ROLE(2, 0);
+        QUEST_CHAIN_STAMP(1);
+        append_decode_body<true>(tail.kv, meta, tail.key, tail.value, b * NT + threadIdx.x);
+        QUEST_CHAIN_STAMP(2);
+        chain_signal(cw, 0, cp.n_groups);  // every group's attention reads the new token
+        QUEST_CHAIN_STAMP(3);
+        return;
+    }
+    b -= cp.n_app;
+    // role of this workgroup
+    bool is_est;
+    uint32_t group, idx;
+    const uint32_t head = cp.lead * cp.est_blocks, pair = cp.attn_blocks + cp.est_blocks,
+                   mid = (cp.n_groups - cp.lead) * pair;
+    if (b < head) {
+        is_est = true, group = b / cp.est_blocks, idx = b % cp.est_blocks;
+    } else if (b - head < mid) {
+        const uint32_t i = (b - head) / pair, r = (b - head) % pair;
+        is_est = r >= cp.attn_blocks;
+        group = is_est ? cp.lead + i : i;
+        idx = is_est ? r - cp.attn_blocks : r;
+    } else {
+        const uint32_t r = b - head - mid;
+        is_est = false, group = cp.n_groups - cp.lead + r / cp.attn_blocks, idx = r % cp.attn_blocks;
+    }
+    QUEST_CHAIN_ROLE(is_est ? 1 : 0, group);
+    if (is_est) {  // ---- estimate: kChainTiles tiles of head group `group`
+        QUEST_CHAIN_STAMP(1);
+        extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+        __shared__ uint32_t s_literal[kChainTiles][EWV];
+        constexpr int R = kWave / (D / kVec);
+        const uint32_t ew = EWV * est_iter<G>() * R / tail.tile_heads;
+        const uint32_t live = (uint32_t)(tail.state->n_pages - 1);
+        const uint32_t et0 = idx * kChainTiles;
+        if (et0 * ew < live) {  // (a workgroup wholly past the live length has nothing to do but to report)
+            const uint32_t t = threadIdx.x / (EWV * kWave);
+            uint32_t et = et0 + t;
+            if (et >= cp.entry_tiles) et = cp.entry_tiles - 1;  // odd tile count: the last workgroup repeats its first tile
+            const size_t tile_lds = (est_tile_lds_bytes(tail.tile_heads, G, D, ew) + 15) & ~(size_t)15;
+            estimate_tile<D, G, HND, EWV, kChainTiles, true>(q, scores, meta, n_out, tail, et, group,
+                                                             threadIdx.x % (EWV * kWave), chain_smem + t * tile_lds,
+                                                             s_literal[t]);
+        }
+        QUEST_CHAIN_STAMP(2);
+        chain_signal(cw, group, group + 1);
+        QUEST_CHAIN_STAMP(3);
+        return;
+    }
+    // ---- attention: workgroup idx of the group -> (query head, chunk)
+    const uint32_t heads_per_group = tail.tile_heads * G;
+    const uint32_t hq = group * heads_per_group + idx / p.n_chunks, chunk = idx % p.n_chunks;
+    sparse_decode_body<D, 16, FC, kChainWaves, true>(p, chunk, hq, 0u, meta.num_heads * G, cw, group);
+    QUEST_CHAIN_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,7 +713,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hk = blockIdx.y;
-    const SeqView sv = select_sequence(p, gridDim.y * GS, D);
+    const SeqView sv = select_sequence(p, gridDim.y * GS, D, blockIdx.z);
     if (p.state) {  // state-driven launch: the plan (chunks) was made for the pool capacity; workgroups whose
                     // chunk lies past the live page list write an empty partial (weight 0 in the merge)
         const quest_step_state_t st = *sv.state;
@@ -652,7 +840,11 @@ template <int D>
 __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const float* __restrict__ ws,
                                                                         half_t* __restrict__ o,
                                                                         float* __restrict__ lse, uint32_t n_chunks,
-                                                                        uint32_t ws_stride) {
+                                                                        uint32_t ws_stride, uint32_t* rearm = nullptr,
+                                                                        uint32_t rearm_lines = 0) {
+    // after a chained launch: zero its hand-off counters for the next one (one word per 128-byte line)
+    if (rearm && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < rearm_lines; i += blockDim.x) rearm[(size_t)i * kChainLineWords] = 0u;
     __shared__ float s_w[1024];  // per-chunk weight exp2(m_c - M); planner keeps n_chunks <= 1024
     __shared__ float s_red[kMergeGroups][D + 1];
     __shared__ float s_M;
@@ -746,6 +938,10 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
 
 using namespace quest;
 
+namespace quest {
+int check_pool(const quest_paged_kv_t& p);  // append.hip
+}
+
 struct quest_decode_handler {
     uint32_t layout = 0;
     bool started = false;
@@ -765,6 +961,8 @@ struct quest_decode_handler {
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
     int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation
+    uint32_t* chain_sync = nullptr;              // chained launch: done[32], passed[32], error (zeroed once; self re-arming)
+    int chain_lead = 0;                          // chained launch: estimate groups ahead of the attention (0 = default)
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
 };
@@ -797,6 +995,7 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
 extern "C" void quest_decode_handler_destroy(quest_decode_handler_t* h) {
     if (!h) return;
     if (h->ws) (void)hipFree(h->ws);
+    if (h->chain_sync) (void)hipFree(h->chain_sync);
     for (float* w : h->retired_ws) (void)hipFree(w);
     delete h;
 }
@@ -890,6 +1089,12 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
         h->ws = bigger;
         h->ws_bytes = need;
     }
+    if (!h->chain_sync) {  // (not inside a stream capture: begin_forward never is)
+        hipError_t e = hipMalloc((void**)&h->chain_sync, kChainSyncWords * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+        e = hipMemset(h->chain_sync, 0, kChainSyncWords * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+    }
     h->started = true;
     return 0;
 }
@@ -942,10 +1147,12 @@ static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, u
     }
 }
 
-static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
-                        uint32_t num_qo_heads, const void* scores, uint32_t n_scores, void* topk_val_out,
-                        int32_t* topk_idx_out, float* lse, hipStream_t s, uint32_t score_stride = 0,
-                        const quest_step_state_t* state = nullptr, quest_batch_t batch = {1, 0, 0, 0}) {
+// Checks + kernel parameters of a per-head-list decode launch; fc = keys per thread of the fused front end (0 = page ids
+// come from an index tensor), waves = workgroup size.
+static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv, uint32_t num_qo_heads,
+                       const void* scores, uint32_t n_scores, void* topk_val_out, int32_t* topk_idx_out, float* lse,
+                       uint32_t score_stride, const quest_step_state_t* state, quest_batch_t batch, DecodeParams& p, int& fc,
+                       uint32_t& waves) {
     if (state) kv.last_page_len = 1;  // placeholder; the kernel reads the real one from `state`
     if (!h || batch.n_seqs == 0) return QUEST_EINVAL;
     if (!h->started) return QUEST_ESTATE;
@@ -968,7 +1175,7 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
         return QUEST_EINVAL;
     if (kv.last_page_len == 0 || kv.last_page_len > kv.page_size) return QUEST_EINVAL;
-    DecodeParams p{};
+    p = DecodeParams{};
     p.q = (const half_t*)q;
     p.o = (half_t*)o;
     p.lse = lse;
@@ -1032,8 +1239,8 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.state = state;
     p.table_stride = batch.kv_table_stride;
     // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor
-    int fc = 0;
-    uint32_t waves = h->dec_waves;
+    fc = 0;
+    waves = h->dec_waves;
     p.cpt = 0;
     if (fused) {
         // the selection is VALU-issue bound (~1000 instructions per wave at 8 keys per thread), so rows
@@ -1058,6 +1265,19 @@ static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest
                             p.score_stride >= ((n_scores + 7u) & ~7u))))
             p.vec_front = 3;
     }
+    return 0;
+}
+
+static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
+                        uint32_t num_qo_heads, const void* scores, uint32_t n_scores, void* topk_val_out,
+                        int32_t* topk_idx_out, float* lse, hipStream_t s, uint32_t score_stride = 0,
+                        const quest_step_state_t* state = nullptr, quest_batch_t batch = {1, 0, 0, 0}) {
+    DecodeParams p;
+    int fc;
+    uint32_t waves;
+    if (int e = plan_decode(h, q, o, kv, num_qo_heads, scores, n_scores, topk_val_out, topk_idx_out, lse, score_stride, state,
+                            batch, p, fc, waves))
+        return e;
     switch (kv.head_dim) {
         case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
         case 128: return launch_decode<128>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
@@ -1185,6 +1405,128 @@ extern "C" int quest_decode_forward_shared_batched(quest_decode_handler_t* h, co
     if (!state) return QUEST_EINVAL;
     if (h && batch.n_seqs > 1 && batch.kv_table_stride < h->n_sel + 1) return QUEST_EINVAL;
     return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream, batch);
+}
+
+// ---- chained launch --------------------------------------------------------------------------------------------
+template <int D, int G, bool HND>
+static int launch_chain_fc(int fc, dim3 grid, size_t lds, hipStream_t s, const half_t* q, half_t* scores,
+                           const quest_paged_kv_t& meta, uint32_t n_out, const AppendTail& tail, const DecodeParams& p,
+                           const ChainPlan& cp, const ChainWait& cw) {
+    const dim3 block(kChainWaves * kWave);
+    switch (fc) {
+        case 8: hipLaunchKernelGGL((chain_kernel<D, G, HND, 8>), grid, block, lds, s, q, scores, meta, n_out, tail, p, cp, cw); break;
+        case 16: hipLaunchKernelGGL((chain_kernel<D, G, HND, 16>), grid, block, lds, s, q, scores, meta, n_out, tail, p, cp, cw); break;
+        case 32: hipLaunchKernelGGL((chain_kernel<D, G, HND, 32>), grid, block, lds, s, q, scores, meta, n_out, tail, p, cp, cw); break;
+        default: return QUEST_EUNSUPPORTED;
+    }
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D, int G>
+static int launch_chain(bool hnd, int fc, dim3 grid, size_t lds, hipStream_t s, const half_t* q, half_t* scores,
+                        const quest_paged_kv_t& meta, uint32_t n_out, const AppendTail& tail, const DecodeParams& p,
+                        const ChainPlan& cp, const ChainWait& cw) {
+    return hnd ? launch_chain_fc<D, G, true>(fc, grid, lds, s, q, scores, meta, n_out, tail, p, cp, cw)
+               : launch_chain_fc<D, G, false>(fc, grid, lds, s, q, scores, meta, n_out, tail, p, cp, cw);
+}
+
+extern "C" int quest_decode_set_chain_lead(quest_decode_handler_t* h, int lead) {
+    if (!h || lead < 0) return QUEST_EINVAL;
+    h->chain_lead = lead;
+    return 0;
+}
+
+extern "C" int quest_chain_decode_dyn(quest_decode_handler_t* h, const void* k, const void* v, quest_paged_kv_t kv,
+                                      const void* q, void* scores, uint32_t score_stride, uint32_t max_n_out,
+                                      quest_paged_kv_t metadata, void* o, uint32_t num_qo_heads,
+                                      const quest_step_state_t* state, float* lse, quest_stream_t stream) {
+    if (!h || !k || !v || !state || !scores || max_n_out == 0 || score_stride < max_n_out) return QUEST_EINVAL;
+    // shapes the chained kernel is built for; callers take the two-launch chain otherwise
+    if (kv.page_size != 16 || kv.head_dim != 128) return QUEST_EUNSUPPORTED;
+    const uint32_t G = kv.num_heads ? num_qo_heads / kv.num_heads : 0;
+    if (G != 1 && G != 4) return QUEST_EUNSUPPORTED;
+    kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim || kv.layout != metadata.layout) return QUEST_EINVAL;
+    if (!metadata.indices) return QUEST_EINVAL;
+    DecodeParams p;
+    int fc;
+    uint32_t waves;
+    const quest_batch_t one = {1, 0, 0, 0};
+    if (int e = plan_decode(h, q, o, kv, num_qo_heads, scores, max_n_out, nullptr, nullptr, lse, score_stride, state, one, p, fc,
+                            waves))
+        return e;
+    if (waves != (uint32_t)kChainWaves || fc > 32) return QUEST_EUNSUPPORTED;  // short rows (4-wave plans), > 16384 pages
+    constexpr uint32_t D = 128, LPR = D / kVec, R = kWave / LPR, EWV = kChainWaves / kChainTiles;
+    AppendTail tail{};
+    tail.kv = kv;
+    tail.key = (const uint16_t*)k;
+    tail.value = (const uint16_t*)v;
+    tail.enabled = 1;
+    tail.state = state;
+    tail.o_stride = score_stride;
+    const uint32_t iter = G >= 2 ? (uint32_t)QUEST_EST_ITER_GQA : (uint32_t)kEstIter;
+    const uint32_t rows = EWV * iter * R;
+    const uint32_t hw = pick_tile_heads(metadata.num_heads, G, LPR, EWV), ew = rows / hw;
+    tail.tile_heads = hw;
+    ChainPlan cp{};
+    cp.n_app = (metadata.num_heads * LPR + kChainWaves * kWave - 1) / (kChainWaves * kWave);
+    cp.n_groups = metadata.num_heads / hw;
+    if (cp.n_groups > kChainMaxGroups) return QUEST_EUNSUPPORTED;
+    cp.entry_tiles = (max_n_out + ew - 1) / ew;
+    cp.est_blocks = (cp.entry_tiles + kChainTiles - 1) / kChainTiles;
+    cp.attn_blocks = hw * G * h->n_chunks;
+    static const int env_lead = [] { const char* e = getenv("QUEST_CHAIN_LEAD"); return e ? atoi(e) : 0; }();
+    // default: every estimate group ahead of the attention -- with two 8-wave workgroups per CU an attention workgroup
+    // that waits holds a slot an estimate workgroup needs (measured at cfg 3, us per layer: lead 4 25.9, 3 28.4, 2 28.2,
+    // 1 34.7)
+    uint32_t lead = h->chain_lead ? (uint32_t)h->chain_lead : env_lead > 0 ? (uint32_t)env_lead : cp.n_groups;
+    cp.lead = lead < 1 ? 1 : lead > cp.n_groups ? cp.n_groups : lead;
+    tail.est_blocks = cp.est_blocks * cp.n_groups;
+    ChainWait cw{};
+    cw.done = h->chain_sync;
+    cw.error = h->chain_sync + kChainCounterWords;
+    cw.target = cp.est_blocks + cp.n_app;
+    const size_t est_lds = kChainTiles * ((est_tile_lds_bytes(hw, G, D, ew) + 15) & ~(size_t)15);
+    const size_t fe_lds = (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0);
+    const size_t lds = est_lds > fe_lds ? est_lds : fe_lds;
+    const dim3 grid(cp.n_app + cp.n_groups * (cp.est_blocks + cp.attn_blocks));
+    hipStream_t s = (hipStream_t)stream;
+    const bool hnd = metadata.layout == QUEST_LAYOUT_HND;
+    int rc = G == 1 ? launch_chain<128, 1>(hnd, fc, grid, lds, s, (const half_t*)q, (half_t*)scores, metadata, max_n_out, tail, p, cp, cw)
+                    : launch_chain<128, 4>(hnd, fc, grid, lds, s, (const half_t*)q, (half_t*)scores, metadata, max_n_out, tail, p, cp, cw);
+    if (rc) return rc;
+    const uint32_t lines = cp.n_groups * kChainReplicas;
+    if (h->n_chunks > 1 && !h->skip_merge) {
+        hipLaunchKernelGGL((merge_states_kernel<128>), dim3(num_qo_heads), dim3(128 * kMergeGroups), 0, s, (const float*)p.ws, p.o,
+                           QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride, h->chain_sync, lines);
+        QUEST_LAUNCH_CHECK();
+    } else {  // no merge to ride on: re-arm the counters with a memset node
+        hipError_t e = hipMemsetAsync(h->chain_sync, 0, (size_t)lines * kChainLineWords * sizeof(uint32_t), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+/* 1 when a chained launch on this handler ever timed out waiting for its producers (device flag; synchronises). */
+extern "C" int quest_chain_error(quest_decode_handler_t* h) {
+    if (!h || !h->chain_sync) return 0;
+    uint32_t flag = 0;
+    if (hipMemcpy(&flag, h->chain_sync + kChainCounterWords, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)flag;
+}
+
+/* Developer aid (-DQUEST_CHAIN_TRACE builds): copy the per-workgroup stamps of the last chained launch, 4 int64 each. */
+extern "C" int quest_chain_trace(quest_decode_handler_t* h, long long* out, uint32_t n_blocks) {
+#ifdef QUEST_CHAIN_TRACE
+    if (!h || !h->chain_sync || !out || n_blocks > kChainTraceBlocks) return QUEST_EINVAL;
+    return (int)hipMemcpy(out, h->chain_sync + kChainCounterWords + 2, (size_t)n_blocks * 4 * sizeof(long long), hipMemcpyDeviceToHost);
+#else
+    (void)h, (void)out, (void)n_blocks;
+    return QUEST_EUNSUPPORTED;
+#endif
 }
 
 extern "C" const char* quest_error_string(int code) {
