@@ -40,6 +40,16 @@
 
 namespace quest {
 
+// K/V tile loads of the per-head-list kernel: streaming (`nt`) by default; -DQUEST_KV_CACHED keeps them in the L2's normal
+// replacement order (tuning: GQA heads of a group re-read each other's pages)
+__device__ __forceinline__ half8 ld8_kv(const half_t* p) {
+#ifdef QUEST_KV_CACHED
+    return ld8(p);
+#else
+    return ld8_stream(p);
+#endif
+}
+
 constexpr float kNegFloor = -1.0e30f;  // finite "-inf": exp2(floor - floor) stays finite, weights it carries are 0
 
 struct DecodeParams {
@@ -81,6 +91,7 @@ struct DecodeParams {
     uint32_t ws_stride;  // floats per partial record (>= D + 2, multiple of 32 -> records own whole 128 B lines)
     uint32_t ids_lds_offset;
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
+    uint32_t xcd_period;  // > 1: grid row y serves query head (y % period) * (Hq / period) + y / period (see sparse_decode_kernel)
 };
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
@@ -498,14 +509,14 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 left[T + t] = len1 - t * R;
                 // rows past the page's length exist in the pool (the page is allocated) but hold
                 // stale bytes; they are fetched only for the sequence's last page and masked in fold
-                k[t] = ld8_stream(b0 + lane_off + t * step);
-                v[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
+                k[t] = ld8_kv(b0 + lane_off + t * step);
+                v[t] = ld8_kv(b0 + lane_off + t * step + p.st.v_off);
             }
             if (has1) {  // wave-uniform
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    k[T + t] = ld8_stream(b1 + lane_off + t * step);
-                    v[T + t] = ld8_stream(b1 + lane_off + t * step + p.st.v_off);
+                    k[T + t] = ld8_kv(b1 + lane_off + t * step);
+                    v[T + t] = ld8_kv(b1 + lane_off + t * step + p.st.v_off);
                 }
                 fold_groups<D, 2 * T>(st, qv, k, v, left, row);
             } else {
@@ -603,9 +614,15 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
 #endif
 }
 
+// Workgroups go to the 8 XCDs round-robin by linear workgroup id, and each XCD has its own L2.  With GQA the query
+// heads of a kv-head group select overlapping page sets (measured: 21 % of their pages are shared, scripts/gqa_overlap.py),
+// so their workgroups should sit on the SAME XCD, at the same time: the host picks `xcd_period` such that grid rows
+// y, y + period, y + 2 period, ... (same XCD for every chunk index) serve a run of consecutive query heads.
 template <int D, int S_T, int FC, int NW>
 __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(DecodeParams p) {
-    sparse_decode_body<D, S_T, FC, NW, false>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, ChainWait{}, 0u);
+    uint32_t hq = blockIdx.y;
+    if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (gridDim.y / p.xcd_period) + hq / p.xcd_period;
+    sparse_decode_body<D, S_T, FC, NW, false>(p, blockIdx.x, hq, blockIdx.z, gridDim.y, ChainWait{}, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1238,6 +1255,14 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     if (fused && !p.vec_front && n_scores > 4096u) return QUEST_EUNSUPPORTED;
     p.state = state;
     p.table_stride = batch.kv_table_stride;
+    {   // XCD-aware row order for GQA (see sparse_decode_kernel); QUEST_XCD_GROUP=0 keeps the plain order (tuning)
+        static const bool xcd_group = [] { const char* e = getenv("QUEST_XCD_GROUP"); return !e || atoi(e) != 0; }();
+        uint32_t gcd = 8, c = h->n_chunks % 8u;
+        while (c) { const uint32_t t = gcd % c; gcd = c; c = t; }
+        const uint32_t period = 8u / gcd;
+        p.xcd_period = (xcd_group && p.group > 1 && period > 1 && num_qo_heads % period == 0 &&
+                        (num_qo_heads / period) % p.group == 0) ? period : 1u;
+    }
     // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor
     fc = 0;
     waves = h->dec_waves;
