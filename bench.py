@@ -672,6 +672,9 @@ def main():
             if w.dyn and not w.dense:
                 ops, roof = step_op_times(w, a, bpl)
                 roof["traffic"] = pmc_traffic()
+                if roof["traffic"] and roof["traffic"] < 0.95 * roof.get("algorithmic_bytes_per_launch", 0):
+                    roof["traffic_note"] = ("HBM bytes below the algorithmic bytes: with GQA the query heads of a kv-head group "
+                                            "run on one XCD (XCD-aware grid order) and re-read each other's pages from its L2")
                 out["roofline"], out["ops_us"] = roof, ops
             ref_ops, dense_us = reference_op_times(w, a, bpl)
             out["reference_op_sequence_us"] = ref_ops
