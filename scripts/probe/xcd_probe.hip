@@ -102,6 +102,43 @@ __global__ void handoff_kernel(int mode, uint32_t prod, uint32_t cons, uint32_t*
     }
 }
 
+// 3. does a page that ANOTHER workgroup (same or different XCD) read a few microseconds ago come back faster -- from that
+// XCD's L2 or from the memory-side Infinity Cache -- while the HBM is saturated?  Workgroup `first` reads 64 KiB (8 KiB
+// per wave, the shape of an attention workgroup's gather) at t0; workgroup `second` reads 64 KiB `delay` ticks later:
+// the same bytes (warm) or bytes nobody touched (cold).  out[0] = the second read's duration in ticks.
+__global__ void reread_kernel(uint32_t first, uint32_t second, const u32x4* region, const u32x4* other, long long delay, long long* out,
+                              const u32x4* stream, uint32_t stream_vecs, uint32_t* sink, long long* t0_shared) {
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (b >= 16) {
+        u32x4 acc = (u32x4)(0u);
+        for (uint32_t r = 0; r < 4; ++r) {
+            u32x4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = __builtin_nontemporal_load(stream + ((size_t)(b - 16) * 4 + r) * 4096 % stream_vecs + i * 256 + t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc ^= v[i];
+        }
+        if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+        return;
+    }
+    if (b != first && b != second) return;
+    // both wait until the background is streaming
+    const long long start = wall_clock64();
+    while (wall_clock64() - start < (b == first ? 300 : 300 + delay)) {}
+    const u32x4* src = (b == first) ? region : other;  // `other` == region for the warm case
+    const long long a = wall_clock64();
+    u32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + i * 256 + t);
+    u32x4 acc = (u32x4)(0u);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc ^= v[i];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[1] = 1;
+    __syncthreads();
+    if (t == 0) out[b == first ? 1 : 0] = wall_clock64() - a;
+}
+
 int main() {
     int dev = 0;
     CK(hipSetDevice(dev));
@@ -166,5 +203,29 @@ int main() {
                    loaded ? "[HBM loaded]" : "[idle]      ", names[mode], same ? "same     " : "different", x0, x1, s / lat.size(), mn, errs,
                    (mode == 2 && !same) ? "  (not a valid recipe across XCDs: shown for contrast)" : "");
         }
+    // ---- 3. re-read latency
+    long long* d_t0;
+    CK(hipMalloc(&d_t0, 64));
+    for (int loaded = 0; loaded < 2; ++loaded)
+        for (int warm = 1; warm >= 0; --warm)
+            for (int same = 1; same >= 0; --same) {
+                const uint32_t first = 0, second = same ? 8 : 1;
+                double s1 = 0, s2 = 0;
+                int n = 0;
+                for (int rep = 0; rep < 24; ++rep) {
+                    // a fresh region every repetition, far from the background stream's blocks of this launch
+                    const u32x4* region = d_stream + ((size_t)(40u << 20) + (size_t)rep * 65536);
+                    const u32x4* other = warm ? region : region + 32768;
+                    CK(hipMemset(d_out, 0, 64));
+                    hipLaunchKernelGGL(reread_kernel, dim3(16 + (loaded ? 2048 : 0)), dim3(256), 0, 0, first, second, region, other, 300LL, d_out,
+                                       d_stream, stream_vecs, d_flag + 512, d_t0);
+                    CK(hipDeviceSynchronize());
+                    long long o[8];
+                    CK(hipMemcpy(o, d_out, 64, hipMemcpyDeviceToHost));
+                    if (rep >= 4) s1 += o[1] / 100.0, s2 += o[0] / 100.0, ++n;
+                }
+                printf("%s 64 KiB read, 3 us after %s workgroup on %s XCD read %s: first read %.2f us, second read %.2f us\n",
+                       loaded ? "[HBM loaded]" : "[idle]      ", "a", same ? "the same     " : "a different  ", warm ? "the SAME bytes " : "other bytes    ", s1 / n, s2 / n);
+            }
     return 0;
 }
