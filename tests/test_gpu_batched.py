@@ -42,6 +42,8 @@ def _gather(buf_layer, indices, n_entries, layout):
     (2, 1, 1, (16 * 18 + 7, 16 * 11 + 1, 16 * 30 + 16), True, 256),
     (8, 2, 1, (16 * 15 + 16, 16 * 33 + 5), True, 128),
     (8, 8, 0, (16 * 70 + 3, 16 * 24 + 15, 16 * 24 + 16, 16 * 50 + 8, 16 * 9 + 9), False, 128),
+    # cfg-5 head shapes, 8 sequences: one workgroup per head -> the XCD-aware grid order (heads of a kv-head group on one XCD)
+    (32, 8, 0, (16 * 20 + 5, 16 * 9 + 16, 16 * 31 + 1, 16 * 12 + 7, 16 * 25 + 3, 16 * 8 + 2, 16 * 17 + 9, 16 * 30 + 16), False, 128),
 ])
 def test_batched_decode_matches_single_sequence(Hq, Hkv, layout, lens, same_split, D):
     import quest_amd.utils as qu
