@@ -203,25 +203,6 @@ int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q
                                         uint32_t max_n_scores, const quest_step_state_t* state, float* lse,
                                         quest_stream_t stream);
 
-/* Chained launch: quest_append_estimate_dyn + quest_decode_forward_fused_topk_dyn of one sequence as ONE grid (plus the
- * merge launch): the attention workgroups of a head group start as soon as that group's scores are complete, while the
- * metadata of the other groups is still streaming (sparse_attn.hip, chain_kernel).  Same operands and the same results,
- * bit for bit, as the two calls: the ops it chains are quest/ops/csrc/page.cu:86-148 (append_kv_cache_decode),
- * estimate.cu:5-45, topk.cu:5-38 and approx_attn.cu:100-147.  `scores` is the [num_qo_heads][score_stride] fp16
- * scratch (written, then read, inside the launch).  Page size 16, head_dim 128, group size 1 or 4, rows of more than
- * 1024 pages; QUEST_EUNSUPPORTED otherwise (callers then issue the two calls). */
-int quest_chain_decode_dyn(quest_decode_handler_t* h, const void* k, const void* v, quest_paged_kv_t kv, const void* q,
-                           void* scores, uint32_t score_stride, uint32_t max_n_out, quest_paged_kv_t metadata, void* o,
-                           uint32_t num_qo_heads, const quest_step_state_t* state, float* lse, quest_stream_t stream);
-/* Tuning aid: head groups whose estimate is dispatched ahead of the first attention group (0 = default). */
-int quest_decode_set_chain_lead(quest_decode_handler_t* h, int lead);
-/* 1 if a chained launch on this handler ever gave up waiting for its producers (never expected; synchronises). */
-int quest_chain_error(quest_decode_handler_t* h);
-
-/* Developer aid: per-workgroup wall-clock stamps of the last chained launch (4 int64 per workgroup: role << 32 | group,
- * start, past the wait / work done, end); QUEST_EUNSUPPORTED unless the library was built with -DQUEST_CHAIN_TRACE. */
-int quest_chain_trace(quest_decode_handler_t* h, long long* out, uint32_t n_blocks);
-
 /* quest_append_kv_cache_decode with lengths / last-page ids from `state` (dense layers of a replayed step). */
 int quest_append_kv_cache_decode_dyn(const void* k, const void* v, quest_paged_kv_t kv, quest_paged_kv_t metadata,
                                      const quest_step_state_t* state, quest_stream_t stream);
@@ -292,6 +273,13 @@ int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_
  * per-workgroup partial states in the handler's workspace (the output tensor is NOT written when the plan has
  * more than one workgroup per head).  Lets a bench time the dominant kernel by itself. */
 int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
+/* Where the per-workgroup partial states of a head are merged (the job of flashinfer's VariableLengthMergeStates,
+ * call site decode_attn.cuh:992-1001): mode 0 (default) = inside the attention launch, by the workgroup of the head
+ * that finishes last (arrival ticket in the handler's workspace; heads split into more than 32 workgroups still take
+ * the launch); mode 1 = always by a separate merge launch.  Same bits either way.  The environment variable
+ * QUEST_MERGE=launch|inline sets the initial mode of new handlers.  A handler (its workspace and tickets) serves ONE
+ * stream at a time. */
+int quest_decode_set_merge_mode(quest_decode_handler_t* h, int mode);
 /* Inspection aid for the state-driven / batched fused launches (quest_decode_forward_fused_topk_dyn/_batched), which
  * otherwise keep the selected pages inside the kernel: while set, every such launch also writes its selection --
  * values (fp16 scores) to val_out and physical page ids to idx_out, both [n_seqs][num_qo_heads][n_selected_pages of

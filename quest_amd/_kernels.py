@@ -533,38 +533,6 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
                                                       state.data_ptr(), None, _stream(q)),
               "BatchDecodeWithPagedKVCache")
 
-    def chain_decode_dyn(self, k, v, q, o, paged_kv_data, page_table, metadata_data, meta_table, scores, state,
-                         max_n_scores: int) -> bool:
-        """append_estimate_dyn + forward_fused_topk_dyn as one chained launch (+ merge).  Returns False when the
-        shapes are outside the chained kernel's set (nothing was launched: issue the two calls instead)."""
-        for t, n in ((k, "k"), (v, "v"), (q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (page_table, "page_table"),
-                     (metadata_data, "metadata_data"), (meta_table, "meta_table"), (scores, "scores"), (state, "state")):
-            _check_input(t, n)
-        _check_dim(3, k, "k")
-        _check_dim(2, scores, "scores")
-        _check_eq(k.size(0), 1, "k.size(0), 1")
-        _check_eq(scores.size(0), q.size(1), "scores.size(0), num_qo_heads")
-        _check_ge(scores.size(1), max_n_scores, "scores.size(1), max_n_scores")
-        _check_half(k, "Append_kv_cache_decode")
-        _check_half(q, "BatchDecodeWithPagedKVCache")
-        kv = _paged(paged_kv_data, page_table, None, 1, 0, self._layout)
-        meta = _paged(metadata_data, meta_table, None, 1, 0, self._layout)
-        rc = lib.quest_chain_decode_dyn(self._h, k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), scores.data_ptr(),
-                                        scores.size(1), int(max_n_scores), meta, o.data_ptr(), q.size(1),
-                                        state.data_ptr(), None, _stream(q))
-        if rc == -2:  # QUEST_EUNSUPPORTED
-            return False
-        check(rc, "BatchDecodeWithPagedKVCache")
-        return True
-
-    def set_chain_lead(self, lead: int) -> None:
-        """Tuning aid of the chained launch: estimate head groups dispatched ahead of the attention (0 = default)."""
-        check(lib.quest_decode_set_chain_lead(self._h, int(lead)), "set_chain_lead")
-
-    def chain_error(self) -> int:
-        """1 if a chained launch on this handler ever gave up waiting (synchronises the device)."""
-        return int(lib.quest_chain_error(self._h))
-
     def set_batch(self, n_seqs: int) -> None:
         """Sequences per launch the NEXT begin_forward plans for (workspace, work split)."""
         check(lib.quest_decode_set_batch(self._h, int(n_seqs)), "set_batch")
@@ -630,3 +598,7 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
     def set_skip_merge(self, skip: bool) -> None:
         """Measurement aid: launch only the attention kernel (partial states stay unmerged, ``o`` unwritten)."""
         check(lib.quest_decode_set_skip_merge(self._h, int(bool(skip))), "set_skip_merge")
+
+    def set_merge_mode(self, mode: int) -> None:
+        """0 = the last-arriving workgroup of a head merges inside the attention launch (default), 1 = merge launch."""
+        check(lib.quest_decode_set_merge_mode(self._h, int(mode)), "set_merge_mode")

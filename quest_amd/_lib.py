@@ -60,11 +60,6 @@ SIGNATURES = {
                                                   c_vp]),
     "quest_decode_forward_fused_topk_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32, c_vp,
                                                             c_vp, c_vp]),
-    "quest_chain_decode_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp, c_u32,
-                                               c_vp, c_vp, c_vp]),
-    "quest_decode_set_chain_lead": (ctypes.c_int, [c_vp, ctypes.c_int]),
-    "quest_chain_error": (ctypes.c_int, [c_vp]),
-    "quest_chain_trace": (ctypes.c_int, [c_vp, c_vp, c_u32]),
     "quest_append_kv_cache_decode_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp, c_vp]),
     "quest_decode_forward_shared_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp, c_vp]),
     "quest_apply_rope_in_place_dyn": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, c_vp]),
@@ -81,6 +76,7 @@ SIGNATURES = {
     "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),
     "quest_decode_set_skip_merge": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "quest_decode_set_merge_mode": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "quest_decode_set_selection_out": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "quest_decode_set_front_end": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "quest_apply_rope_in_place": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp]),

@@ -38,18 +38,7 @@ __device__ __forceinline__ ushort8 fold_min(ushort8 m, ushort8 k) {
 constexpr uint16_t kHalfMax = 0x7bffu;     // +65504 (CUDART_MAX_NORMAL_FP16, decode_page.cuh:430-431)
 constexpr uint16_t kHalfNegMax = 0xfbffu;  // -65504
 
-// 16-byte store that is visible device-wide when it completes (two relaxed agent-scope atomic stores: `sc1`,
-// written through the XCD's L2) -- for data handed to other workgroups of the SAME launch (chained launch), where a
-// device-scope release fence would write back the whole L2.
-__device__ __forceinline__ void store_agent(uint16_t* dst, const ushort8& v) {
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2 w = __builtin_bit_cast(u64x2, v);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Body of the decode append for global thread id `tid` (one thread = 8 halves of one head).  WT: write-through stores.
-template <bool WT = false>
+// Body of the decode append for global thread id `tid` (one thread = 8 halves of one head).
 __device__ __forceinline__ void append_decode_body(const quest_paged_kv_t& kv, const quest_paged_kv_t& meta,
                                                    const uint16_t* __restrict__ key,
                                                    const uint16_t* __restrict__ value, uint32_t tid) {
@@ -86,17 +75,10 @@ __device__ __forceinline__ void append_decode_body(const quest_paged_kv_t& kv, c
     }
     mx = fold_max(mx, k8);
     mn = fold_min(mn, k8);
-    if constexpr (WT) {
-        store_agent(kdst, k8);
-        store_agent(kdst + ks.v_off, v8);
-        store_agent(mmax, mx);
-        store_agent(mmin, mn);
-    } else {
-        *reinterpret_cast<ushort8*>(kdst) = k8;
-        *reinterpret_cast<ushort8*>(kdst + ks.v_off) = v8;
-        *reinterpret_cast<ushort8*>(mmax) = mx;
-        *reinterpret_cast<ushort8*>(mmin) = mn;
-    }
+    *reinterpret_cast<ushort8*>(kdst) = k8;
+    *reinterpret_cast<ushort8*>(kdst + ks.v_off) = v8;
+    *reinterpret_cast<ushort8*>(mmax) = mx;
+    *reinterpret_cast<ushort8*>(mmin) = mn;
 }
 
 }  // namespace quest

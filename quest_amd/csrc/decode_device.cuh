@@ -1,6 +1,6 @@
-// Device code of the sparse paged decode attention: kernel parameters, the online-softmax row state, the hand-off of
-// the chained launch and the workgroup body shared by sparse_decode_kernel and chain_kernel (sparse_attn.hip, which
-// also holds the reference citations and the design notes).
+// Device code of the sparse paged decode attention: kernel parameters, the online-softmax row state, the merge of the
+// per-workgroup partial states (by the last-arriving workgroup of a head, or by merge_states_kernel) and the workgroup
+// body of sparse_decode_kernel (sparse_attn.hip, which also holds the reference citations and the design notes).
 #pragma once
 #include "estimate_device.cuh"
 #include "topk_bitmap.cuh"
@@ -32,9 +32,11 @@ __device__ __forceinline__ half8 ld8_kv(const half_t* p) {
 constexpr float kNegFloor = -1.0e30f;  // finite "-inf": exp2(floor - floor) stays finite, weights it carries are 0
 
 struct DecodeParams {
-    // The pointers come first: with -amdgpu-kernarg-preload-count=16 (build.py) the first 16 kernarg dwords
-    // arrive in SGPRs at wave launch, so the first loads of a workgroup do not wait for a scalar load of the
-    // argument block (0.3 us per launch on the fused kernel).
+    // Kernarg preload (-amdgpu-kernarg-preload-count, build.py) only covers SCALAR kernel arguments -- a struct passed
+    // by value is fetched with s_load whatever its layout (round 2 believed otherwise; the ISA showed three serialised
+    // scalar loads before the first vector load).  So the kernels take the fields their first loads need as separate
+    // leading arguments (QUEST_DECODE_HEAD_*, 14 dwords = what the hardware preloads beside the kernarg pointer) and
+    // copy them over the struct's fields; the rest of the struct arrives by s_load while those first loads fly.
     const half_t* q;
     const half_t* kv;
     const int32_t* indices;
@@ -71,7 +73,26 @@ struct DecodeParams {
     uint32_t ids_lds_offset;
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
     uint32_t xcd_period;  // > 1: grid row y serves query head (y % period) * (Hq / period) + y / period (see sparse_decode_kernel)
+    uint32_t* tickets;    // [n_seqs][heads of the grid] arrival counters of the in-kernel merge (zero between launches);
+                          // nullptr: partials are merged by merge_states_kernel (or left unmerged)
 };
+
+// leading scalar kernel arguments (preloaded into SGPRs at wave launch) and their hand-over to the struct; a_pack =
+// vec_front | cpt << 4 | stage_ids << 12 | xcd_period << 16 (one dword, so that the query-head count fits as well:
+// gridDim.y would be an s_load of the hidden arguments in front of the score-row address)
+#define QUEST_DECODE_HEAD_PARAMS                                                                                        \
+    const half_t *a_q, const int32_t *a_indices, const uint16_t *a_scores, const quest_step_state_t *a_state,           \
+        uint32_t a_n_scores, uint32_t a_score_stride, uint32_t a_table_stride, uint32_t a_pack, uint32_t a_num_qo_heads
+#define QUEST_DECODE_HEAD_ARGS(p, num_qo_heads)                                                  \
+    (p).q, (p).indices, (p).scores, (p).state, (p).n_scores, (p).score_stride, (p).table_stride, \
+        ((p).vec_front | (p).cpt << 4 | ((p).stage_ids ? 1u : 0u) << 12 | (p).xcd_period << 16), (uint32_t)(num_qo_heads)
+#define QUEST_DECODE_HEAD_TAKE(p)                                                                                    \
+    do {                                                                                                             \
+        (p).q = a_q, (p).indices = a_indices, (p).scores = a_scores, (p).state = a_state, (p).n_scores = a_n_scores; \
+        (p).score_stride = a_score_stride, (p).table_stride = a_table_stride;                                        \
+        (p).vec_front = a_pack & 15u, (p).cpt = (a_pack >> 4) & 255u, (p).stage_ids = (a_pack >> 12) & 1u;           \
+        (p).xcd_period = a_pack >> 16;                                                                               \
+    } while (0)
 
 // Batched state-driven launch: blockIdx.z selects the sequence; every per-sequence operand is a row of a
 // batched tensor ([n_seqs][Hq][...]), the pools are shared.  A single-sequence launch has blockIdx.z == 0.
@@ -142,77 +163,92 @@ __device__ __forceinline__ void fold_groups(RowState<D>& st, const float8& qv, c
     st.m = m_new;
 }
 
-constexpr uint32_t kChainReplicas = 16, kChainLineWords = 32;  // see ChainWait
-#ifdef QUEST_CHAIN_TRACE  // developer aid (scripts/chain_trace.py): per workgroup {role/group, start, past the wait, end} wall-clock stamps
-constexpr uint32_t kChainTraceBlocks = 4096;
-constexpr uint32_t kChainMaxGroups = 32, kChainCounterWords = kChainMaxGroups * kChainReplicas * kChainLineWords, kChainSyncWords = kChainCounterWords + 2 + 8 * kChainTraceBlocks;
-#define QUEST_CHAIN_STAMP(slot)                                                                          \
-    do {                                                                                                 \
-        if (threadIdx.x == 0 && blockIdx.x < kChainTraceBlocks)                                          \
-            reinterpret_cast<long long*>(cw.error + 2)[4 * blockIdx.x + (slot)] = wall_clock64();        \
-    } while (0)
-#define QUEST_CHAIN_ROLE(role, group)                                                                    \
-    do {                                                                                                 \
-        if (threadIdx.x == 0 && blockIdx.x < kChainTraceBlocks)                                          \
-            reinterpret_cast<long long*>(cw.error + 2)[4 * blockIdx.x] = ((long long)(role) << 32) | (group); \
-    } while (0)
-#else
-constexpr uint32_t kChainMaxGroups = 32, kChainCounterWords = kChainMaxGroups * kChainReplicas * kChainLineWords, kChainSyncWords = kChainCounterWords + 2;
-#define QUEST_CHAIN_STAMP(slot) \
-    do { } while (0)
-#define QUEST_CHAIN_ROLE(role, group) \
-    do { } while (0)
-#endif
+// ---- merge of the per-chunk partial states of a head (flashinfer's VariableLengthMergeStates, call site
+// decode_attn.cuh:992-1001): weights exp2(m_c - M), weighted sum, normalise, cast.
+constexpr int kMergeGroups = 4;   // the chunks of a head are dealt round-robin over 4 partial sums per feature
+constexpr int kMergePre = 8;      // chunks per partial sum requested up front (one memory round trip)
+constexpr uint32_t kMergeFastChunks = 32;  // = kMergePre * kMergeGroups <= kWave: the one-round-trip form below
 
-// Chained launch (chain_kernel below): the estimate and the attention of a step run in ONE grid.  Workgroups are
-// dispatched in index order; the estimate (and append) workgroups of a head group come before the attention
-// workgroups that consume their scores and never wait for anything.  Hand-off, built from what was measured on MI355X
-// (scripts/chain_trace.py):
-//   * a device-scope RELEASE fence writes back the XCD's whole L2 (`buffer_wbl2 sc1`): ~8 us per workgroup, serialised
-//     -> 28 us per launch.  So the producers' data (scores; the appended token) leave by write-through stores
-//     (relaxed agent-scope atomic stores, `sc1`), each wave waits for its own stores to complete (`s_waitcnt`), the
-//     workgroup meets at a barrier, and only then are the counters bumped (relaxed, no fence);
-//   * several hundred workgroups polling ONE word queue up behind each other at its memory channel (4-6 us per poll,
-//     and the estimate's own loads to that channel wait in the same queue) -> every group's counter exists in
-//     kChainReplicas copies on separate 128-byte lines; producers bump all of them, a consumer polls one;
-//   * a consumer's first thread polls (bounded: a stuck grid sets *error and carries on instead of hanging the GPU),
-//     then an ACQUIRE fence (`buffer_inv sc1`, cheap) and a workgroup barrier;
-//   * the counters are re-armed by the merge launch that follows (kernel boundary), so nothing is counted twice.
-struct ChainWait {
-    uint32_t* done;      // [groups][kChainReplicas] counters, one 128-byte line each
-    uint32_t* error;     // set to 1 when a wait timed out
-    uint32_t target;     // producers per group (estimate workgroups of the group + append workgroups)
-};
-#ifndef QUEST_CHAIN_SLEEP
-#define QUEST_CHAIN_SLEEP 4  // x 64 cycles between two polls of the counter
-#endif
-constexpr long long kChainTimeoutTicks = 5000000;  // 50 ms of the 100 MHz wall clock
+// Partial records handed from one workgroup to another INSIDE a launch: relaxed agent-scope atomics compile to `sc1`
+// accesses -- stores are written through the XCD's L2 to memory (complete device-wide when s_waitcnt vmcnt sees them
+// done), loads bypass non-coherent copies.  A device-scope release FENCE instead would write back the XCD's whole L2
+// (measured in round 2: ~8 us per workgroup).
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool AGENT>
+__device__ __forceinline__ float ld_partial(const float* p) {
+    if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
 
-__device__ __forceinline__ uint32_t* chain_counter(const ChainWait& cw, uint32_t group, uint32_t replica) {
-    return cw.done + ((size_t)group * kChainReplicas + replica) * kChainLineWords;
-}
-// all threads of a producer workgroup, after their last write-through store
-__device__ __forceinline__ void chain_signal(const ChainWait& cw, uint32_t group_begin, uint32_t group_end) {
-    __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have completed (device-wide: they are write-through)
-    __syncthreads();
-    if (threadIdx.x < kChainReplicas)
-        for (uint32_t g = group_begin; g < group_end; ++g)
-            __hip_atomic_fetch_add(chain_counter(cw, g, threadIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void chain_wait(const ChainWait& cw, uint32_t group) {
-    if (threadIdx.x == 0) {
-        uint32_t* flag = chain_counter(cw, group, blockIdx.x % kChainReplicas);
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cw.target) {
-            __builtin_amdgcn_s_sleep(QUEST_CHAIN_SLEEP);
-            if (wall_clock64() - t0 > kChainTimeoutTicks) {
-                *cw.error = 1u;
-                break;
-            }
+// Merge of one head with n_chunks <= kMergeFastChunks by NT threads (whole waves; D >= 64 so a wave lies inside one
+// feature group).  Every wave derives the chunk weights by itself -- lane c holds chunk c's (m, d) -- so the only
+// barrier is the cross-group sum.  The association order is fixed (chunks g, g+4, g+8, ... ascending into partial sum
+// g; then ((s0 + s1) + s2) + s3), independent of NT: the in-kernel merge and merge_states_kernel give the same bits.
+// s_red: kMergeGroups * D floats of LDS.
+template <int D, int NT, bool AGENT>
+__device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, half_t* __restrict__ o_row, float* lse_ptr,
+                                                uint32_t n_chunks, uint32_t ws_stride, uint32_t tid, float* s_red) {
+    constexpr int ITEMS = kMergeGroups * D, PASSES = (ITEMS + NT - 1) / NT;
+    float pre[PASSES][kMergePre];
+#pragma unroll
+    for (int r = 0; r < PASSES; ++r) {
+        const uint32_t item = tid + r * NT, f = item % D, g = item / D;
+#pragma unroll
+        for (int j = 0; j < kMergePre; ++j) {
+            const uint32_t c = g + j * kMergeGroups, cc = c < n_chunks ? c : n_chunks - 1;  // clamped: no branch
+            pre[r][j] = ld_partial<AGENT>(w + (size_t)cc * ws_stride + f);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const uint32_t lane = tid & 63, lc = lane < n_chunks ? lane : n_chunks - 1;
+    const float m_c = ld_partial<AGENT>(w + (size_t)lc * ws_stride + D), d_c = ld_partial<AGENT>(w + (size_t)lc * ws_stride + D + 1);
+    const float Mw = wave_allreduce_max(lane < n_chunks ? m_c : kNegFloor, (int)lane);
+    const float e_c = lane < n_chunks ? __builtin_amdgcn_exp2f(m_c - Mw) : 0.f;
+    const float dn = wave_allreduce_sum(e_c * d_c, (int)lane);
+#pragma unroll
+    for (int r = 0; r < PASSES; ++r) {
+        const uint32_t item = tid + r * NT, f = item % D;
+        if (ITEMS % NT == 0 || item < (uint32_t)ITEMS) {
+            const uint32_t g_u = __builtin_amdgcn_readfirstlane(item / D);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < kMergePre; ++j) {
+                const uint32_t c = g_u + j * kMergeGroups;  // wave-uniform: the chunk weight is a scalar broadcast
+                const float wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_c),
+                                                                                   (int)(c < n_chunks ? c : 0)));
+                if (c < n_chunks) a += wc * pre[r][j];
+            }
+            s_red[g_u * D + f] = a;
+        }
     }
     __syncthreads();
+    for (uint32_t f = tid; f < (uint32_t)D; f += NT) {
+        float tot = s_red[f];
+#pragma unroll
+        for (int j = 1; j < kMergeGroups; ++j) tot += s_red[j * D + f];
+        o_row[f] = (half_t)(tot / dn);
+        if (lse_ptr && f == 0) *lse_ptr = (Mw + __builtin_amdgcn_logf(dn)) * 0.6931471805599453f;
+    }
+}
+
+// In-kernel merge: called by ALL threads of a workgroup after its partial record(s) left by st_agent stores.
+//   every wave waits for its own stores (write-through: complete = in memory), workgroup barrier, ONE relaxed atomic
+//   ticket per (sequence, head); the workgroup that draws n_chunks - 1 knows every record of the head is in memory: it
+//   re-arms the ticket (nobody else touches it before the next launch on this stream), invalidates (acquire fence =
+//   `buffer_inv sc1`) and merges.  Nobody polls or waits for another workgroup.  Returns whether this workgroup merges.
+// One stream per handler: the tickets (like the partial records) belong to the launch in flight.
+__device__ __forceinline__ bool merge_ticket_is_last(uint32_t* ticket, uint32_t n_chunks, uint32_t* s_flag) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == n_chunks - 1;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *s_flag != 0u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last;
 }
 
 // S_T = compile-time page size (16) or 0 for the generic run-time path.
@@ -228,16 +264,16 @@ __device__ __forceinline__ void chain_wait(const ChainWait& cw, uint32_t group) 
 // drop their physical page id into LDS.  All workgroups of a head repeat the (cheap, L2-resident)
 // selection instead of waiting for one another.
 //
-// The body is a device function so that the chained launch can run it as one role of a larger grid: (chunk, hq, seq)
-// are the workgroup's coordinates, CHAIN = wait for the head group's scores (chain_wait) before touching them.
-template <int D, int S_T, int FC, int NW, bool CHAIN>
+// (chunk, hq, seq) are the workgroup's coordinates.
+template <int D, int S_T, int FC, int NW>
 __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_t chunk, const uint32_t hq, const uint32_t seq,
-                                                   const uint32_t num_qo_heads, const ChainWait& cw, const uint32_t wait_group) {
+                                                   const uint32_t num_qo_heads) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
     // wave index as an SGPR so per-wave control flow below is scalar branching
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
-    const uint32_t hk = hq / p.group;
+    // Source order matters up to the first loads: everything above them uses only the preloaded arguments (see
+    // DecodeParams); values that need the rest of the struct (kv head, slots, pool strides) are derived after them.
 #ifdef QUEST_TIMELINE
     long long tl[10] = {};
     long long sub_out[9] = {};
@@ -258,16 +294,17 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
     // slots = selected pages + the current page; a state-driven launch on a sequence still shorter than the
     // budget selects ALL of its pages (k = n: the reference's full-attention branch, QuestAttention.py:123-132)
     // and workgroups whose chunk lies past the live list write an empty partial (weight 0 in the merge)
-    uint32_t n_slots = p.n_sel + 1;
-    const uint32_t slot_begin = chunk * p.pages_per_chunk;
-    uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
+    uint32_t n_slots = 0, slot_begin = 0, slot_end = 0;
+    auto plan_slots = [&]() {
+        n_slots = p.n_sel + 1;
+        slot_begin = chunk * p.pages_per_chunk;
+        slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
+    };
+    if constexpr (FC == 0) plan_slots();
 
     // q is requested now but first used after the top-k front end, so its latency hides under the selection
     const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);
 
-    const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
-    const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
-    const int32_t* idx_row = sv.indices + (size_t)hq * p.idx_stride;  // uniform
     RowState<D> st;
 
     __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
@@ -279,6 +316,11 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
         Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
+        // live lengths of a state-driven launch: ONE scalar load (n_pages, last page's length and id are adjacent),
+        // issued before the vector loads below and consumed after them
+        // (unconditional, from q's bytes when there is no state: a load under a branch is waited for at the join)
+        const int4 live = *(p.state ? reinterpret_cast<const int4*>(sv.state)
+                                    : reinterpret_cast<const int4*>(p.q));  // seq_len, n_pages, kv_last_page_len, kv_last_page_idx
         uint4 own_keys = make_uint4(0u, 0u, 0u, 0u), own_ids[2] = {own_keys, own_keys};  // vec_front == 3
         const bool own_cols = FC == 8 && p.vec_front == 3;
         // the thread's own contiguous columns (vec_front 3): their page ids (1-2 x 16 bytes) and 16 bytes of scores per
@@ -301,13 +343,6 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                     }
                 }
         }
-        // chained launch: everything above is independent of the estimate; the score row (and the appended token's
-        // K/V further down) is not
-        if constexpr (CHAIN) {
-            QUEST_CHAIN_STAMP(1);
-            chain_wait(cw, wait_group);
-            QUEST_CHAIN_STAMP(2);
-        }
         if (own_cols) {
             if (p.cpt == 8) {
                 own_keys = *reinterpret_cast<const uint4*>(srow + own_cc);
@@ -321,14 +356,12 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             fe2_clear<NT>(sm);
         }
         if (p.state) {  // live lengths
-            const quest_step_state_t st = *sv.state;
-            p.n_scores = (uint32_t)(st.n_pages - 1);
-            p.last_page_len = (uint32_t)st.kv_last_page_len;
-            p.last_page_idx = st.kv_last_page_idx;
+            p.n_scores = (uint32_t)(live.y - 1);
+            p.last_page_len = (uint32_t)live.z;
+            p.last_page_idx = live.w;
             p.n_sel = min(p.n_sel, p.n_scores);
-            n_slots = p.n_sel + 1;
-            slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
         }
+        plan_slots();
         const uint32_t n = p.n_scores;
         if (n > 0 && p.vec_front == 2) {
             QUEST_STAMP(1);
@@ -459,6 +492,10 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             }
         }  // n > 0
     }
+    const uint32_t hk = hq / p.group;
+    const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
+    const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
+    const int32_t* idx_row = sv.indices + (size_t)hq * p.idx_stride;  // uniform
     float8 qv = to_f32(q_raw);
     qv *= p.scale_log2;
     // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
@@ -575,11 +612,28 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             if (QUEST_LSE_ENABLED && p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
         } else {
             float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
-            w[f] = acc;
-            if (f == 0) {
-                w[D] = M;
-                w[D + 1] = den;
+            if (p.tickets) {  // handed to the merging workgroup of this launch: write-through
+                st_agent(w + f, acc);
+                if (f == 0) {
+                    st_agent(w + D, M);
+                    st_agent(w + D + 1, den);
+                }
+            } else {
+                w[f] = acc;
+                if (f == 0) {
+                    w[D] = M;
+                    w[D + 1] = den;
+                }
             }
+        }
+    }
+    if (p.n_chunks > 1 && p.tickets) {  // launch-uniform
+        __shared__ uint32_t s_last;
+        if (merge_ticket_is_last(p.tickets + (size_t)seq * num_qo_heads + hq, p.n_chunks, &s_last)) {
+            static_assert(NW >= kMergeGroups, "s_acc is reused as the merge's cross-group buffer");
+            merge_head_fast<D, NW * kWave, true>(sv.ws + (size_t)hq * p.n_chunks * p.ws_stride, sv.o + (size_t)hq * D,
+                                                 QUEST_LSE_ENABLED && p.lse ? sv.lse + hq : nullptr, p.n_chunks, p.ws_stride,
+                                                 threadIdx.x, &s_acc[0][0]);
         }
     }
 #ifdef QUEST_TIMELINE

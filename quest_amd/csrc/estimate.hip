@@ -23,20 +23,29 @@
 namespace quest {
 
 // One tile per workgroup (device body: estimate_device.cuh); blocks >= tail.est_blocks run the decode append.
+// The leading scalar arguments are the fields the first loads of a workgroup need (role, page-table entry, metadata
+// rows, live length): scalar kernel arguments are preloaded into SGPRs at wave launch (14 dwords beside the kernarg
+// pointer, build.py), a struct passed by value is not -- its remaining fields arrive by s_load while those loads fly.
 template <int D, int G, bool HND>
-__global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimate_kernel(const half_t* __restrict__ q, half_t* __restrict__ o,
-                                                                    quest_paged_kv_t meta, uint32_t n_out,
-                                                                    AppendTail tail) {
+__global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimate_kernel(
+    const half_t* __restrict__ q, void* a_meta_data, const int32_t* a_meta_indices, const quest_step_state_t* a_state,
+    uint32_t n_out, uint32_t a_num_heads, uint32_t a_page_size, uint32_t a_tile_log2, uint32_t a_append_from,
+    uint32_t a_meta_table_stride, half_t* __restrict__ o, quest_paged_kv_t meta, AppendTail tail) {
+    // a_append_from: first append block (= est_blocks), 0xffffffff when no append rides in this launch
+    meta.data = a_meta_data, meta.indices = a_meta_indices, meta.num_heads = a_num_heads, meta.page_size = a_page_size;
+    meta.head_dim = D, meta.layout = HND ? QUEST_LAYOUT_HND : QUEST_LAYOUT_NHD;
+    tail.state = a_state, tail.tile_log2 = a_tile_log2, tail.tile_heads = 1u << a_tile_log2, tail.est_blocks = a_append_from, tail.enabled = 1u;
+    tail.meta_table_stride = a_meta_table_stride;
+    uint32_t seq = 0;
     if (tail.state) {  // state-driven launches may be batched: blockIdx.y = sequence (0 for a single one)
-        const uint32_t seq = blockIdx.y;
+        seq = blockIdx.y;
         tail.state += seq;
         q += (size_t)seq * meta.num_heads * G * D;
-        o += (size_t)seq * meta.num_heads * G * tail.o_stride;
         meta.indices += (size_t)seq * tail.meta_table_stride;
+    }
+    if (blockIdx.x >= tail.est_blocks) {
         tail.key += (size_t)seq * meta.num_heads * D;
         tail.value += (size_t)seq * meta.num_heads * D;
-    }
-    if (tail.enabled && blockIdx.x >= tail.est_blocks) {
         if (tail.state) {
             const quest_step_state_t st = *tail.state;
             meta.last_page_len = (uint32_t)st.meta_last_page_len;
@@ -51,9 +60,9 @@ __global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimat
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char est_smem[];
     __shared__ uint32_t s_literal[kEstWaves];
-    const uint32_t head_tiles = meta.num_heads / tail.tile_heads;
+    const uint32_t head_tiles = meta.num_heads >> tail.tile_log2;
     estimate_tile<D, G, HND, kEstWaves, 1>(q, o, meta, n_out, tail, blockIdx.x / head_tiles, blockIdx.x % head_tiles,
-                                           threadIdx.x, est_smem, s_literal);
+                                           threadIdx.x, est_smem, s_literal, seq * meta.num_heads * G);
 }
 
 template <int D, int G>
@@ -65,19 +74,23 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     if (!tail.state) tail.o_stride = n_out;
     const uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec), ew = ROWS / hw;
     tail.tile_heads = hw;
+    tail.tile_log2 = (uint32_t)__builtin_ctz(hw);
     tail.est_blocks = ((n_out + ew - 1) / ew) * (meta.num_heads / hw);
     uint32_t blocks = tail.est_blocks;
     if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + kEstWaves * kWave - 1) / (kEstWaves * kWave);
     if (blocks == 0) return 0;
     dim3 grid(blocks, n_seqs);
     const size_t lds = est_tile_lds_bytes(hw, G, D, ew);
+    const uint32_t append_from = tail.enabled ? tail.est_blocks : 0xffffffffu;
     if (hw * G * (D / kVec) > 2 * kEstWaves * kWave) return QUEST_EUNSUPPORTED;  // q staging capacity
     if (hnd)
-        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q,
-                           (half_t*)o, meta, n_out, tail);
+        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q, meta.data,
+                           meta.indices, tail.state, n_out, meta.num_heads, meta.page_size, tail.tile_log2, append_from,
+                           tail.meta_table_stride, (half_t*)o, meta, tail);
     else
-        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q,
-                           (half_t*)o, meta, n_out, tail);
+        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q, meta.data,
+                           meta.indices, tail.state, n_out, meta.num_heads, meta.page_size, tail.tile_log2, append_from,
+                           tail.meta_table_stride, (half_t*)o, meta, tail);
     QUEST_LAUNCH_CHECK();
     return 0;
 }

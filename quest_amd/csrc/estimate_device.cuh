@@ -1,4 +1,4 @@
-// Device code of the page-criticality estimate (shared by estimate.hip and the chained launch in sparse_attn.hip).
+// Device code of the page-criticality estimate (estimate.hip).
 // See estimate.hip for the reference citations and the arithmetic.
 #pragma once
 #include "append_device.cuh"
@@ -31,6 +31,7 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
     const quest_step_state_t* state;  // optional device-resident lengths / last-page ids (graph replay)
     uint32_t o_stride;                // row stride of o (== n_out unless state-driven)
     uint32_t tile_heads;              // kv heads per workgroup tile (power of two dividing num_heads, <= 8)
+    uint32_t tile_log2;               // log2(tile_heads): tile rows and heads are powers of two -> shifts, not divisions
     uint32_t meta_table_stride;       // batched launches (blockIdx.y = sequence): entries between page tables
 };
 
@@ -55,12 +56,13 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
 // EWV = waves per tile, TPB = tiles per workgroup (tile t of the workgroup is run by waves [t*EWV, (t+1)*EWV)); the
 // tile is (entry tile `et`, head tile `ht`).  With TPB > 1 the tiles of a workgroup share its barriers, so a tile
 // that lies past the live length runs through with clamped loads and masked stores instead of returning.
-// `smem` = the tile's dynamic LDS (est_tile_lds_bytes), `s_literal` = EWV words of LDS.  WT: the scores leave by
-// write-through stores (chained launch).
-template <int D, int G, bool HND, int EWV, int TPB, bool WT = false>
+// `smem` = the tile's dynamic LDS (est_tile_lds_bytes), `s_literal` = EWV words of LDS.
+template <int D, int G, bool HND, int EWV, int TPB>
 __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half_t* __restrict__ o, const quest_paged_kv_t& meta,
                                               uint32_t n_out, const AppendTail& tail, uint32_t et, uint32_t ht, uint32_t tid,
-                                              unsigned char* est_smem, uint32_t* s_literal) {
+                                              unsigned char* est_smem, uint32_t* s_literal, uint32_t o_row0 = 0) {
+    // o_row0: first row of `o` that belongs to this launch's sequence (batched launches).  It is applied at the final
+    // store: tail.o_stride arrives by s_load (not preloaded), and nothing before the metadata loads may wait for it.
     constexpr int LPR = D / kVec;   // lanes per row
     constexpr int R = kWave / LPR;  // rows per load instruction
     constexpr int kEstIter = est_iter<G>();  // (shadows the namespace constant: GQA instantiations may differ)
@@ -68,7 +70,9 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
     // n_out as passed bounds every address (state-driven launches pass the largest n_out the graph will
     // see; page tables and pools cover it); the live n_out comes from the state further down.
     const uint32_t n_cap = n_out;
-    const uint32_t HW = tail.tile_heads, EW = ROWS / HW;
+    static_assert((ROWS & (ROWS - 1)) == 0, "tile rows must be a power of two");
+    const uint32_t hw_l2 = tail.tile_log2, ew_l2 = (uint32_t)__builtin_ctz(ROWS) - hw_l2;
+    const uint32_t HW = 1u << hw_l2, EW = 1u << ew_l2;
     half_t* q_s = reinterpret_cast<half_t*>(est_smem);                              // [HW*G][D]  q
     uint16_t* neg_s = reinterpret_cast<uint16_t*>(q_s + (size_t)HW * G * D);        // [HW*G][D]  q < 0 ? 0xffff : 0
     half_t* out_s = reinterpret_cast<half_t*>(neg_s + (size_t)HW * G * D);          // [HW*G][EW] scores
@@ -99,14 +103,14 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
 #pragma unroll
     for (int j = 0; j < kEstIter; ++j) {
         const uint32_t r = (wave * kEstIter + j) * R + row;  // row inside the tile
-        el[j] = HND ? r % EW : r / HW;
-        hl[j] = HND ? r / EW : r % HW;
+        el[j] = HND ? r & (EW - 1) : r >> hw_l2;
+        hl[j] = HND ? r >> ew_l2 : r & (HW - 1);
         const uint32_t e = e0 + el[j];
         // Loads are unconditional from a clamped entry: a predicated load compiles to branch + load + wait
         // and serialises the round trips.  Clamped rows re-read the last entry (tail tiles only).
         ecl[j] = e < n_cap ? e : n_cap - 1;
     }
-    if (S % EW == 0) {
+    if ((S & (EW - 1)) == 0) {
         // the tile's EW consecutive entries (and the clamped ones of a tail tile) lie in ONE metadata page: a
         // single wave-uniform (scalar) table load instead of a vector load per row at the head of the
         // table -> metadata dependency chain
@@ -214,19 +218,14 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
     __syncthreads();
     const uint32_t n_scores = HW * G * EW;
     for (uint32_t t = tid; t < n_scores; t += EWV * kWave) {
-        const uint32_t qh = t / EW, e = e0 + t % EW;
+        const uint32_t qh = t >> ew_l2, e = e0 + (t & (EW - 1));
 #ifdef QUEST_EST_NOSTORE
         if (e < n_out && out_s[t] == (half_t)12345.f)
 #else
         if (e < n_out)
 #endif
         {
-            half_t* dst = o + ((size_t)h0 * G + qh) * tail.o_stride + e;
-            if constexpr (WT)  // visible device-wide on completion (see store_agent)
-                __hip_atomic_store(reinterpret_cast<uint16_t*>(dst), __builtin_bit_cast(uint16_t, out_s[t]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            else
-                *dst = out_s[t];
+            o[((size_t)o_row0 + (size_t)h0 * G + qh) * tail.o_stride + e] = out_s[t];
         }
     }
 }

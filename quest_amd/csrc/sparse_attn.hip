@@ -32,103 +32,11 @@ namespace quest {
 // so their workgroups should sit on the SAME XCD, at the same time: the host picks `xcd_period` such that grid rows
 // y, y + period, y + 2 period, ... (same XCD for every chunk index) serve a run of consecutive query heads.
 template <int D, int S_T, int FC, int NW>
-__global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(DecodeParams p) {
+__global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
+    QUEST_DECODE_HEAD_TAKE(p);
     uint32_t hq = blockIdx.y;
-    if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (gridDim.y / p.xcd_period) + hq / p.xcd_period;
-    sparse_decode_body<D, S_T, FC, NW, false>(p, blockIdx.x, hq, blockIdx.z, gridDim.y, ChainWait{}, 0u);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Chained launch: append + estimate + top-k + attention of one decode step of one sequence in ONE grid (the merge
-// stays a second launch).  The idea: a dependent kernel boundary costs ~1.5 us + ~1.3 us until the next kernel's first
-// data arrives, and after it every workgroup of the attention launch does its page selection at the same time, with the
-// HBM idle.  Here the workgroups are laid out in dispatch order as
-//     append | estimate of head groups 0..L-1 | attention g0, estimate gL | attention g1, estimate gL+1 | ... |
-//     attention of the remaining groups
-// (a head group = the kv heads of one estimate tile column, `tile_heads` of them), so the attention of a group can start
-// as soon as ITS scores are complete.  See ChainWait for the hand-off.  Page size 16, 8 waves per workgroup; an estimate
-// workgroup runs two 4-wave tiles.
-// MEASURED (profiles/r02_chain_trace_cfg3.log): bit-identical to the two launches, and not faster -- cfg 3
-// 25.9 us per layer against 23.5.  The hand-off itself is down to ~1 us, but at 115 VGPRs only two 8-wave workgroups fit a
-// CU, so estimate and attention cannot be resident together: L < groups only parks waiting attention workgroups in slots
-// the estimate needs.  Kept as an opt-in (QUEST_CHAIN=1) with its parity tests.
-struct ChainPlan {
-    uint32_t n_app;        // append workgroups (first in the grid)
-    uint32_t n_groups;     // head groups = num_kv_heads / tile_heads
-    uint32_t lead;         // estimate groups dispatched ahead of the first attention group (1..n_groups)
-    uint32_t est_blocks;   // estimate workgroups per group
-    uint32_t attn_blocks;  // attention workgroups per group = tile_heads * group size * chunks
-    uint32_t entry_tiles;  // estimate tiles per group along the entries
-};
-
-constexpr int kChainWaves = 8, kChainTiles = 2;  // waves per workgroup; estimate tiles per workgroup
-
-template <int D, int G, bool HND, int FC>
-__global__ __launch_bounds__(kChainWaves* kWave, kChainWaves / 2) void chain_kernel(const half_t* __restrict__ q, half_t* scores,
-                                                                                     quest_paged_kv_t meta, uint32_t n_out,
-                                                                                     AppendTail tail, DecodeParams p, ChainPlan cp,
-                                                                                     ChainWait cw) {
-    constexpr int NT = kChainWaves * kWave, EWV = kChainWaves / kChainTiles;
-    uint32_t b = blockIdx.x;
-    if (b < cp.n_app) {  // ---- append: the current page's K/V entry and metadata entry
-        const quest_step_state_t st = *tail.state;
-        meta.last_page_len = (uint32_t)st.meta_last_page_len;
-        meta.last_page_idx = st.meta_last_page_idx;
-        tail.kv.last_page_len = (uint32_t)st.kv_last_page_len;
-        tail.kv.last_page_idx = st.kv_last_page_idx;
-        QUEST_CHAIN_ROLE(2, 0);
-        QUEST_CHAIN_STAMP(1);
-        append_decode_body<true>(tail.kv, meta, tail.key, tail.value, b * NT + threadIdx.x);
-        QUEST_CHAIN_STAMP(2);
-        chain_signal(cw, 0, cp.n_groups);  // every group's attention reads the new token
-        QUEST_CHAIN_STAMP(3);
-        return;
-    }
-    b -= cp.n_app;
-    // role of this workgroup
-    bool is_est;
-    uint32_t group, idx;
-    const uint32_t head = cp.lead * cp.est_blocks, pair = cp.attn_blocks + cp.est_blocks,
-                   mid = (cp.n_groups - cp.lead) * pair;
-    if (b < head) {
-        is_est = true, group = b / cp.est_blocks, idx = b % cp.est_blocks;
-    } else if (b - head < mid) {
-        const uint32_t i = (b - head) / pair, r = (b - head) % pair;
-        is_est = r >= cp.attn_blocks;
-        group = is_est ? cp.lead + i : i;
-        idx = is_est ? r - cp.attn_blocks : r;
-    } else {
-        const uint32_t r = b - head - mid;
-        is_est = false, group = cp.n_groups - cp.lead + r / cp.attn_blocks, idx = r % cp.attn_blocks;
-    }
-    QUEST_CHAIN_ROLE(is_est ? 1 : 0, group);
-    if (is_est) {  // ---- estimate: kChainTiles tiles of head group `group`
-        QUEST_CHAIN_STAMP(1);
-        extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
-        __shared__ uint32_t s_literal[kChainTiles][EWV];
-        constexpr int R = kWave / (D / kVec);
-        const uint32_t ew = EWV * est_iter<G>() * R / tail.tile_heads;
-        const uint32_t live = (uint32_t)(tail.state->n_pages - 1);
-        const uint32_t et0 = idx * kChainTiles;
-        if (et0 * ew < live) {  // (a workgroup wholly past the live length has nothing to do but to report)
-            const uint32_t t = threadIdx.x / (EWV * kWave);
-            uint32_t et = et0 + t;
-            if (et >= cp.entry_tiles) et = cp.entry_tiles - 1;  // odd tile count: the last workgroup repeats its first tile
-            const size_t tile_lds = (est_tile_lds_bytes(tail.tile_heads, G, D, ew) + 15) & ~(size_t)15;
-            estimate_tile<D, G, HND, EWV, kChainTiles, true>(q, scores, meta, n_out, tail, et, group,
-                                                             threadIdx.x % (EWV * kWave), chain_smem + t * tile_lds,
-                                                             s_literal[t]);
-        }
-        QUEST_CHAIN_STAMP(2);
-        chain_signal(cw, group, group + 1);
-        QUEST_CHAIN_STAMP(3);
-        return;
-    }
-    // ---- attention: workgroup idx of the group -> (query head, chunk)
-    const uint32_t heads_per_group = tail.tile_heads * G;
-    const uint32_t hq = group * heads_per_group + idx / p.n_chunks, chunk = idx % p.n_chunks;
-    sparse_decode_body<D, 16, FC, kChainWaves, true>(p, chunk, hq, 0u, meta.num_heads * G, cw, group);
-    QUEST_CHAIN_STAMP(3);
+    if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (a_num_qo_heads / p.xcd_period) + hq / p.xcd_period;
+    sparse_decode_body<D, S_T, FC, NW>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -138,12 +46,13 @@ __global__ __launch_bounds__(kChainWaves* kWave, kChainWaves / 2) void chain_ker
 // as the per-head-list kernel above would (4x the traffic at Llama-3 GQA).  Same work split, same partial
 // records, same merge kernel.
 template <int D, int GS, int NW>
-__global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(DecodeParams p) {
+__global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
+    QUEST_DECODE_HEAD_TAKE(p);
     constexpr int LPR = D / kVec, R = kWave / LPR, S_T = 16, T = (S_T + R - 1) / R;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
     const uint32_t chunk = blockIdx.x, hk = blockIdx.y;
-    const SeqView sv = select_sequence(p, gridDim.y * GS, D, blockIdx.z);
+    const SeqView sv = select_sequence(p, a_num_qo_heads, D, blockIdx.z);
     if (p.state) {  // state-driven launch: the plan (chunks) was made for the pool capacity; workgroups whose
                     // chunk lies past the live page list write an empty partial (weight 0 in the merge)
         const quest_step_state_t st = *sv.state;
@@ -252,71 +161,64 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(Decode
             if (p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
         } else {
             float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
-            w[f] = acc;
-            if (f == 0) {
-                w[D] = M;
-                w[D + 1] = den;
+            if (p.tickets) {  // handed to the merging workgroup of this launch: write-through
+                st_agent(w + f, acc);
+                if (f == 0) {
+                    st_agent(w + D, M);
+                    st_agent(w + D + 1, den);
+                }
+            } else {
+                w[f] = acc;
+                if (f == 0) {
+                    w[D] = M;
+                    w[D + 1] = den;
+                }
+            }
+        }
+    }
+    if (p.n_chunks > 1 && p.tickets) {  // launch-uniform: the last-arriving workgroup of the kv head merges its GS query heads
+        __shared__ uint32_t s_last;
+        if (merge_ticket_is_last(p.tickets + (size_t)blockIdx.z * (a_num_qo_heads / GS) + hk, p.n_chunks, &s_last)) {
+            static_assert(NW * GS >= kMergeGroups, "s_acc is reused as the merge's cross-group buffer");
+            for (uint32_t g = 0; g < (uint32_t)GS; ++g) {
+                const uint32_t hq = hk * GS + g;
+                merge_head_fast<D, NW * kWave, true>(sv.ws + (size_t)hq * p.n_chunks * p.ws_stride, sv.o + (size_t)hq * D,
+                                                     p.lse ? sv.lse + hq : nullptr, p.n_chunks, p.ws_stride, threadIdx.x,
+                                                     &s_acc[0][0][0]);
+                __syncthreads();  // s_acc is rewritten by the next head
             }
         }
     }
 }
 
 // Merge the per-chunk partial states of a head, normalise, cast to fp16 (the job of flashinfer's
-// VariableLengthMergeStates).  kMergeGroups thread groups each take every kMergeGroups-th chunk with
-// all of their loads independent (unrolled), then combine through LDS: two memory round trips total.
-constexpr int kMergeGroups = 4;
-
+// VariableLengthMergeStates) as a launch of its own: heads with more than kMergeFastChunks chunks, and the
+// QUEST_MERGE=launch / quest_decode_set_merge_mode(1) path (by default the last-arriving workgroup of the
+// attention launch merges, decode_device.cuh).  kMergeGroups thread groups each take every kMergeGroups-th
+// chunk with all of their loads independent (unrolled), then combine through LDS: two memory round trips total.
 template <int D>
 __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const float* __restrict__ ws,
                                                                         half_t* __restrict__ o,
                                                                         float* __restrict__ lse, uint32_t n_chunks,
-                                                                        uint32_t ws_stride, uint32_t* rearm = nullptr,
-                                                                        uint32_t rearm_lines = 0) {
-    // after a chained launch: zero its hand-off counters for the next one (one word per 128-byte line)
-    if (rearm && blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < rearm_lines; i += blockDim.x) rearm[(size_t)i * kChainLineWords] = 0u;
+                                                                        uint32_t ws_stride) {
     __shared__ float s_w[1024];  // per-chunk weight exp2(m_c - M); planner keeps n_chunks <= 1024
     __shared__ float s_red[kMergeGroups][D + 1];
     __shared__ float s_M;
     const uint32_t hq = blockIdx.x, tid = threadIdx.x;
     const uint32_t f = tid % D, g = tid / D;
     const float* w = ws + (size_t)hq * n_chunks * ws_stride;
-    // the first kPre partial rows of this thread's chunks are requested up front so the whole merge is
-    // one memory round trip for n_chunks <= kPre * kMergeGroups
-    constexpr int kPre = 8;
+    if (n_chunks <= kMergeFastChunks) {  // launch-uniform
+        merge_head_fast<D, D * kMergeGroups, false>(w, o + (size_t)hq * D, lse ? lse + hq : nullptr, n_chunks, ws_stride, tid,
+                                                    &s_red[0][0]);
+        return;
+    }
+    // the first kPre partial rows of this thread's chunks are requested up front
+    constexpr int kPre = kMergePre;
     float pre[kPre];
 #pragma unroll
     for (int j = 0; j < kPre; ++j) {
         const uint32_t c = g + j * kMergeGroups, cc = c < n_chunks ? c : n_chunks - 1;  // clamped: no branch
         pre[j] = w[(size_t)cc * ws_stride + f];
-    }
-    if (n_chunks <= (uint32_t)kWave && n_chunks <= (uint32_t)(kPre * kMergeGroups)) {
-        // Common case (<= 32 chunks): every wave derives the chunk weights by itself -- lane c holds chunk
-        // c's (m, d) -- so the only workgroup barrier is the final cross-group sum.
-        const uint32_t lane = tid & 63, lc = lane < n_chunks ? lane : n_chunks - 1;
-        const float m_c = w[(size_t)lc * ws_stride + D], d_c = w[(size_t)lc * ws_stride + D + 1];
-        const float Mw = wave_allreduce_max(lane < n_chunks ? m_c : kNegFloor, (int)lane);
-        const float e_c = lane < n_chunks ? __builtin_amdgcn_exp2f(m_c - Mw) : 0.f;
-        const float dn = wave_allreduce_sum(e_c * d_c, (int)lane);
-        float a = 0.f;
-        const uint32_t g_u = __builtin_amdgcn_readfirstlane(g);  // a wave lies inside one group (D >= 64)
-#pragma unroll
-        for (int j = 0; j < kPre; ++j) {
-            const uint32_t c = g_u + j * kMergeGroups;  // wave-uniform: the chunk weight is a scalar broadcast
-            const float wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_c),
-                                                                               (int)(c < n_chunks ? c : 0)));
-            if (c < n_chunks) a += wc * pre[j];
-        }
-        s_red[g][f] = a;
-        __syncthreads();
-        if (g == 0) {
-            float tot = s_red[0][f];
-#pragma unroll
-            for (int j = 1; j < kMergeGroups; ++j) tot += s_red[j][f];
-            o[(size_t)hq * D + f] = (half_t)(tot / dn);
-            if (lse && f == 0) lse[hq] = (Mw + __builtin_amdgcn_logf(dn)) * 0.6931471805599453f;
-        }
-        return;
     }
     // pass 1: chunk maxima -> M, weights, denominator
     float M = kNegFloor;
@@ -378,21 +280,25 @@ struct quest_decode_handler {
     uint32_t n_sel = 0, num_qo_heads = 0, num_kv_heads = 0, head_dim = 0, page_size = 0;
     uint32_t pages_per_chunk = 0, n_chunks = 0;
     uint32_t forced_ppc = 0;
+    void* ws_block = nullptr;  // one allocation: tickets, then the partial records (`ws`)
     float* ws = nullptr;
-    size_t ws_bytes = 0;
+    size_t ws_bytes = 0, ticket_bytes = 0;
     uint32_t ws_stride = 0;
     // Workspaces outgrown by a later plan.  Launches captured in a hipGraph hold the workspace pointer BY VALUE
     // (DecodeParams.ws), so a buffer that any launch was issued on may still be written by a replay: it is
     // retired, never freed before the handler itself is destroyed.  (A few hundred KiB each.)
-    std::vector<float*> retired_ws;
+    std::vector<void*> retired_ws;
     uint32_t dec_waves = 4;
     uint32_t shared_ppc = 0, shared_chunks = 0;  // plan of the group-shared kernel (grid.y = kv heads)
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
     int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation
-    uint32_t* chain_sync = nullptr;              // chained launch: done[32], passed[32], error (zeroed once; self re-arming)
-    int chain_lead = 0;                          // chained launch: estimate groups ahead of the attention (0 = default)
+    // in-kernel merge: arrival tickets [batch][num_qo_heads] at the head of the workspace block (zeroed when the
+    // block is allocated; the merging workgroup re-arms its ticket).  merge_mode 0 = the last-arriving workgroup of
+    // a head merges (heads of <= kMergeFastChunks chunks; more take the launch), 1 = always merge_states_kernel
+    uint32_t* tickets = nullptr;
+    int merge_mode = 0;
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
 };
@@ -405,6 +311,10 @@ struct quest_decode_handler {
 // launch).
 static uint32_t target_workgroups(const quest_decode_handler* h) { return h->batch > 1 ? h->num_cus : 2 * h->num_cus; }
 static constexpr uint32_t kMaxChunks = 1024;  // merge kernel's LDS weight table
+// whether the last-arriving workgroup of a head merges its partial records inside the attention launch
+static bool merge_in_kernel(const quest_decode_handler* h, uint32_t n_chunks) {
+    return h->merge_mode == 0 && !h->skip_merge && n_chunks > 1 && n_chunks <= kMergeFastChunks && h->tickets != nullptr;
+}
 
 extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout) {
     if (!out || layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
@@ -418,15 +328,15 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
     else
         (void)hipGetLastError();  // no device (CPU-only import): keep the MI355X default
     if (const char* e = getenv("QUEST_DEC_WAVES")) h->dec_waves = atoi(e) == 8 ? 8 : 4;  // tuning knob
+    if (const char* e = getenv("QUEST_MERGE")) h->merge_mode = e[0] == 'l' ? 1 : 0;      // "launch" / "inline" (A/B)
     *out = h;
     return 0;
 }
 
 extern "C" void quest_decode_handler_destroy(quest_decode_handler_t* h) {
     if (!h) return;
-    if (h->ws) (void)hipFree(h->ws);
-    if (h->chain_sync) (void)hipFree(h->chain_sync);
-    for (float* w : h->retired_ws) (void)hipFree(w);
+    if (h->ws_block) (void)hipFree(h->ws_block);
+    for (void* w : h->retired_ws) (void)hipFree(w);
     delete h;
 }
 
@@ -439,6 +349,12 @@ extern "C" int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint3
 extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) {
     if (!h) return QUEST_EINVAL;
     h->skip_merge = skip != 0;
+    return 0;
+}
+
+extern "C" int quest_decode_set_merge_mode(quest_decode_handler_t* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return QUEST_EINVAL;
+    h->merge_mode = mode;
     return 0;
 }
 
@@ -504,26 +420,30 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     h->ws_stride = (head_dim + 2 + 31) / 32 * 32;
     const uint32_t max_chunks = h->n_chunks > h->shared_chunks ? h->n_chunks : h->shared_chunks;
     const size_t need = (size_t)h->batch * num_qo_heads * max_chunks * h->ws_stride * sizeof(float);
-    if (max_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
-        float* bigger = nullptr;
-        hipError_t e = hipMalloc((void**)&bigger, need);
+    const size_t ticket_bytes = ((size_t)h->batch * num_qo_heads * sizeof(uint32_t) + 255) & ~(size_t)255;
+    if (max_chunks > 1 && (need > h->ws_bytes || ticket_bytes > h->ticket_bytes)) {  // grow-only; reused across begin/end cycles
+        void* bigger = nullptr;
+        const size_t nb = need > h->ws_bytes ? need : h->ws_bytes, tb = ticket_bytes > h->ticket_bytes ? ticket_bytes : h->ticket_bytes;
+        hipError_t e = hipMalloc(&bigger, tb + nb);
         if (e != hipSuccess) return (int)e;
-        if (h->ws) {
+        e = hipMemset(bigger, 0, tb);  // (not inside a stream capture: begin_forward never is)
+        if (e != hipSuccess) {
+            (void)hipFree(bigger);
+            return (int)e;
+        }
+        if (h->ws_block) {
             try {
-                h->retired_ws.push_back(h->ws);  // a captured graph may still reference it (see retired_ws)
+                h->retired_ws.push_back(h->ws_block);  // a captured graph may still reference it (see retired_ws)
             } catch (...) {
                 (void)hipFree(bigger);
                 return (int)hipErrorOutOfMemory;
             }
         }
-        h->ws = bigger;
-        h->ws_bytes = need;
-    }
-    if (!h->chain_sync) {  // (not inside a stream capture: begin_forward never is)
-        hipError_t e = hipMalloc((void**)&h->chain_sync, kChainSyncWords * sizeof(uint32_t));
-        if (e != hipSuccess) return (int)e;
-        e = hipMemset(h->chain_sync, 0, kChainSyncWords * sizeof(uint32_t));
-        if (e != hipSuccess) return (int)e;
+        h->ws_block = bigger;
+        h->tickets = (uint32_t*)bigger;
+        h->ws = (float*)((char*)bigger + tb);
+        h->ws_bytes = nb;
+        h->ticket_bytes = tb;
     }
     h->started = true;
     return 0;
@@ -549,13 +469,13 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     dim3 grid(h->n_chunks, num_qo_heads, n_seqs);
     const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0) : 0;  // the table has n_scores + 1 entries, staged in granules of 4
     if (p.page_size == 16 && waves == 8)
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), lds, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
     else if (p.page_size == 16)
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 4>), grid, dim3(4 * kWave), lds, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 4>), grid, dim3(4 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
     else
-        hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), lds, s, p);
+        hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
     QUEST_LAUNCH_CHECK();
-    if (h->n_chunks > 1 && !h->skip_merge) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
+    if (h->n_chunks > 1 && !p.tickets && !h->skip_merge) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
@@ -632,6 +552,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     }
     p.sel_stride = h->n_sel;
     p.ws_stride = h->ws_stride;
+    p.tickets = merge_in_kernel(h, h->n_chunks) ? h->tickets : nullptr;
     p.score_stride = score_stride ? score_stride : n_scores;
     p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
@@ -734,14 +655,14 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, u
                          hipStream_t s, uint32_t n_seqs) {
     dim3 grid(p.n_chunks, num_qo_heads / gs, n_seqs), block(4 * kWave);
     switch (gs) {
-        case 1: hipLaunchKernelGGL((shared_decode_kernel<D, 1, 4>), grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL((shared_decode_kernel<D, 2, 4>), grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL((shared_decode_kernel<D, 4, 4>), grid, block, 0, s, p); break;
-        case 8: hipLaunchKernelGGL((shared_decode_kernel<D, 8, 4>), grid, block, 0, s, p); break;
+        case 1: hipLaunchKernelGGL((shared_decode_kernel<D, 1, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
+        case 2: hipLaunchKernelGGL((shared_decode_kernel<D, 2, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
+        case 4: hipLaunchKernelGGL((shared_decode_kernel<D, 4, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
+        case 8: hipLaunchKernelGGL((shared_decode_kernel<D, 8, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
         default: return QUEST_EUNSUPPORTED;
     }
     QUEST_LAUNCH_CHECK();
-    if (p.n_chunks > 1) {
+    if (p.n_chunks > 1 && !p.tickets) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, p.lse, p.n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
@@ -789,6 +710,8 @@ static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.ws_stride = h->ws_stride;
     p.state = state;
     p.table_stride = batch.kv_table_stride;
+    // (skip_merge is a measurement aid of the per-head-list kernel; the group-shared kernel always merges)
+    p.tickets = h->merge_mode == 0 && p.n_chunks > 1 && p.n_chunks <= kMergeFastChunks ? h->tickets : nullptr;
     hipStream_t s = (hipStream_t)stream;
     return kv.head_dim == 64 ? launch_shared<64>(h, p, num_qo_heads, p.group, s, batch.n_seqs)
                              : launch_shared<128>(h, p, num_qo_heads, p.group, s, batch.n_seqs);
@@ -845,128 +768,6 @@ extern "C" int quest_decode_forward_shared_batched(quest_decode_handler_t* h, co
     return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream, batch);
 }
 
-// ---- chained launch --------------------------------------------------------------------------------------------
-template <int D, int G, bool HND>
-static int launch_chain_fc(int fc, dim3 grid, size_t lds, hipStream_t s, const half_t* q, half_t* scores,
-                           const quest_paged_kv_t& meta, uint32_t n_out, const AppendTail& tail, const DecodeParams& p,
-                           const ChainPlan& cp, const ChainWait& cw) {
-    const dim3 block(kChainWaves * kWave);
-    switch (fc) {
-        case 8: hipLaunchKernelGGL((chain_kernel<D, G, HND, 8>), grid, block, lds, s, q, scores, meta, n_out, tail, p, cp, cw); break;
-        case 16: hipLaunchKernelGGL((chain_kernel<D, G, HND, 16>), grid, block, lds, s, q, scores, meta, n_out, tail, p, cp, cw); break;
-        case 32: hipLaunchKernelGGL((chain_kernel<D, G, HND, 32>), grid, block, lds, s, q, scores, meta, n_out, tail, p, cp, cw); break;
-        default: return QUEST_EUNSUPPORTED;
-    }
-    QUEST_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int D, int G>
-static int launch_chain(bool hnd, int fc, dim3 grid, size_t lds, hipStream_t s, const half_t* q, half_t* scores,
-                        const quest_paged_kv_t& meta, uint32_t n_out, const AppendTail& tail, const DecodeParams& p,
-                        const ChainPlan& cp, const ChainWait& cw) {
-    return hnd ? launch_chain_fc<D, G, true>(fc, grid, lds, s, q, scores, meta, n_out, tail, p, cp, cw)
-               : launch_chain_fc<D, G, false>(fc, grid, lds, s, q, scores, meta, n_out, tail, p, cp, cw);
-}
-
-extern "C" int quest_decode_set_chain_lead(quest_decode_handler_t* h, int lead) {
-    if (!h || lead < 0) return QUEST_EINVAL;
-    h->chain_lead = lead;
-    return 0;
-}
-
-extern "C" int quest_chain_decode_dyn(quest_decode_handler_t* h, const void* k, const void* v, quest_paged_kv_t kv,
-                                      const void* q, void* scores, uint32_t score_stride, uint32_t max_n_out,
-                                      quest_paged_kv_t metadata, void* o, uint32_t num_qo_heads,
-                                      const quest_step_state_t* state, float* lse, quest_stream_t stream) {
-    if (!h || !k || !v || !state || !scores || max_n_out == 0 || score_stride < max_n_out) return QUEST_EINVAL;
-    // shapes the chained kernel is built for; callers take the two-launch chain otherwise
-    if (kv.page_size != 16 || kv.head_dim != 128) return QUEST_EUNSUPPORTED;
-    const uint32_t G = kv.num_heads ? num_qo_heads / kv.num_heads : 0;
-    if (G != 1 && G != 4) return QUEST_EUNSUPPORTED;
-    kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
-    if (int e = check_pool(kv)) return e;
-    if (int e = check_pool(metadata)) return e;
-    if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim || kv.layout != metadata.layout) return QUEST_EINVAL;
-    if (!metadata.indices) return QUEST_EINVAL;
-    DecodeParams p;
-    int fc;
-    uint32_t waves;
-    const quest_batch_t one = {1, 0, 0, 0};
-    if (int e = plan_decode(h, q, o, kv, num_qo_heads, scores, max_n_out, nullptr, nullptr, lse, score_stride, state, one, p, fc,
-                            waves))
-        return e;
-    if (waves != (uint32_t)kChainWaves || fc > 32) return QUEST_EUNSUPPORTED;  // short rows (4-wave plans), > 16384 pages
-    constexpr uint32_t D = 128, LPR = D / kVec, R = kWave / LPR, EWV = kChainWaves / kChainTiles;
-    AppendTail tail{};
-    tail.kv = kv;
-    tail.key = (const uint16_t*)k;
-    tail.value = (const uint16_t*)v;
-    tail.enabled = 1;
-    tail.state = state;
-    tail.o_stride = score_stride;
-    const uint32_t iter = G >= 2 ? (uint32_t)QUEST_EST_ITER_GQA : (uint32_t)kEstIter;
-    const uint32_t rows = EWV * iter * R;
-    const uint32_t hw = pick_tile_heads(metadata.num_heads, G, LPR, EWV), ew = rows / hw;
-    tail.tile_heads = hw;
-    ChainPlan cp{};
-    cp.n_app = (metadata.num_heads * LPR + kChainWaves * kWave - 1) / (kChainWaves * kWave);
-    cp.n_groups = metadata.num_heads / hw;
-    if (cp.n_groups > kChainMaxGroups) return QUEST_EUNSUPPORTED;
-    cp.entry_tiles = (max_n_out + ew - 1) / ew;
-    cp.est_blocks = (cp.entry_tiles + kChainTiles - 1) / kChainTiles;
-    cp.attn_blocks = hw * G * h->n_chunks;
-    static const int env_lead = [] { const char* e = getenv("QUEST_CHAIN_LEAD"); return e ? atoi(e) : 0; }();
-    // default: every estimate group ahead of the attention -- with two 8-wave workgroups per CU an attention workgroup
-    // that waits holds a slot an estimate workgroup needs (measured at cfg 3, us per layer: lead 4 25.9, 3 28.4, 2 28.2,
-    // 1 34.7)
-    uint32_t lead = h->chain_lead ? (uint32_t)h->chain_lead : env_lead > 0 ? (uint32_t)env_lead : cp.n_groups;
-    cp.lead = lead < 1 ? 1 : lead > cp.n_groups ? cp.n_groups : lead;
-    tail.est_blocks = cp.est_blocks * cp.n_groups;
-    ChainWait cw{};
-    cw.done = h->chain_sync;
-    cw.error = h->chain_sync + kChainCounterWords;
-    cw.target = cp.est_blocks + cp.n_app;
-    const size_t est_lds = kChainTiles * ((est_tile_lds_bytes(hw, G, D, ew) + 15) & ~(size_t)15);
-    const size_t fe_lds = (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0);
-    const size_t lds = est_lds > fe_lds ? est_lds : fe_lds;
-    const dim3 grid(cp.n_app + cp.n_groups * (cp.est_blocks + cp.attn_blocks));
-    hipStream_t s = (hipStream_t)stream;
-    const bool hnd = metadata.layout == QUEST_LAYOUT_HND;
-    int rc = G == 1 ? launch_chain<128, 1>(hnd, fc, grid, lds, s, (const half_t*)q, (half_t*)scores, metadata, max_n_out, tail, p, cp, cw)
-                    : launch_chain<128, 4>(hnd, fc, grid, lds, s, (const half_t*)q, (half_t*)scores, metadata, max_n_out, tail, p, cp, cw);
-    if (rc) return rc;
-    const uint32_t lines = cp.n_groups * kChainReplicas;
-    if (h->n_chunks > 1 && !h->skip_merge) {
-        hipLaunchKernelGGL((merge_states_kernel<128>), dim3(num_qo_heads), dim3(128 * kMergeGroups), 0, s, (const float*)p.ws, p.o,
-                           QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride, h->chain_sync, lines);
-        QUEST_LAUNCH_CHECK();
-    } else {  // no merge to ride on: re-arm the counters with a memset node
-        hipError_t e = hipMemsetAsync(h->chain_sync, 0, (size_t)lines * kChainLineWords * sizeof(uint32_t), s);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
-}
-
-/* 1 when a chained launch on this handler ever timed out waiting for its producers (device flag; synchronises). */
-extern "C" int quest_chain_error(quest_decode_handler_t* h) {
-    if (!h || !h->chain_sync) return 0;
-    uint32_t flag = 0;
-    if (hipMemcpy(&flag, h->chain_sync + kChainCounterWords, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)flag;
-}
-
-/* Developer aid (-DQUEST_CHAIN_TRACE builds): copy the per-workgroup stamps of the last chained launch, 4 int64 each. */
-extern "C" int quest_chain_trace(quest_decode_handler_t* h, long long* out, uint32_t n_blocks) {
-#ifdef QUEST_CHAIN_TRACE
-    if (!h || !h->chain_sync || !out || n_blocks > kChainTraceBlocks) return QUEST_EINVAL;
-    return (int)hipMemcpy(out, h->chain_sync + kChainCounterWords + 2, (size_t)n_blocks * 4 * sizeof(long long), hipMemcpyDeviceToHost);
-#else
-    (void)h, (void)out, (void)n_blocks;
-    return QUEST_EUNSUPPORTED;
-#endif
-}
-
 extern "C" const char* quest_error_string(int code) {
     switch (code) {
         case 0: return "success";
@@ -978,4 +779,4 @@ extern "C" const char* quest_error_string(int code) {
     }
 }
 
-extern "C" const char* quest_build_info(void) { return "quest_hip gfx950 r1"; }
+extern "C" const char* quest_build_info(void) { return "quest_hip gfx950 r3"; }

@@ -183,32 +183,17 @@ def step_advance_dyn(iController: InferenceController) -> None:
                                 iController.page_size)
 
 
-def chain_default() -> bool:
-    """Whether ``decode_layer_dyn`` takes the chained launch (one grid for append + estimate + top-k + attention) where
-    the shapes allow it.  Off unless ``QUEST_CHAIN=1``: measured on MI355X it ties with the two launches at best
-    (cfg 3: 25.9 vs 23.5 us per layer)."""
-    return os.environ.get("QUEST_CHAIN", "0") == "1"
-
-
 def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
                      layer_idx: int, scores: torch.Tensor, rope_scale: Optional[float] = None,
-                     rope_theta: Optional[float] = None, apply_rope: bool = False,
-                     chain: Optional[bool] = None) -> torch.Tensor:
+                     rope_theta: Optional[float] = None, apply_rope: bool = False) -> torch.Tensor:
     """One layer of a decode token in the sparse regime (pages > budget), every length read from the
     device-resident state: [RoPE] -> append+estimate -> top-k+attention (+merge).  ``scores`` is a
-    caller-owned ``[Hq, >= max_pages]`` fp16 scratch.  ``chain``: run append+estimate+top-k+attention as ONE chained
-    launch where the kernel covers the shapes (same bits; default ``chain_default()``)."""
+    caller-owned ``[Hq, >= max_pages]`` fp16 scratch."""
     ctl = iController
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
     max_n = ctl.max_pages - 1
-    if chain_default() if chain is None else chain:
-        o = torch.empty_like(q)
-        if ctl._decode_handler.chain_decode_dyn(k, v, q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full,
-                                                ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, scores,
-                                                ctl.step_state, max_n):
-            return o
     _kernels.append_estimate_dyn(k, v, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, q, scores,
                                  ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, ctl.step_state, max_n,
                                  ctl.layout)

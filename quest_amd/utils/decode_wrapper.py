@@ -49,17 +49,6 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
         self._wrapper.forward_fused_topk_dyn(q, o, paged_kv_data, page_table, scores, state, max_n_scores)
 
-    def chain_decode_dyn(self, k, v, q, o, paged_kv_data, page_table, metadata_data, meta_table, scores, state,
-                         max_n_scores: int) -> bool:
-        return self._wrapper.chain_decode_dyn(k, v, q, o, paged_kv_data, page_table, metadata_data, meta_table, scores,
-                                              state, max_n_scores)
-
-    def set_chain_lead(self, lead: int) -> None:
-        self._wrapper.set_chain_lead(lead)
-
-    def chain_error(self) -> int:
-        return self._wrapper.chain_error()
-
     def set_batch(self, n_seqs: int) -> None:
         self._wrapper.set_batch(n_seqs)
 
@@ -77,6 +66,9 @@ class BatchDecodeWithPagedKVCacheWrapper:
 
     def set_skip_merge(self, skip: bool) -> None:
         self._wrapper.set_skip_merge(skip)
+
+    def set_merge_mode(self, mode: int) -> None:
+        self._wrapper.set_merge_mode(mode)
 
     def set_front_end(self, generation: int) -> None:
         self._wrapper.set_front_end(generation)
