@@ -273,13 +273,6 @@ int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_
  * per-workgroup partial states in the handler's workspace (the output tensor is NOT written when the plan has
  * more than one workgroup per head).  Lets a bench time the dominant kernel by itself. */
 int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
-/* Where the per-workgroup partial states of a head are merged (the job of flashinfer's VariableLengthMergeStates,
- * call site decode_attn.cuh:992-1001): mode 0 (default) = inside the attention launch, by the workgroup of the head
- * that finishes last (arrival ticket in the handler's workspace; heads split into more than 32 workgroups still take
- * the launch); mode 1 = always by a separate merge launch.  Same bits either way.  The environment variable
- * QUEST_MERGE=launch|inline sets the initial mode of new handlers.  A handler (its workspace and tickets) serves ONE
- * stream at a time. */
-int quest_decode_set_merge_mode(quest_decode_handler_t* h, int mode);
 /* Inspection aid for the state-driven / batched fused launches (quest_decode_forward_fused_topk_dyn/_batched), which
  * otherwise keep the selected pages inside the kernel: while set, every such launch also writes its selection --
  * values (fp16 scores) to val_out and physical page ids to idx_out, both [n_seqs][num_qo_heads][n_selected_pages of

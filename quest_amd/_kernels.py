@@ -598,7 +598,3 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
     def set_skip_merge(self, skip: bool) -> None:
         """Measurement aid: launch only the attention kernel (partial states stay unmerged, ``o`` unwritten)."""
         check(lib.quest_decode_set_skip_merge(self._h, int(bool(skip))), "set_skip_merge")
-
-    def set_merge_mode(self, mode: int) -> None:
-        """0 = the last-arriving workgroup of a head merges inside the attention launch (default), 1 = merge launch."""
-        check(lib.quest_decode_set_merge_mode(self._h, int(mode)), "set_merge_mode")

@@ -76,7 +76,6 @@ SIGNATURES = {
     "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),
     "quest_decode_set_skip_merge": (ctypes.c_int, [c_vp, ctypes.c_int]),
-    "quest_decode_set_merge_mode": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "quest_decode_set_selection_out": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "quest_decode_set_front_end": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "quest_apply_rope_in_place": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp]),

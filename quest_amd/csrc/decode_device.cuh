@@ -1,6 +1,5 @@
 // Device code of the sparse paged decode attention: kernel parameters, the online-softmax row state, the merge of the
-// per-workgroup partial states (by the last-arriving workgroup of a head, or by merge_states_kernel) and the workgroup
-// body of sparse_decode_kernel (sparse_attn.hip, which also holds the reference citations and the design notes).
+// per-workgroup partial states (merge_states_kernel's fast path) and the workgroup body of sparse_decode_kernel (sparse_attn.hip, which also holds the reference citations and the design notes).
 #pragma once
 #include "estimate_device.cuh"
 #include "topk_bitmap.cuh"
@@ -73,8 +72,6 @@ struct DecodeParams {
     uint32_t ids_lds_offset;
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
     uint32_t xcd_period;  // > 1: grid row y serves query head (y % period) * (Hq / period) + y / period (see sparse_decode_kernel)
-    uint32_t* tickets;    // [n_seqs][heads of the grid] arrival counters of the in-kernel merge (zero between launches);
-                          // nullptr: partials are merged by merge_states_kernel (or left unmerged)
 };
 
 // leading scalar kernel arguments (preloaded into SGPRs at wave launch) and their hand-over to the struct; a_pack =
@@ -169,23 +166,12 @@ constexpr int kMergeGroups = 4;   // the chunks of a head are dealt round-robin 
 constexpr int kMergePre = 8;      // chunks per partial sum requested up front (one memory round trip)
 constexpr uint32_t kMergeFastChunks = 32;  // = kMergePre * kMergeGroups <= kWave: the one-round-trip form below
 
-// Partial records handed from one workgroup to another INSIDE a launch: relaxed agent-scope atomics compile to `sc1`
-// accesses -- stores are written through the XCD's L2 to memory (complete device-wide when s_waitcnt vmcnt sees them
-// done), loads bypass non-coherent copies.  A device-scope release FENCE instead would write back the XCD's whole L2
-// (measured in round 2: ~8 us per workgroup).
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool AGENT>
-__device__ __forceinline__ float ld_partial(const float* p) {
-    if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-
 // Merge of one head with n_chunks <= kMergeFastChunks by NT threads (whole waves; D >= 64 so a wave lies inside one
 // feature group).  Every wave derives the chunk weights by itself -- lane c holds chunk c's (m, d) -- so the only
 // barrier is the cross-group sum.  The association order is fixed (chunks g, g+4, g+8, ... ascending into partial sum
-// g; then ((s0 + s1) + s2) + s3), independent of NT: the in-kernel merge and merge_states_kernel give the same bits.
+// g; then ((s0 + s1) + s2) + s3), independent of NT.
 // s_red: kMergeGroups * D floats of LDS.
-template <int D, int NT, bool AGENT>
+template <int D, int NT>
 __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, half_t* __restrict__ o_row, float* lse_ptr,
                                                 uint32_t n_chunks, uint32_t ws_stride, uint32_t tid, float* s_red) {
     constexpr int ITEMS = kMergeGroups * D, PASSES = (ITEMS + NT - 1) / NT;
@@ -196,11 +182,11 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
 #pragma unroll
         for (int j = 0; j < kMergePre; ++j) {
             const uint32_t c = g + j * kMergeGroups, cc = c < n_chunks ? c : n_chunks - 1;  // clamped: no branch
-            pre[r][j] = ld_partial<AGENT>(w + (size_t)cc * ws_stride + f);
+            pre[r][j] = w[(size_t)cc * ws_stride + f];
         }
     }
     const uint32_t lane = tid & 63, lc = lane < n_chunks ? lane : n_chunks - 1;
-    const float m_c = ld_partial<AGENT>(w + (size_t)lc * ws_stride + D), d_c = ld_partial<AGENT>(w + (size_t)lc * ws_stride + D + 1);
+    const float m_c = w[(size_t)lc * ws_stride + D], d_c = w[(size_t)lc * ws_stride + D + 1];
     const float Mw = wave_allreduce_max(lane < n_chunks ? m_c : kNegFloor, (int)lane);
     const float e_c = lane < n_chunks ? __builtin_amdgcn_exp2f(m_c - Mw) : 0.f;
     const float dn = wave_allreduce_sum(e_c * d_c, (int)lane);
@@ -228,27 +214,6 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
         o_row[f] = (half_t)(tot / dn);
         if (lse_ptr && f == 0) *lse_ptr = (Mw + __builtin_amdgcn_logf(dn)) * 0.6931471805599453f;
     }
-}
-
-// In-kernel merge: called by ALL threads of a workgroup after its partial record(s) left by st_agent stores.
-//   every wave waits for its own stores (write-through: complete = in memory), workgroup barrier, ONE relaxed atomic
-//   ticket per (sequence, head); the workgroup that draws n_chunks - 1 knows every record of the head is in memory: it
-//   re-arms the ticket (nobody else touches it before the next launch on this stream), invalidates (acquire fence =
-//   `buffer_inv sc1`) and merges.  Nobody polls or waits for another workgroup.  Returns whether this workgroup merges.
-// One stream per handler: the tickets (like the partial records) belong to the launch in flight.
-__device__ __forceinline__ bool merge_ticket_is_last(uint32_t* ticket, uint32_t n_chunks, uint32_t* s_flag) {
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = old == n_chunks - 1;
-        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = *s_flag != 0u;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return last;
 }
 
 // S_T = compile-time page size (16) or 0 for the generic run-time path.
@@ -612,28 +577,11 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             if (QUEST_LSE_ENABLED && p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
         } else {
             float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
-            if (p.tickets) {  // handed to the merging workgroup of this launch: write-through
-                st_agent(w + f, acc);
-                if (f == 0) {
-                    st_agent(w + D, M);
-                    st_agent(w + D + 1, den);
-                }
-            } else {
-                w[f] = acc;
-                if (f == 0) {
-                    w[D] = M;
-                    w[D + 1] = den;
-                }
+            w[f] = acc;
+            if (f == 0) {
+                w[D] = M;
+                w[D + 1] = den;
             }
-        }
-    }
-    if (p.n_chunks > 1 && p.tickets) {  // launch-uniform
-        __shared__ uint32_t s_last;
-        if (merge_ticket_is_last(p.tickets + (size_t)seq * num_qo_heads + hq, p.n_chunks, &s_last)) {
-            static_assert(NW >= kMergeGroups, "s_acc is reused as the merge's cross-group buffer");
-            merge_head_fast<D, NW * kWave, true>(sv.ws + (size_t)hq * p.n_chunks * p.ws_stride, sv.o + (size_t)hq * D,
-                                                 QUEST_LSE_ENABLED && p.lse ? sv.lse + hq : nullptr, p.n_chunks, p.ws_stride,
-                                                 threadIdx.x, &s_acc[0][0]);
         }
     }
 #ifdef QUEST_TIMELINE

@@ -161,41 +161,23 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
             if (p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
         } else {
             float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
-            if (p.tickets) {  // handed to the merging workgroup of this launch: write-through
-                st_agent(w + f, acc);
-                if (f == 0) {
-                    st_agent(w + D, M);
-                    st_agent(w + D + 1, den);
-                }
-            } else {
-                w[f] = acc;
-                if (f == 0) {
-                    w[D] = M;
-                    w[D + 1] = den;
-                }
-            }
-        }
-    }
-    if (p.n_chunks > 1 && p.tickets) {  // launch-uniform: the last-arriving workgroup of the kv head merges its GS query heads
-        __shared__ uint32_t s_last;
-        if (merge_ticket_is_last(p.tickets + (size_t)blockIdx.z * (a_num_qo_heads / GS) + hk, p.n_chunks, &s_last)) {
-            static_assert(NW * GS >= kMergeGroups, "s_acc is reused as the merge's cross-group buffer");
-            for (uint32_t g = 0; g < (uint32_t)GS; ++g) {
-                const uint32_t hq = hk * GS + g;
-                merge_head_fast<D, NW * kWave, true>(sv.ws + (size_t)hq * p.n_chunks * p.ws_stride, sv.o + (size_t)hq * D,
-                                                     p.lse ? sv.lse + hq : nullptr, p.n_chunks, p.ws_stride, threadIdx.x,
-                                                     &s_acc[0][0][0]);
-                __syncthreads();  // s_acc is rewritten by the next head
+            w[f] = acc;
+            if (f == 0) {
+                w[D] = M;
+                w[D + 1] = den;
             }
         }
     }
 }
 
 // Merge the per-chunk partial states of a head, normalise, cast to fp16 (the job of flashinfer's
-// VariableLengthMergeStates) as a launch of its own: heads with more than kMergeFastChunks chunks, and the
-// QUEST_MERGE=launch / quest_decode_set_merge_mode(1) path (by default the last-arriving workgroup of the
-// attention launch merges, decode_device.cuh).  kMergeGroups thread groups each take every kMergeGroups-th
-// chunk with all of their loads independent (unrolled), then combine through LDS: two memory round trips total.
+// VariableLengthMergeStates).  kMergeGroups thread groups each take every kMergeGroups-th chunk with all of
+// their loads independent (unrolled), then combine through LDS: two memory round trips total.
+// Merging INSIDE the attention launch (the workgroup of a head that draws the last arrival ticket merges; partial
+// records leave by write-through stores) was built twice -- round 1, and round 3 with the recipe of VERDICT r2 item 1a
+// -- bit-identical and slower: every workgroup's tail gains a store acknowledgement and an atomic round trip that
+// queue behind the launch's own streaming reads.  Same box, us per launch incl. merge: cfg 3 14.7 (this launch) vs
+// 22.4 (in-kernel), cfg 2 17.7 vs 20.6, cfg 4 23.8 vs 26.9 (gpurun_out/r3a_*).
 template <int D>
 __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const float* __restrict__ ws,
                                                                         half_t* __restrict__ o,
@@ -208,7 +190,7 @@ __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const flo
     const uint32_t f = tid % D, g = tid / D;
     const float* w = ws + (size_t)hq * n_chunks * ws_stride;
     if (n_chunks <= kMergeFastChunks) {  // launch-uniform
-        merge_head_fast<D, D * kMergeGroups, false>(w, o + (size_t)hq * D, lse ? lse + hq : nullptr, n_chunks, ws_stride, tid,
+        merge_head_fast<D, D * kMergeGroups>(w, o + (size_t)hq * D, lse ? lse + hq : nullptr, n_chunks, ws_stride, tid,
                                                     &s_red[0][0]);
         return;
     }
@@ -280,25 +262,19 @@ struct quest_decode_handler {
     uint32_t n_sel = 0, num_qo_heads = 0, num_kv_heads = 0, head_dim = 0, page_size = 0;
     uint32_t pages_per_chunk = 0, n_chunks = 0;
     uint32_t forced_ppc = 0;
-    void* ws_block = nullptr;  // one allocation: tickets, then the partial records (`ws`)
     float* ws = nullptr;
-    size_t ws_bytes = 0, ticket_bytes = 0;
+    size_t ws_bytes = 0;
     uint32_t ws_stride = 0;
     // Workspaces outgrown by a later plan.  Launches captured in a hipGraph hold the workspace pointer BY VALUE
     // (DecodeParams.ws), so a buffer that any launch was issued on may still be written by a replay: it is
     // retired, never freed before the handler itself is destroyed.  (A few hundred KiB each.)
-    std::vector<void*> retired_ws;
+    std::vector<float*> retired_ws;
     uint32_t dec_waves = 4;
     uint32_t shared_ppc = 0, shared_chunks = 0;  // plan of the group-shared kernel (grid.y = kv heads)
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
     int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation
-    // in-kernel merge: arrival tickets [batch][num_qo_heads] at the head of the workspace block (zeroed when the
-    // block is allocated; the merging workgroup re-arms its ticket).  merge_mode 0 = the last-arriving workgroup of
-    // a head merges (heads of <= kMergeFastChunks chunks; more take the launch), 1 = always merge_states_kernel
-    uint32_t* tickets = nullptr;
-    int merge_mode = 0;
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
 };
@@ -311,11 +287,6 @@ struct quest_decode_handler {
 // launch).
 static uint32_t target_workgroups(const quest_decode_handler* h) { return h->batch > 1 ? h->num_cus : 2 * h->num_cus; }
 static constexpr uint32_t kMaxChunks = 1024;  // merge kernel's LDS weight table
-// whether the last-arriving workgroup of a head merges its partial records inside the attention launch
-static bool merge_in_kernel(const quest_decode_handler* h, uint32_t n_chunks) {
-    return h->merge_mode == 0 && !h->skip_merge && n_chunks > 1 && n_chunks <= kMergeFastChunks && h->tickets != nullptr;
-}
-
 extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout) {
     if (!out || layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
     quest_decode_handler* h = new (std::nothrow) quest_decode_handler();
@@ -328,15 +299,14 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
     else
         (void)hipGetLastError();  // no device (CPU-only import): keep the MI355X default
     if (const char* e = getenv("QUEST_DEC_WAVES")) h->dec_waves = atoi(e) == 8 ? 8 : 4;  // tuning knob
-    if (const char* e = getenv("QUEST_MERGE")) h->merge_mode = e[0] == 'l' ? 1 : 0;      // "launch" / "inline" (A/B)
     *out = h;
     return 0;
 }
 
 extern "C" void quest_decode_handler_destroy(quest_decode_handler_t* h) {
     if (!h) return;
-    if (h->ws_block) (void)hipFree(h->ws_block);
-    for (void* w : h->retired_ws) (void)hipFree(w);
+    if (h->ws) (void)hipFree(h->ws);
+    for (float* w : h->retired_ws) (void)hipFree(w);
     delete h;
 }
 
@@ -349,12 +319,6 @@ extern "C" int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint3
 extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) {
     if (!h) return QUEST_EINVAL;
     h->skip_merge = skip != 0;
-    return 0;
-}
-
-extern "C" int quest_decode_set_merge_mode(quest_decode_handler_t* h, int mode) {
-    if (!h || mode < 0 || mode > 1) return QUEST_EINVAL;
-    h->merge_mode = mode;
     return 0;
 }
 
@@ -420,30 +384,20 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     h->ws_stride = (head_dim + 2 + 31) / 32 * 32;
     const uint32_t max_chunks = h->n_chunks > h->shared_chunks ? h->n_chunks : h->shared_chunks;
     const size_t need = (size_t)h->batch * num_qo_heads * max_chunks * h->ws_stride * sizeof(float);
-    const size_t ticket_bytes = ((size_t)h->batch * num_qo_heads * sizeof(uint32_t) + 255) & ~(size_t)255;
-    if (max_chunks > 1 && (need > h->ws_bytes || ticket_bytes > h->ticket_bytes)) {  // grow-only; reused across begin/end cycles
-        void* bigger = nullptr;
-        const size_t nb = need > h->ws_bytes ? need : h->ws_bytes, tb = ticket_bytes > h->ticket_bytes ? ticket_bytes : h->ticket_bytes;
-        hipError_t e = hipMalloc(&bigger, tb + nb);
+    if (max_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
+        float* bigger = nullptr;
+        hipError_t e = hipMalloc((void**)&bigger, need);
         if (e != hipSuccess) return (int)e;
-        e = hipMemset(bigger, 0, tb);  // (not inside a stream capture: begin_forward never is)
-        if (e != hipSuccess) {
-            (void)hipFree(bigger);
-            return (int)e;
-        }
-        if (h->ws_block) {
+        if (h->ws) {
             try {
-                h->retired_ws.push_back(h->ws_block);  // a captured graph may still reference it (see retired_ws)
+                h->retired_ws.push_back(h->ws);  // a captured graph may still reference it (see retired_ws)
             } catch (...) {
                 (void)hipFree(bigger);
                 return (int)hipErrorOutOfMemory;
             }
         }
-        h->ws_block = bigger;
-        h->tickets = (uint32_t*)bigger;
-        h->ws = (float*)((char*)bigger + tb);
-        h->ws_bytes = nb;
-        h->ticket_bytes = tb;
+        h->ws = bigger;
+        h->ws_bytes = need;
     }
     h->started = true;
     return 0;
@@ -475,7 +429,7 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     else
         hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
     QUEST_LAUNCH_CHECK();
-    if (h->n_chunks > 1 && !p.tickets && !h->skip_merge) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
+    if (h->n_chunks > 1 && !h->skip_merge) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
@@ -552,7 +506,6 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     }
     p.sel_stride = h->n_sel;
     p.ws_stride = h->ws_stride;
-    p.tickets = merge_in_kernel(h, h->n_chunks) ? h->tickets : nullptr;
     p.score_stride = score_stride ? score_stride : n_scores;
     p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
@@ -662,7 +615,7 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, u
         default: return QUEST_EUNSUPPORTED;
     }
     QUEST_LAUNCH_CHECK();
-    if (p.n_chunks > 1 && !p.tickets) {
+    if (p.n_chunks > 1) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, p.lse, p.n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();
@@ -710,8 +663,6 @@ static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.ws_stride = h->ws_stride;
     p.state = state;
     p.table_stride = batch.kv_table_stride;
-    // (skip_merge is a measurement aid of the per-head-list kernel; the group-shared kernel always merges)
-    p.tickets = h->merge_mode == 0 && p.n_chunks > 1 && p.n_chunks <= kMergeFastChunks ? h->tickets : nullptr;
     hipStream_t s = (hipStream_t)stream;
     return kv.head_dim == 64 ? launch_shared<64>(h, p, num_qo_heads, p.group, s, batch.n_seqs)
                              : launch_shared<128>(h, p, num_qo_heads, p.group, s, batch.n_seqs);

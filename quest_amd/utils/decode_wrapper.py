@@ -67,9 +67,6 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def set_skip_merge(self, skip: bool) -> None:
         self._wrapper.set_skip_merge(skip)
 
-    def set_merge_mode(self, mode: int) -> None:
-        self._wrapper.set_merge_mode(mode)
-
     def set_front_end(self, generation: int) -> None:
         self._wrapper.set_front_end(generation)
 
