@@ -24,6 +24,7 @@ sparse_decode_kernel with its top-k front end; algorithmic bytes / HIP-event lau
 "cpu_baseline" (oracle/torch_ref eager port timed on the host cores, bounded sample).
 """
 import argparse
+import datetime
 import json
 import os
 import statistics
@@ -82,6 +83,10 @@ def parse(argv=None):
     ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side configurations (8 sequences per GPU) the default headline run measures after its "
+                         "timed region")
+    ap.add_argument("--side-steps", type=int, default=100, help="timed steps of each side configuration")
     ap.add_argument("--cpu-sample-s", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic K/V/q (SURVEY 8d: seeds 0, 1, 2)")
     a = ap.parse_args(argv)
@@ -106,10 +111,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n):
+RENDEZVOUS_TIMEOUT_S = 120  # init_process_group / collectives: a peer that never shows up must not stall the node
+
+
+def launch_ranks(n, poll_s=0.1):
     """Start n rank processes of this script and relay rank 0's stdout.  The launcher never initialises the
     GPU (no torch.cuda / HIP call) and no process that has done so is ever re-exec'd: every rank is a fresh
-    child.  Returns the exit code (non-zero if any rank failed)."""
+    child.  ALL children are polled: on the first non-zero exit the others are terminated (a rank that dies
+    before the rendezvous would otherwise leave its peers waiting for the process-group timeout) and the
+    launcher returns that exit code promptly, after printing one JSON error line if rank 0 produced none."""
     port = _free_port()
     procs = []
     for r in range(n):
@@ -118,13 +128,42 @@ def launch_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    sys.stdout.write(out.decode())
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # drains rank 0's pipe while every child is being watched
+    failed = None  # (rank, exit code) of the first rank seen to fail
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                failed = (r, code)
+                break
+        if live and failed is None:
+            time.sleep(poll_s)
+    if failed is not None:
+        for r in live:
+            procs[r].terminate()
+        deadline = time.time() + 10
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    reader.join(timeout=10)
+    out = (chunks[0] if chunks else b"").decode()
+    if failed is not None and not any(l.startswith("{") for l in out.splitlines()):
+        out += json.dumps({"error": f"rank {failed[0]} of {n} exited with code {failed[1]}; the other ranks were "
+                                    "terminated", "n_gpus": n, "failed_rank": failed[0], "exit_code": failed[1]}) + "\n"
+    sys.stdout.write(out)
     sys.stdout.flush()
-    return rc
+    return 0 if failed is None else (failed[1] if failed[1] > 0 else 1)
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -495,44 +534,40 @@ def cpu_baseline(a, w, budget_s):
                       f"{per_layer * 1e3:.0f} ms per layer-step, scaled to {a.layers} layers, one sequence"}
 
 
-def main():
-    a = parse()
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        sys.exit(launch_ranks(a.gpus))
+def pmc_traffic(a, n_local):
+    """HBM bytes (read + write) per launch of the dominant kernel of this configuration, from the COMMITTED rocprofv3
+    --pmc passes of this very command (profiles/traffic_latest.json, gfx950 FETCH_SIZE correction applied) -- a lookup,
+    not a measurement of the run that prints it.  Returns (bytes or None, source description)."""
+    tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if "custom" in a.workload_label and not (a.config == 3 and n_local == 8):
+        return None, None
+    try:
+        t = json.load(open(tp))
+        val = t["sparse_decode_kernel_bytes_per_launch"].get(f"cfg{a.config}_seqs{n_local}")
+        return val, ("committed profile profiles/traffic_latest.json (" + t.get("source", "rocprofv3 --pmc") + "); "
+                     "not re-measured by this run")
+    except Exception:
+        return None, None
 
+
+def add_traffic(roof, a, n_local):
+    """roofline.traffic + its source + the fraction of the HBM peak the PMC bytes amount to (next to `frac`, which is
+    algorithmic bytes / time)."""
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(a, n_local)
+    roof["frac_hbm_pmc"] = (roof["traffic"] / (roof["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                            if roof["traffic"] and roof.get("launch_us") else None)
+    if roof["traffic"] and roof["traffic"] < 0.95 * roof.get("algorithmic_bytes_per_launch", 0):
+        roof["traffic_note"] = ("HBM bytes below the algorithmic bytes: with GQA the query heads of a kv-head group "
+                                "run on one XCD (XCD-aware grid order) and re-read each other's pages from its L2")
+
+
+def measure(a, dev, dist, world_seen, rank, stub, side=False):
+    """Build the workload `a` describes, capture the step, time EXACTLY a.steps steps after a.warmup (barrier +
+    synchronize on both sides, max over ranks) and, on rank 0, return the result line as a dict (None elsewhere).
+    side=True: a side configuration measured after the headline -- no CPU baseline, no reference-op side figures."""
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    stub = os.environ.get("QUEST_BENCH_STUB") == "1"
-    rehearse = os.environ.get("QUEST_BENCH_REHEARSE") == "1" or stub
-    if world > 1 or os.environ.get("QUEST_BENCH_FORCE_DIST") == "1":  # the latter: rehearse the RCCL path on 1 GPU
-        import torch.distributed as dist
-
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearse:
-            # rehearsal of the N > 1 control flow on a ONE-GPU (or, with the stub, CPU-only) box: gloo collectives
-            local = 0
-            if not stub:
-                torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        world_seen = dist.get_world_size()
-    else:
-        dist = None
-        world_seen = 1
-    if stub:
-        dev = torch.device("cpu")
-    else:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a GPU: the quest_amd operators have no CPU fallback")
-        dev = torch.device("cuda", local)
-        torch.cuda.set_device(dev)
     sync = (lambda: None) if stub else torch.cuda.synchronize
-
     from quest_amd.parallel import gather_tokens
 
     n_local = a.seqs_per_gpu
@@ -562,11 +597,11 @@ def main():
 
     # ---- the step, eager or captured
     if a.mode in ("graph", "graph-static") and not stub:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
             step_all()  # warm the allocator / plan before capture
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         for wl in ws:
             wl.sync()  # the warm-up advanced the device state; start from the prefilled cache
@@ -657,45 +692,113 @@ def main():
         if not stub:
             ctl0 = w.ctl.seqs[0] if batched else w.ctl
             out["config"]["seqlen_after_run"] = ctl0.kv_cache.seqlen
-            def pmc_traffic():
-                # HBM bytes (read + write) per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-                # very command (profiles/r02_*_pmc_traffic.json, gfx950 FETCH_SIZE correction applied); None for shapes
-                # that were not profiled
-                tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-                if "custom" in a.workload_label and not (a.config == 3 and n_local == 8):
-                    return None
-                try:
-                    return json.load(open(tp))["sparse_decode_kernel_bytes_per_launch"].get(f"cfg{a.config}_seqs{n_local}")
-                except Exception:
-                    return None
-
             if w.dyn and not w.dense:
                 ops, roof = step_op_times(w, a, bpl)
-                roof["traffic"] = pmc_traffic()
-                if roof["traffic"] and roof["traffic"] < 0.95 * roof.get("algorithmic_bytes_per_launch", 0):
-                    roof["traffic_note"] = ("HBM bytes below the algorithmic bytes: with GQA the query heads of a kv-head group "
-                                            "run on one XCD (XCD-aware grid order) and re-read each other's pages from its L2")
+                add_traffic(roof, a, n_local)
                 out["roofline"], out["ops_us"] = roof, ops
-            ref_ops, dense_us = reference_op_times(w, a, bpl)
-            out["reference_op_sequence_us"] = ref_ops
+            dense_us = None
+            if not side:
+                ref_ops, dense_us = reference_op_times(w, a, bpl)
+                out["reference_op_sequence_us"] = ref_ops
             if w.dense and dense_us is not None:  # full-KV config: the dense kernel IS the dominant kernel
                 ach = bpl["dense"] / (dense_us * 1e-6) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": "shared_decode_kernel (full-KV decode, K/V read once per kv head)",
                                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                   "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": bpl["dense"],
-                                   "launch_us": dense_us}
+                                   "traffic": None, "algorithmic_bytes_per_launch": bpl["dense"], "launch_us": dense_us}
+                add_traffic(out["roofline"], a, n_local)
             if dense_us is not None:
                 out["dense_full_kv_us"] = dense_us
                 out["dense_gbs"] = bpl["dense"] / (dense_us * 1e-6) / 1e9
                 out["speedup_vs_dense"] = dense_us / us_per_seq_layer
             if "ops_us" in out and "batched_dense_full_kv_us_per_sequence" in out["ops_us"]:
                 out["speedup_vs_batched_dense"] = out["ops_us"]["batched_dense_full_kv_us_per_sequence"] / us_per_seq_layer
-            if world_seen == 1 and not a.no_cpu_baseline:
+            if world_seen == 1 and not a.no_cpu_baseline and not side:
                 out["cpu_baseline"] = cpu_baseline(a, w, a.cpu_sample_s)
             else:
                 out["cpu_baseline"] = None
         else:
             out["roofline"], out["cpu_baseline"] = None, None
+    return out
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus))
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = os.environ.get("QUEST_BENCH_STUB") == "1"
+    if stub and os.environ.get("QUEST_BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(3)  # tests/test_parallel_gloo.py: a peer that exits before the rendezvous
+    rehearse = os.environ.get("QUEST_BENCH_REHEARSE") == "1" or stub
+    if world > 1 or os.environ.get("QUEST_BENCH_FORCE_DIST") == "1":  # the latter: rehearse the RCCL path on 1 GPU
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rehearse:
+            # rehearsal of the N > 1 control flow on a ONE-GPU (or, with the stub, CPU-only) box: gloo collectives
+            local = 0
+            if not stub:
+                torch.cuda.set_device(0)
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                    timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
+        world_seen = dist.get_world_size()
+    else:
+        dist = None
+        world_seen = 1
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the quest_amd operators have no CPU fallback")
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+    out = measure(a, dev, dist, world_seen, rank, stub)
+
+    # ---- side configurations: where the fixed costs of a launch are shared by 8 sequences per GPU --
+    # the per-GPU load of BASELINE configs[4] -- measured AFTER the headline, outside `value`: the headline shapes x 8
+    # sequences (MHA) and configs[4] itself (GQA).  Only in the driver's default single-GPU headline run.
+    if (out is not None and not stub and world_seen == 1 and dist is None and a.config == 3 and not a.no_side
+            and "custom" not in a.workload_label and a.mode == "graph"):
+        import gc
+
+        for name, overrides in (("batched_8seq", dict(config=3, seqs_per_gpu=8)),
+                                ("cfg5_8seq_gqa", dict(config=5))):
+            gc.collect()
+            torch.cuda.empty_cache()
+            a2 = parse(["--config", str(overrides["config"]), "--steps", str(a.side_steps), "--warmup", str(a.warmup),
+                        "--seed", str(a.seed), "--no-cpu-baseline"]
+                       + (["--seqs-per-gpu", str(overrides["seqs_per_gpu"])] if "seqs_per_gpu" in overrides else []))
+            try:
+                full = measure(a2, dev, None, 1, 0, False, side=True)
+            except Exception as exc:  # the headline line must survive a side measurement that fails (e.g. memory)
+                out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                continue
+            roof, ops = full.get("roofline") or {}, full.get("ops_us") or {}
+            out[name] = {
+                "workload": full["config"]["workload"], "sequences_per_gpu": full["config"]["sequences_per_gpu"],
+                "steps": full["steps"], "tokens_per_s": full["value"], "ms_per_step": full["ms_per_step"],
+                "us_per_sequence_layer": full["selfattn_us_per_layer"],
+                "chain_frac_of_hbm_peak": full["chain_frac_of_hbm_peak"],
+                "dominant_kernel": roof.get("kernel"), "dominant_kernel_launch_us": roof.get("launch_us"),
+                "dominant_kernel_frac_algorithmic": roof.get("frac"), "dominant_kernel_frac_hbm_pmc": roof.get("frac_hbm_pmc"),
+                "dominant_kernel_traffic_bytes": roof.get("traffic"), "traffic_source": roof.get("traffic_source"),
+                "append_estimate_us": ops.get("append_estimate_us"),
+                "append_estimate_frac_of_hbm_peak": ops.get("append_estimate_frac_of_hbm_peak"),
+                "batched_dense_full_kv_us_per_sequence": ops.get("batched_dense_full_kv_us_per_sequence"),
+                "speedup_vs_batched_dense": full.get("speedup_vs_batched_dense"),
+                "speedup_vs_single_sequence_dense": (out["dense_full_kv_us"] / full["selfattn_us_per_layer"]
+                                                     if overrides["config"] == 3 and out.get("dense_full_kv_us") else None),
+                "note": "measured after the headline timing in the same process; not part of `value`",
+            }
+
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -704,4 +807,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as exc:  # one machine-readable line for whoever parses stdout, then the traceback as usual
+        if os.environ.get("RANK", "0") == "0":
+            print(json.dumps({"error": f"{type(exc).__name__}: {exc}", "rank": 0}), flush=True)
+        raise

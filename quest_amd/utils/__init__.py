@@ -178,7 +178,18 @@ def score_scratch(controller) -> torch.Tensor:
     return torch.empty(shape, dtype=torch.float16, device=controller.device)
 
 
+def _need_state(controller) -> None:
+    """The state-driven ops read lengths and page tables from device memory: `enable_device_state()` must have been
+    called after the prefill (and again after `clean_states()` / `quest_clear()`, which drop it)."""
+    state = getattr(controller, "step_state", None) if not isinstance(controller, BatchedInferenceController) \
+        else getattr(controller, "step_states", None)
+    if state is None:
+        raise RuntimeError("the controller has no device-resident step state: call enable_device_state() after the "
+                           "prefill (clean_states() / quest_clear() drop it)")
+
+
 def step_advance_dyn(iController: InferenceController) -> None:
+    _need_state(iController)
     _kernels.step_state_advance(iController.step_state, iController.kv_table_full, iController.meta_table_full,
                                 iController.page_size)
 
@@ -190,6 +201,7 @@ def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iControl
     device-resident state: [RoPE] -> append+estimate -> top-k+attention (+merge).  ``scores`` is a
     caller-owned ``[Hq, >= max_pages]`` fp16 scratch."""
     ctl = iController
+    _need_state(ctl)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
@@ -210,6 +222,7 @@ def decode_layer_dense_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iC
     [RoPE] -> append -> attention over all pages (group-shared kernel) (+merge).  Needs
     ``begin_graph_decode(dense_layers=True)``."""
     ctl = iController
+    _need_state(ctl)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
@@ -237,6 +250,7 @@ def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bCon
                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``decode_layer_dyn`` for every sequence at once; ``scores`` is ``[n_seqs, Hq, >= max_pages]`` fp16."""
     b = bController
+    _need_state(b)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_batched(q, k, scale, theta, b.step_states)
@@ -254,6 +268,7 @@ def decode_layer_dense_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor
                                apply_rope: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``decode_layer_dense_dyn`` for every sequence at once (needs ``begin_graph_decode(dense_layers=True)``)."""
     b = bController
+    _need_state(b)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_batched(q, k, scale, theta, b.step_states)

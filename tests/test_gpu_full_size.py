@@ -202,3 +202,36 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
         last = c.kv_cache.indicies[-1]
         slot = (L - 1) % PAGE
         assert torch.equal(b.kv_layer(0)[last, 0, slot], ks[i][-1]) and torch.equal(b.kv_layer(0)[last, 1, slot], vs[i][-1])
+
+
+def test_cfg2_longchat_4096_tokens_budget_512_pages_full_kv():
+    """BASELINE configs[1] at its exact shape (SURVEY cfg 2): Hq = Hkv = 32, D = 128, L = 4096 (256 pages), page budget
+    512 >= 256 -> the reference's full-KV branch (QuestAttention.py:123-132, bench_batch_decode.cu's published row).
+    The state-driven dense layer (`decode_layer_dense_dyn`: append + group-shared attention + merge) against fp32
+    torch attention over the whole context, for the token that fills the 256th page and the one that opens the 257th."""
+    import quest_amd.utils as qu
+
+    dev = torch.device(DEV)
+    H, L, budget = 32, 4096, 512
+    g = torch.Generator(device=dev).manual_seed(21)
+    k = torch.randn(L + 1, H, D, generator=g, device=dev, dtype=torch.float16)
+    v = torch.randn(L + 1, H, D, generator=g, device=dev, dtype=torch.float16)
+    q = torch.randn(2, 1, H, D, generator=g, device=dev, dtype=torch.float16)
+    ctl = qu.InferenceController(1, H, D, PAGE, budget, L + 4 * PAGE, torch.float16, dev, shuffle_seed=6)
+    ctl.prepare_metadata(L - 1)
+    ctl.begin_forward(L - 1)
+    qu.append_kv(k[:L - 1], v[:L - 1], ctl, 0)
+    ctl.end_forward()
+    ctl.enable_device_state()
+    ctl.begin_graph_decode(dense_layers=True)
+    for t, n_tok in enumerate((L, L + 1)):
+        qu.step_advance_dyn(ctl)
+        o = qu.decode_layer_dense_dyn(q[t], k[n_tok - 1:n_tok], v[n_tok - 1:n_tok], ctl, 0)
+        ctl.prepare_metadata(1)
+        assert not ctl.need_estimate()  # 256 / 257 pages <= budget 512: full KV
+        kf, vf = k[:n_tok].float(), v[:n_tok].float()
+        p = torch.softmax(torch.einsum("hd,lhd->hl", q[t, 0].float(), kf) / D ** 0.5, -1)
+        ref = torch.einsum("hl,lhd->hd", p, vf)
+        torch.testing.assert_close(o[0].float(), ref, rtol=5e-3, atol=5e-3)
+        assert (o[0].float() - ref).abs().max() < 2e-3
+    assert ctl.kv_cache.seqlen == L + 1 and len(ctl.kv_cache.indicies) == 257

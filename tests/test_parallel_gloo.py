@@ -90,6 +90,48 @@ def test_bench_launcher_starts_n_ranks_and_reports_world_size():
     assert abs(out["value"] - 2 * 8 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-6
 
 
+def test_bench_launcher_returns_promptly_when_a_peer_dies_before_rendezvous():
+    """Rank 1 exits (code 3) before init_process_group: the launcher must notice, terminate rank 0 (which would
+    otherwise sit in the rendezvous until the process-group timeout), print one JSON error line and return non-zero
+    well inside 30 s -- an 8-GPU SCALE point must never hang on a bad LOCAL_RANK / missing GPU / OOM of one rank."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["QUEST_BENCH_STUB"] = "1"
+    env["QUEST_BENCH_STUB_FAIL_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    took = time.time() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert took < 30, took
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    err = json.loads(lines[0])
+    assert err["failed_rank"] == 1 and err["exit_code"] == 3 and err["n_gpus"] == 2 and "error" in err
+
+
+def test_bench_launcher_reports_a_failing_rank0():
+    """Rank 0 itself dies: still one JSON error line and a non-zero exit code, and rank 1 does not linger."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["QUEST_BENCH_STUB"] = "1"
+    env["QUEST_BENCH_STUB_FAIL_RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["failed_rank"] == 0
+
+
 def test_bench_config_labels_follow_the_arguments():
     import importlib.util
 
