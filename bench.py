@@ -83,6 +83,10 @@ def parse(argv=None):
     ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--kernel-sweep", action="store_true",
+                    help="instead of the step bench: the reference's own kernel benches row for row (attention kernel "
+                         "alone at seqlen 4096 x budgets 64-512 and 32768 x 256/640/896, top-k and estimate at the six "
+                         "LongBench pairs of scripts/bench_kernels.sh) -> gpurun_out/kernel_sweep.json + a markdown table")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side configurations (8 sequences per GPU) the default headline run measures after its "
                          "timed region")
@@ -723,6 +727,15 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
 
 def main():
     a = parse()
+    if a.kernel_sweep:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import kbench_reference_rows as sweep
+
+        path = os.path.join(ROOT, "gpurun_out", "kernel_sweep.json")
+        res = sweep.run(out_path=path)
+        print(sweep.markdown(res), file=sys.stderr)
+        print(json.dumps({"kernel_sweep": os.path.relpath(path, ROOT), "rows": res["rows"]}), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a.gpus))
 
