@@ -281,7 +281,8 @@ int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
 int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int32_t* idx_out);
 /* Which top-k front end the fused launches use: 0 = chosen by row length (default), 1 = first generation
  * (csrc/topk_select.cuh; rows up to 4096 pages), 2 = second generation (csrc/topk_bitmap.cuh; needs 8-byte aligned
- * score rows).  Both implement the same selection (bit-identical page lists); tuning / test aid. */
+ * score rows) without its histogram pre-filter, 3 = second generation with the pre-filter (the default beyond 4096
+ * pages).  All implement the same selection (bit-identical page lists); tuning / test aid. */
 int quest_decode_set_front_end(quest_decode_handler_t* h, int generation);
 /* Override the planner (0 = automatic).  Used by tuning sweeps. */
 int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);

@@ -72,6 +72,7 @@ struct DecodeParams {
     uint32_t ids_lds_offset;
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
     uint32_t xcd_period;  // > 1: grid row y serves query head (y % period) * (Hq / period) + y / period (see sparse_decode_kernel)
+    uint32_t fe2_prefilter;  // second-generation front end: histogram only the keys above a per-wave lower bound (topk_bitmap.cuh)
 };
 
 // leading scalar kernel arguments (preloaded into SGPRs at wave launch) and their hand-over to the struct; a_pack =
@@ -336,7 +337,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             int32_t* idx_row_out = p.sel_idx_out ? p.sel_idx_out + out_row : nullptr;
             fe2_select<NT, FC>(sm, s_bm, raw, srow, sv.indices,
                                ids_staged ? reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset) : nullptr, n_cap, n,
-                               p.n_sel, slot_begin, slot_end, s_sel, val_row, idx_row_out
+                               p.n_sel, slot_begin, slot_end, s_sel, val_row, idx_row_out, p.fe2_prefilter != 0
 #ifdef QUEST_TIMELINE
                                , sub_out
 #endif

@@ -274,7 +274,7 @@ struct quest_decode_handler {
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
-    int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation
+    int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation, 3 = 2 + pre-filter
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
 };
@@ -323,7 +323,7 @@ extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) 
 }
 
 extern "C" int quest_decode_set_front_end(quest_decode_handler_t* h, int generation) {
-    if (!h || generation < 0 || generation > 2) return QUEST_EINVAL;
+    if (!h || generation < 0 || generation > 3) return QUEST_EINVAL;
     h->front_end = generation;
     return 0;
 }
@@ -525,7 +525,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         const bool table_aligned = ((uintptr_t)kv.indices & 15u) == 0 && (batch.n_seqs == 1 || batch.kv_table_stride % 4u == 0);
         int gen = 1;
         if (aligned) {
-            if (forced == 2 || (forced == 0 && n_scores > 4096u)) gen = 2;
+            if (forced == 2 || forced == 3 || (forced == 0 && n_scores > 4096u)) gen = 2;
         }
         if (gen != 1) {
             p.vec_front = 2;
@@ -533,6 +533,10 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
             // page ids are staged with 16-byte loads: the table(s) must be 16-byte aligned
             if (!table_aligned) p.stage_ids = 0;
             // (gen 2 stages ids only in the instantiations with <= 16 keys per thread: rows <= 4096 columns)
+            // pre-filter of the histogram: pays where a thread holds many keys (rows beyond 4096 columns); QUEST_FE2_PREFILTER=0
+            // turns it off, =2 turns it on for every second-generation launch (tuning, tests)
+            static const int pre_env = [] { const char* e = getenv("QUEST_FE2_PREFILTER"); return e ? atoi(e) : 1; }();
+            p.fe2_prefilter = forced == 3 || pre_env == 2 || (pre_env == 1 && forced != 2 && n_scores > 4096u) ? 1u : 0u;
         } else if (aligned && table_aligned && p.stage_ids && forced != 1) {
             p.vec_front = 1;  // generation 1 with its staging arrays filled by the granule loads (8 / 16 bytes per lane)
         }

@@ -31,7 +31,10 @@ struct Fe2Raw<true> {
     uint2 k;
     uint4 ids;   // their physical page ids (rows short enough for the ids to be staged in LDS)
 };
-// page ids are staged in LDS for rows of up to 4096 columns: 8 keys per thread at 512 threads, 16 at 256
+// page ids are staged in LDS for rows of up to 4096 columns: 8 keys per thread at 512 threads, 16 at 256.  (Staging
+// them for rows up to 8192 columns as well -- 32 KiB -- was measured in round 3 at cfg 4: 22.5 vs 21.6 us per launch.
+// The 2.3 us the timeline shows between "selection done" and "page list in LDS" is not the column -> page round trip
+// of fe2_resolve_pages but the younger waves of the SIMD catching up with wave 0 on an issue-bound phase.)
 constexpr bool fe2_has_ids(int FC) { return FC <= 16; }
 
 // Issue the loads of the thread's granules (rounds < RMAX): call first, before anything waits on memory.
@@ -152,7 +155,8 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
                                            const Fe2Raw<fe2_has_ids(FC)> (&raw)[FC / 4],
                                            const uint16_t* srow, const int32_t* table, int32_t* ids_s, uint32_t n_cap,
                                            uint32_t n, uint32_t k, uint32_t slot_begin, uint32_t slot_end, int32_t* s_sel,
-                                           uint16_t* sel_val_row, int32_t* sel_idx_row, long long* sub = nullptr) {
+                                           uint16_t* sel_val_row, int32_t* sel_idx_row, bool prefilter,
+                                           long long* sub = nullptr) {
     constexpr int RMAX = FC / 4, NWV = NT / kWave;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,6 +194,26 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
         mm = ((xl > xh ? xl : xh) << 16) | (0xffffu - (nl < nh ? nl : nh));  // (max, 0xffff - min) of the thread's keys
     }
     topk_publish_range<NT>(sm, mm);
+    // Pre-filter of long rows (a thread holds many keys, the histogram's LDS atomics dominate: 8191 of them cost 1.85 us
+    // at cfg 4).  Every wave finds the j-th largest of its 64 per-thread MAXIMA, j = ceil(k / waves), by bisection over
+    // the 16 key bits with ballots: at least j of the wave's keys reach that value, so at least k keys of the row reach
+    // the minimum over the waves -- a guaranteed lower bound LB of the threshold key.  Only keys >= LB enter the
+    // histogram (a few hundred instead of thousands; bins then start at LB, which usually makes a bin a single key
+    // value).  Threshold, tie count and bitmaps are exact as before: same T, same pages.  No extra barrier (LB rides
+    // with the range).
+    const uint32_t jw = (k + (uint32_t)NWV - 1u) / (uint32_t)NWV;
+    prefilter = prefilter && jw <= (uint32_t)kWave;
+    if (prefilter) {  // block-uniform
+        const uint32_t tmax = mm >> 16;  // the thread's largest valid key (0 when it holds none)
+        uint32_t m = 0u;
+#pragma unroll
+        for (int bit = 15; bit >= 0; --bit) {
+            const uint32_t cand = m | (1u << bit);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(tmax >= cand));
+            m = cnt >= jw ? cand : m;
+        }
+        if (lane == 0u) sm.wave_lb[wave] = m;
+    }
     QUEST_SUBSTAMP(0);
     __syncthreads();  // A: range + cleared histograms (+ ids) visible
     QUEST_SUBSTAMP(1);
@@ -197,7 +221,14 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
     mm = kMmNeutral;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) mm = pk_max_u16(mm, sm.wave_mm[w]);
-    const uint32_t kmax = mm >> 16, kmin = 0xffffu - (mm & 0xffffu);
+    uint32_t kmin = 0xffffu - (mm & 0xffffu);
+    const uint32_t kmax = mm >> 16;
+    if (prefilter) {  // bins start at the lower bound of the threshold; keys below it are neither counted nor selected
+        uint32_t lb = 0xffffu;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) lb = min(lb, sm.wave_lb[w]);
+        kmin = max(kmin, lb);
+    }
     const uint32_t range = kmax - kmin;
     const uint32_t bits = 32u - (uint32_t)__builtin_clz(range | 1u);
     const uint32_t shift = bits > 11u ? bits - 11u : 0u;
@@ -206,8 +237,10 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
         if ((uint32_t)r < rounds) {
             const uint32_t c0 = 4u * (tid + (uint32_t)r * NT);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (c0 + i < n) atomicAdd(&sm.hist1[(key_at(key2, 4 * r + i) - kmin) >> shift], 1u);
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t kk = key_at(key2, 4 * r + i);
+                if (c0 + i < n && kk >= kmin) atomicAdd(&sm.hist1[(kk - kmin) >> shift], 1u);
+            }
         }
     QUEST_SUBSTAMP(2);
     __syncthreads();  // B: histogram complete
@@ -254,9 +287,11 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
                 if ((uint32_t)r < rounds) {
                     const uint32_t c0 = 4u * (tid + (uint32_t)r * NT);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (c0 + i < n && ((key_at(key2, 4 * r + i) - kmin) >> shift) == thr_bin)
-                            atomicAdd(&sm.hist2[(key_at(key2, 4 * r + i) - kmin) & low_mask], 1u);
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t kk = key_at(key2, 4 * r + i);
+                        if (c0 + i < n && kk >= kmin && ((kk - kmin) >> shift) == thr_bin)
+                            atomicAdd(&sm.hist2[(kk - kmin) & low_mask], 1u);
+                    }
                 }
             __syncthreads();  // (only rows spanning >= 2048 key values)
             const uint32_t c3 = lane < (uint32_t)kBins2 ? sm.hist2[kBins2 - 1 - lane] : 0u;

@@ -118,6 +118,19 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
     torch.testing.assert_close(o2[0].float(), o_ref, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
+    # the same step (the append is idempotent) without and with the histogram pre-filter of the long-row front end
+    # (csrc/topk_bitmap.cuh; the default above is "with"): same pages, same bits
+    for gen in (2, 3):
+        ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
+        ctl._decode_handler.set_front_end(gen)
+        sel_i2 = torch.full_like(sel_i, -1)
+        ctl._decode_handler.set_selection_out(None, sel_i2)
+        qu.step_advance_dyn(ctl)
+        o3 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, qu.score_scratch(ctl).zero_())
+        ctl._decode_handler.set_selection_out(None, None)
+        assert torch.equal(sel_i2, sel_i), f"front end {gen}: page lists differ"
+        assert torch.equal(o3, o2), f"front end {gen}"
+    ctl._decode_handler.set_front_end(0)
     ctl.end_forward()
 
     # ---- dense decode of the same cache (the speed-up's baseline): group-shared kernel == torch fp32 full attention
@@ -169,7 +182,7 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
     b.step_states[:, 2] -= 1   # kv_last_page_len (every sequence's last page holds >= 2 tokens here)
     assert bool((b.step_states[:, 2] >= 1).all())
     rewound = b.step_states.clone()
-    for gen in (1, 2):
+    for gen in (1, 2, 3):
         b.step_states.copy_(rewound)
         b._decode_handler.set_front_end(gen)
         sel_i2 = torch.full_like(sel_i, -1)

@@ -79,6 +79,7 @@ def test_random_shape_chain_matches_oracle(case):
         # both top-k front ends of the fused launch: first generation (csrc/topk_select.cuh; any row stride) and
         # second (csrc/topk_bitmap.cuh; 8-byte aligned rows), then the default choice
         for gen, scores in ((2, qu.score_scratch(ctl).zero_()),
+                            (3, qu.score_scratch(ctl).zero_()),  # second generation with its histogram pre-filter
                             (1, torch.zeros(Hq, ctl.max_pages | 1, dtype=torch.float16, device="cuda:0")),
                             (0, qu.score_scratch(ctl).zero_())):
             ctl._decode_handler.set_front_end(gen)
