@@ -237,6 +237,12 @@ typedef struct quest_batch {
     uint32_t kv_table_stride;   /* int32 entries between consecutive sequences' KV page tables */
     uint32_t meta_table_stride; /* ... metadata page tables */
     uint32_t reserved;
+    /* Optional per-sequence page budgets, device int32[n_seqs]: pages sequence i attends INCLUDING its current page
+     * (the reference's per-request page budget: InferenceController.set_page_budget, quest/utils/controller.py:39-41,
+     * one controller per request).  NULL: every sequence takes the budget the handler was planned with.  With
+     * budgets, plan the handler (begin_forward) with the LARGEST one; sequence i then selects
+     * min(budget[i] - 1, its pages - 1) pages. */
+    const int32_t* page_budgets;
 } quest_batch_t;
 
 /* quest_step_state_advance for every sequence of the batch (tables: [n_seqs][*_table_stride], each row
@@ -259,6 +265,29 @@ int quest_append_kv_cache_decode_batched(const void* k, const void* v, quest_pag
 int quest_decode_forward_shared_batched(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
                                         uint32_t num_qo_heads, const quest_step_state_t* state, quest_batch_t batch,
                                         float* lse, quest_stream_t stream);
+/*
+ * The four operators of a decode step one by one for a whole batch (the state-driven counterparts of
+ * append_kv_cache_decode / estimate_attn_score / topk_filtering / BatchDecodeWithPagedKVCache.forward, bsk_ops.h:38-116,
+ * as quest/utils/__init__.py:141-276 calls them per request): quest_append_kv_cache_decode_batched above, and
+ *   estimate : o[n_seqs][num_qo_heads][o_stride], row i scored over state[i].n_pages - 1 pages;
+ *   top-k    : per (sequence, head) the k_i = min(budget_i - 1, n_pages_i - 1) largest scores of the row and the
+ *              physical pages they belong to (kv_tables[i][column]), written to the first k_i entries of rows of
+ *              out_stride entries; page_budget = the launch-wide budget (pages incl. the current one) used where
+ *              batch.page_budgets is NULL;
+ *   attention: per (sequence, head) over indices[i][h][0 .. k_i) + the current page; plan the handler with
+ *              begin_forward(n_selected_pages = max_i budget_i - 1) after quest_decode_set_batch.
+ * Same bits as the single-sequence operators on each sequence.
+ */
+int quest_estimate_attn_score_batched(const void* q, void* o, uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                                      quest_paged_kv_t metadata, const quest_step_state_t* state, quest_batch_t batch,
+                                      quest_stream_t stream);
+int quest_topk_filtering_batched(const void* scores, uint32_t score_stride, uint32_t max_num_pages, const int32_t* kv_tables,
+                                 void* d_out, int32_t* indices_out, uint32_t out_stride, uint32_t num_heads,
+                                 uint32_t page_budget, const quest_step_state_t* state, quest_batch_t batch,
+                                 quest_stream_t stream);
+int quest_decode_forward_batched(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                 uint32_t num_qo_heads, const int32_t* indices, uint32_t idx_stride,
+                                 const quest_step_state_t* state, quest_batch_t batch, float* lse, quest_stream_t stream);
 /* q: [n_seqs][num_qo_heads][dim], k: [n_seqs][num_kv_heads][dim]; row i sits at position state[i].seq_len - 1. */
 int quest_apply_rope_in_place_batched(void* q, void* k, uint32_t num_qo_heads, uint32_t num_kv_heads,
                                       uint32_t head_dim, float rope_scale, float rope_theta,

@@ -295,9 +295,17 @@ def apply_rope_in_place_dyn(q, k, rope_scale: float, rope_theta: float, state) -
 # Batched state-driven step (EXTENSION; SURVEY 8f-3, BASELINE config 5): n sequences per launch.  The pools
 # are shared, page tables are rows of ``[n, stride]`` int32 matrices, ``state`` is ``[n, 8]`` int32,
 # q/k/v/o are ``[n, heads, dim]``, scores ``[n, Hq, stride]``.
-def _batch(state, kv_tables, meta_tables) -> Batch:
+def _batch(state, kv_tables, meta_tables, budgets=None) -> Batch:
+    """quest_batch_t.  ``budgets``: optional int32 ``[n]`` device tensor of per-sequence page budgets (pages a sequence
+    attends INCLUDING its current one); None = the budget the handler was planned with, for every sequence."""
     _check_dim(2, state, "state")
     n = state.size(0)
+    if budgets is not None:
+        _check_input(budgets, "page_budgets")
+        _check_dim(1, budgets, "page_budgets")
+        _check_eq(budgets.size(0), n, "page_budgets.size(0), n_seqs")
+        if budgets.dtype != torch.int32:
+            raise RuntimeError("page_budgets must be an int32 tensor")
     for t, name in ((kv_tables, "kv_tables"), (meta_tables, "meta_tables")):
         if t is not None:
             _check_input(t, name)
@@ -305,7 +313,8 @@ def _batch(state, kv_tables, meta_tables) -> Batch:
             _check_eq(t.size(0), n, f"{name}.size(0), n_seqs")
             if t.dtype != torch.int32:
                 raise RuntimeError(f"{name} must be an int32 tensor")
-    return Batch(n, 0 if kv_tables is None else kv_tables.size(1), 0 if meta_tables is None else meta_tables.size(1), 0)
+    return Batch(n, 0 if kv_tables is None else kv_tables.size(1), 0 if meta_tables is None else meta_tables.size(1), 0,
+                 None if budgets is None else budgets.data_ptr())
 
 
 def step_state_advance_batched(state, kv_tables, meta_tables, page_size: int) -> None:
@@ -337,6 +346,47 @@ def append_estimate_batched(k, v, kv_data, kv_tables, q, o, metadata_data, meta_
     check(lib.quest_append_estimate_batched(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1),
                                             o.size(2), int(max_n_out), meta, state.data_ptr(), b, _stream(k)),
           "append_estimate_batched")
+
+
+def estimate_attn_score_batched(q, o, metadata_data, meta_tables, state, max_n_out: int, layout: int) -> None:
+    """estimate_attn_score (estimate.cu:6-84) for ``n`` sequences in one launch: q ``[n, Hq, D]``, o ``[n, Hq, stride]``;
+    row i is scored over ``state[i].n_pages - 1`` pages."""
+    for t, n in ((q, "q"), (o, "o"), (metadata_data, "metadata_data"), (state, "state")):
+        _check_input(t, n)
+    b = _batch(state, None, meta_tables)
+    _check_dim(3, q, "q")
+    _check_dim(3, o, "o")
+    _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+    _check_eq(o.size(0), b.n_seqs, "o.size(0), n_seqs")
+    _check_eq(o.size(1), q.size(1), "o.size(1), num_heads")
+    _check_ge(o.size(2), max_n_out, "o.size(2), max_n_out")
+    _check_half(q, "Estimate_attn_score")
+    meta = _paged(metadata_data, meta_tables, None, 1, 0, layout)
+    check(lib.quest_estimate_attn_score_batched(q.data_ptr(), o.data_ptr(), q.size(1), o.size(2), int(max_n_out), meta,
+                                                state.data_ptr(), b, _stream(q)), "Estimate_attn_score")
+
+
+def topk_filtering_batched(scores, kv_tables, d_out, indices_out, state, max_num_pages: int, page_budget: int,
+                           budgets=None) -> None:
+    """topk_filtering (topk.cu:7-46) for ``n`` sequences in one launch: scores ``[n, H, stride]``, page ids = each
+    sequence's own page table ``kv_tables[i]``, outputs ``[n, H, k_max]`` of which row (i, h) gets its first
+    ``min(budget_i - 1, n_pages_i - 1)`` entries written (``budget_i`` from ``budgets`` or ``page_budget``)."""
+    for t, n in ((scores, "scores"), (d_out, "d_out"), (indices_out, "indices_out"), (state, "state")):
+        _check_input(t, n)
+    b = _batch(state, kv_tables, None, budgets)
+    _check_dim(3, scores, "scores")
+    _check_dim(3, d_out, "d_out")
+    _check_dim(3, indices_out, "indices_out")
+    _check_eq(scores.size(0), b.n_seqs, "scores.size(0), n_seqs")
+    _check_eq(d_out.size(0), b.n_seqs, "d_out.size(0), n_seqs")
+    _check_eq(d_out.size(1), scores.size(1), "d_out.size(1), num_heads")
+    _check_eq(tuple(indices_out.shape), tuple(d_out.shape), "indices_out.shape, d_out.shape")
+    _check_eq(indices_out.dtype, torch.int32, "indices_out.scalar_type(), torch::kInt32")
+    _check_ge(scores.size(2), max_num_pages, "scores.size(2), max_num_pages")
+    _check_half(scores, "Top-k filtering")
+    check(lib.quest_topk_filtering_batched(scores.data_ptr(), scores.size(2), int(max_num_pages), kv_tables.data_ptr(),
+                                           d_out.data_ptr(), indices_out.data_ptr(), d_out.size(2), scores.size(1),
+                                           int(page_budget), state.data_ptr(), b, _stream(scores)), "Top-k filtering")
 
 
 def append_kv_cache_decode_batched(k, v, kv_data, kv_tables, metadata_data, meta_tables, state, layout: int) -> None:
@@ -537,11 +587,30 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         """Sequences per launch the NEXT begin_forward plans for (workspace, work split)."""
         check(lib.quest_decode_set_batch(self._h, int(n_seqs)), "set_batch")
 
-    def forward_fused_topk_batched(self, q, o, paged_kv_data, kv_tables, scores, state, max_n_scores: int) -> None:
+    def forward_batched(self, q, o, paged_kv_data, indices, state, budgets=None) -> None:
+        """forward for ``n`` sequences in one launch: q/o ``[n, Hq, D]``, indices ``[n, Hq, k_max]`` (int32) of which
+        row (i, h) is read up to ``min(budget_i - 1, n_pages_i - 1)`` entries; the current page comes from ``state``."""
+        for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (indices, "indices"), (state, "state")):
+            _check_input(t, n)
+        b = _batch(state, None, None, budgets)
+        _check_dim(3, q, "q")
+        _check_dim(3, indices, "indices")
+        _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+        _check_eq(indices.size(0), b.n_seqs, "indices.size(0), n_seqs")
+        _check_eq(indices.size(1), q.size(1), "indices.size(1), num_qo_heads")
+        _check_eq(indices.dtype, torch.int32, "indices.scalar_type(), torch::kInt32")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, None, None, 1, 0, self._layout)
+        check(lib.quest_decode_forward_batched(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), indices.data_ptr(),
+                                               indices.size(2), state.data_ptr(), b, None, _stream(q)),
+              "BatchDecodeWithPagedKVCache")
+
+    def forward_fused_topk_batched(self, q, o, paged_kv_data, kv_tables, scores, state, max_n_scores: int,
+                                   budgets=None) -> None:
         """forward_fused_topk_dyn for ``n`` sequences in one launch: q/o ``[n, Hq, D]``, scores ``[n, Hq, stride]``."""
         for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (scores, "scores"), (state, "state")):
             _check_input(t, n)
-        b = _batch(state, kv_tables, None)
+        b = _batch(state, kv_tables, None, budgets)
         _check_dim(3, q, "q")
         _check_dim(3, scores, "scores")
         _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")

@@ -35,7 +35,8 @@ class PagedKV(ctypes.Structure):
 class Batch(ctypes.Structure):
     """quest_batch_t (include/quest_hip.h)."""
 
-    _fields_ = [("n_seqs", c_u32), ("kv_table_stride", c_u32), ("meta_table_stride", c_u32), ("reserved", c_u32)]
+    _fields_ = [("n_seqs", c_u32), ("kv_table_stride", c_u32), ("meta_table_stride", c_u32), ("reserved", c_u32),
+                ("page_budgets", c_vp)]
 
 
 # name -> (restype, argtypes); must list every function include/quest_hip.h declares
@@ -72,6 +73,10 @@ SIGNATURES = {
     "quest_decode_forward_shared_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, Batch, c_vp, c_vp]),
     "quest_apply_rope_in_place_batched": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, Batch,
                                                           c_vp]),
+    "quest_estimate_attn_score_batched": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, PagedKV, c_vp, Batch, c_vp]),
+    "quest_topk_filtering_batched": (ctypes.c_int, [c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, Batch,
+                                                     c_vp]),
+    "quest_decode_forward_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_vp, Batch, c_vp, c_vp]),
     "quest_decode_set_batch": (ctypes.c_int, [c_vp, c_u32]),
     "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
     "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),

@@ -73,6 +73,7 @@ struct DecodeParams {
     uint32_t sel_stride;  // row stride of sel_val_out / sel_idx_out (the plan's n_sel; the live n_sel may be smaller)
     uint32_t xcd_period;  // > 1: grid row y serves query head (y % period) * (Hq / period) + y / period (see sparse_decode_kernel)
     uint32_t fe2_prefilter;  // second-generation front end: histogram only the keys above a per-wave lower bound (topk_bitmap.cuh)
+    const int32_t* budgets;  // optional per-sequence page budgets (pages incl. the current one) of a batched launch
 };
 
 // leading scalar kernel arguments (preloaded into SGPRs at wave launch) and their hand-over to the struct; a_pack =
@@ -253,6 +254,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                                // does not cover (shared_entry's fallback); the list is the page table itself
         const quest_step_state_t st = *sv.state;
         p.n_scores = (uint32_t)(st.n_pages - 1);
+        if (p.budgets) p.n_sel = min(p.n_sel, (uint32_t)max(p.budgets[seq] - 1, 0));
         p.n_sel = min(p.n_sel, p.n_scores);
         p.last_page_len = (uint32_t)st.kv_last_page_len;
         p.last_page_idx = st.kv_last_page_idx;
@@ -325,6 +327,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             p.n_scores = (uint32_t)(live.y - 1);
             p.last_page_len = (uint32_t)live.z;
             p.last_page_idx = live.w;
+            if (p.budgets) p.n_sel = min(p.n_sel, (uint32_t)max(p.budgets[seq] - 1, 0));
             p.n_sel = min(p.n_sel, p.n_scores);
         }
         plan_slots();

@@ -157,6 +157,20 @@ static int append_estimate_state(const void* k, const void* v, quest_paged_kv_t 
     return estimate_entry(q, o, num_qo_heads, max_n_out, metadata, tail, (hipStream_t)stream, batch.n_seqs);
 }
 
+extern "C" int quest_estimate_attn_score_batched(const void* q, void* o, uint32_t num_qo_heads, uint32_t o_stride,
+                                                 uint32_t max_n_out, quest_paged_kv_t metadata,
+                                                 const quest_step_state_t* state, quest_batch_t batch, quest_stream_t stream) {
+    if (!state || max_n_out == 0 || o_stride < max_n_out || batch.n_seqs == 0) return QUEST_EINVAL;
+    if (batch.n_seqs > 1 && (uint64_t)batch.meta_table_stride * metadata.page_size < max_n_out) return QUEST_EINVAL;
+    metadata.last_page_len = 1;  // placeholder; the kernel reads the live length from `state`
+    if (int e = check_pool(metadata)) return e;
+    AppendTail tail{};
+    tail.state = state;
+    tail.o_stride = o_stride;
+    tail.meta_table_stride = batch.meta_table_stride;
+    return estimate_entry(q, o, num_qo_heads, max_n_out, metadata, tail, (hipStream_t)stream, batch.n_seqs);
+}
+
 extern "C" int quest_append_estimate_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
                                          uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
                                          quest_paged_kv_t metadata, const quest_step_state_t* state,

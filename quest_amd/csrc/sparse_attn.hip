@@ -546,6 +546,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     if (fused && !p.vec_front && n_scores > 4096u) return QUEST_EUNSUPPORTED;
     p.state = state;
     p.table_stride = batch.kv_table_stride;
+    p.budgets = state ? batch.page_budgets : nullptr;
     {   // XCD-aware row order for GQA (see sparse_decode_kernel); QUEST_XCD_GROUP=0 keeps the plain order (tuning)
         static const bool xcd_group = [] { const char* e = getenv("QUEST_XCD_GROUP"); return !e || atoi(e) != 0; }();
         uint32_t gcd = 8, c = h->n_chunks % 8u;
@@ -712,6 +713,18 @@ extern "C" int quest_decode_forward_fused_topk_batched(quest_decode_handler_t* h
     if (batch.n_seqs > 1 && batch.kv_table_stride < max_n_scores + 1) return QUEST_EINVAL;
     return decode_entry(h, q, o, kv, num_qo_heads, scores, max_n_scores, nullptr, nullptr, lse, (hipStream_t)stream,
                         score_stride, state, batch);
+}
+
+extern "C" int quest_decode_forward_batched(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
+                                            uint32_t num_qo_heads, const int32_t* indices, uint32_t idx_stride,
+                                            const quest_step_state_t* state, quest_batch_t batch, float* lse,
+                                            quest_stream_t stream) {
+    if (!h || !state || !indices) return QUEST_EINVAL;
+    if (idx_stride < h->n_sel) return QUEST_EINVAL;  // rows must hold the plan's selected-page count
+    kv.indices = indices;        // [n_seqs][num_qo_heads][idx_stride]
+    kv.page_budget = idx_stride;  // row stride of a head's list
+    batch.kv_table_stride = num_qo_heads * idx_stride;  // entries between the sequences' index blocks
+    return decode_entry(h, q, o, kv, num_qo_heads, nullptr, 0, nullptr, nullptr, lse, (hipStream_t)stream, 0, state, batch);
 }
 
 extern "C" int quest_decode_forward_shared_batched(quest_decode_handler_t* h, const void* q, void* o,

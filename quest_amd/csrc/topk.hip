@@ -26,21 +26,16 @@ constexpr int kTkThreads = 1024;
 // 8191 columns that alone cost ~6 us of address-unit time.)
 constexpr uint32_t kTkStageIdsMax = 8192;  // page ids are staged in LDS up to this row length (32 KiB)
 
+// One row: v / ii = the row's n scores and page ids, ov / oi = its k outputs.  All threads of the workgroup call it.
 template <int C>
-__global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __restrict__ vals,
-                                                          const int32_t* __restrict__ in_idx,
-                                                          uint16_t* __restrict__ out_val,
-                                                          int32_t* __restrict__ out_idx, uint32_t n, uint32_t k) {
-    __shared__ TopkSmem<kTkThreads> sm;
-    extern __shared__ __attribute__((aligned(16))) unsigned char tk_dyn[];
+__device__ __forceinline__ void topk_row(TopkSmem<kTkThreads>& sm, unsigned char* tk_dyn, const uint16_t* __restrict__ v,
+                                         const int32_t* __restrict__ ii, uint16_t* __restrict__ ov,
+                                         int32_t* __restrict__ oi, uint32_t n, uint32_t k, bool stage_ids) {
+    // stage_ids: the page ids fit the dynamic LDS next to the keys (decided by the host from the row CAPACITY)
     uint16_t* keys_s = reinterpret_cast<uint16_t*>(tk_dyn);
-    const bool stage_ids = n <= kTkStageIdsMax;
     int32_t* ids_s = reinterpret_cast<int32_t*>(tk_dyn + (((size_t)n * 2 + 15) & ~(size_t)15));
 
     const uint32_t tid = threadIdx.x;
-    const size_t row = blockIdx.x;
-    const uint16_t* v = vals + row * n;
-    const int32_t* ii = in_idx + row * n;
     const uint32_t cpt = topk_cols_per_thread<kTkThreads>(n);
     const uint32_t c0 = tid * cpt;
 
@@ -83,12 +78,46 @@ __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __rest
         }
     }
     __syncthreads();
-    uint16_t* ov = out_val + row * k;
-    int32_t* oi = out_idx + row * k;
     for (uint32_t t = tid; t < k; t += kTkThreads) {
         ov[t] = selv_s[t];
         oi[t] = seli_s[t];
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __restrict__ vals,
+                                                          const int32_t* __restrict__ in_idx,
+                                                          uint16_t* __restrict__ out_val,
+                                                          int32_t* __restrict__ out_idx, uint32_t n, uint32_t k) {
+    __shared__ TopkSmem<kTkThreads> sm;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tk_dyn[];
+    const size_t row = blockIdx.x;
+    topk_row<C>(sm, tk_dyn, vals + row * n, in_idx + row * n, out_val + row * k, out_idx + row * k, n, k, n <= kTkStageIdsMax);
+}
+
+// Batched, state-driven form (EXTENSION; replaces the per-request Python loop around topk_filtering of a batch of
+// `constexpr batch_size = 1` calls, quest/utils/controller.py:80-129 + utils/__init__.py:207-237): grid (head, sequence);
+// the row length is the sequence's live page count minus the current page, read from its device-resident state; the
+// page ids are the sequence's own page table (one row for all heads); k = min(budget of the sequence - 1, row length),
+// the budget from `budgets` (pages INCLUDING the current one) or the launch-wide `k_plan`.  Outputs are rows of
+// `out_stride` entries of which the first k are written.
+template <int C>
+__global__ __launch_bounds__(kTkThreads) void topk_batched_kernel(const uint16_t* __restrict__ vals, uint32_t val_stride,
+                                                                  const int32_t* __restrict__ tables, uint32_t table_stride,
+                                                                  uint16_t* __restrict__ out_val, int32_t* __restrict__ out_idx,
+                                                                  uint32_t out_stride, const quest_step_state_t* __restrict__ state,
+                                                                  const int32_t* __restrict__ budgets, uint32_t k_plan,
+                                                                  uint32_t stage_ids) {
+    __shared__ TopkSmem<kTkThreads> sm;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tk_dyn[];
+    const uint32_t head = blockIdx.x, seq = blockIdx.y, heads = gridDim.x;
+    const uint32_t n = (uint32_t)(state[seq].n_pages - 1);
+    uint32_t k = budgets ? (uint32_t)max(budgets[seq] - 1, 0) : k_plan;
+    k = min(min(k, n), out_stride);
+    if (n == 0 || k == 0) return;  // block-uniform: a one-page sequence has nothing to select from
+    const size_t row = (size_t)seq * heads + head;
+    topk_row<C>(sm, tk_dyn, vals + row * val_stride, tables + (size_t)seq * table_stride, out_val + row * out_stride,
+                out_idx + row * out_stride, n, k, stage_ids != 0);
 }
 
 }  // namespace quest
@@ -121,6 +150,33 @@ extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* 
     else if (num_pages <= 8 * kTkThreads) QUEST_TOPK_LAUNCH(8);
     else QUEST_TOPK_LAUNCH(16);
 #undef QUEST_TOPK_LAUNCH
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int quest_topk_filtering_batched(const void* scores, uint32_t score_stride, uint32_t max_num_pages,
+                                            const int32_t* kv_tables, void* d_out, int32_t* indices_out, uint32_t out_stride,
+                                            uint32_t num_heads, uint32_t page_budget, const quest_step_state_t* state,
+                                            quest_batch_t batch, quest_stream_t stream) {
+    if (!scores || !kv_tables || !state || !d_out || !indices_out) return QUEST_EINVAL;
+    if (num_heads == 0 || batch.n_seqs == 0 || batch.n_seqs > 65535u || max_num_pages == 0 || out_stride == 0) return QUEST_EINVAL;
+    if (score_stride < max_num_pages || (batch.n_seqs > 1 && batch.kv_table_stride < max_num_pages)) return QUEST_EINVAL;
+    if (max_num_pages > QUEST_TOPK_MAX_ROW) return QUEST_ETOOLARGE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t k_plan = page_budget > 0 ? page_budget - 1 : 0;  // pages besides the current one
+    const size_t tk_lds = (((size_t)max_num_pages * 2 + 15) & ~(size_t)15) +
+                          (max_num_pages <= kTkStageIdsMax ? (size_t)max_num_pages * 4 : 0) + (size_t)out_stride * 4;
+    const dim3 grid(num_heads, batch.n_seqs);
+#define QUEST_TOPK_LAUNCH_B(CC)                                                                                           \
+    hipLaunchKernelGGL((topk_batched_kernel<CC>), grid, dim3(kTkThreads), tk_lds, s, (const uint16_t*)scores, score_stride, \
+                       kv_tables, batch.kv_table_stride, (uint16_t*)d_out, indices_out, out_stride, state, batch.page_budgets, k_plan, \
+                       max_num_pages <= kTkStageIdsMax ? 1u : 0u)
+    if (max_num_pages <= 1 * kTkThreads) QUEST_TOPK_LAUNCH_B(1);
+    else if (max_num_pages <= 2 * kTkThreads) QUEST_TOPK_LAUNCH_B(2);
+    else if (max_num_pages <= 4 * kTkThreads) QUEST_TOPK_LAUNCH_B(4);
+    else if (max_num_pages <= 8 * kTkThreads) QUEST_TOPK_LAUNCH_B(8);
+    else QUEST_TOPK_LAUNCH_B(16);
+#undef QUEST_TOPK_LAUNCH_B
     QUEST_LAUNCH_CHECK();
     return 0;
 }

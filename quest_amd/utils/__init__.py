@@ -41,6 +41,11 @@ __all__ = [
     "step_advance_batched",
     "decode_layer_batched",
     "decode_layer_dense_batched",
+    # the four operators one by one for a whole batch (eager), per-sequence page budgets
+    "append_kv_batched",
+    "decode_estimate_batched",
+    "decode_topk_batched",
+    "decode_sparse_attn_batched",
 ]
 
 
@@ -258,7 +263,51 @@ def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bCon
     _kernels.append_estimate_batched(k, v, b.kv_layer(layer_idx), b.kv_tables, q, scores, b.metadata_layer(layer_idx),
                                      b.meta_tables, b.step_states, max_n, b.layout)
     o = torch.empty_like(q) if out is None else out
-    b._decode_handler.forward_fused_topk_batched(q, o, b.kv_layer(layer_idx), b.kv_tables, scores, b.step_states, max_n)
+    b._decode_handler.forward_fused_topk_batched(q, o, b.kv_layer(layer_idx), b.kv_tables, scores, b.step_states, max_n,
+                                                 b.page_budgets)
+    return o
+
+
+# ---- the reference's four operators of a decode step, one by one, for a whole batch (eager: no captured graph needed;
+# lengths come from the device state uploaded by ``BatchedInferenceController.begin_forward``).  Per sequence the
+# results are the single-sequence operators' bits (tests/test_gpu_batched.py).
+
+def append_kv_batched(k: torch.Tensor, v: torch.Tensor, bController: BatchedInferenceController, layer_idx: int) -> None:
+    """``append_kv`` of one decode token per sequence: k, v ``[n_seqs, Hkv, D]``."""
+    b = bController
+    _need_state(b)
+    _kernels.append_kv_cache_decode_batched(k, v, b.kv_layer(layer_idx), b.kv_tables, b.metadata_layer(layer_idx),
+                                            b.meta_tables, b.step_states, b.layout)
+
+
+def decode_estimate_batched(q: torch.Tensor, bController: BatchedInferenceController, layer_idx: int,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``decode_estimate`` for every sequence: returns ``[n_seqs, Hq, stride]`` page scores (row i valid up to its
+    page count - 1)."""
+    b = bController
+    _need_state(b)
+    o = score_scratch(b) if out is None else out
+    _kernels.estimate_attn_score_batched(q, o, b.metadata_layer(layer_idx), b.meta_tables, b.step_states, b.max_pages - 1,
+                                         b.layout)
+    return o
+
+
+def decode_topk_batched(estimated_attn_score: torch.Tensor, bController: BatchedInferenceController) -> None:
+    """``decode_topk`` for every sequence into ``topk_dout_buffer`` / ``topk_dindices_buffer`` ``[n_seqs, Hq, k_max]``:
+    row (i, h) holds ``min(budget_i - 1, pages_i - 1)`` (score, physical page) pairs in ascending column order."""
+    b = bController
+    _need_state(b)
+    _kernels.topk_filtering_batched(estimated_attn_score, b.kv_tables, b.topk_dout_buffer, b.topk_dindices_buffer,
+                                    b.step_states, b.max_pages - 1, b.inference_page_budget, b.page_budgets)
+
+
+def decode_sparse_attn_batched(q: torch.Tensor, bController: BatchedInferenceController, layer_idx: int,
+                               topk_indices: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``decode_sparse_attn`` for every sequence over ``topk_indices`` ``[n_seqs, Hq, k_max]`` + the current pages."""
+    b = bController
+    _need_state(b)
+    o = torch.empty_like(q) if out is None else out
+    b._decode_handler.forward_batched(q, o, b.kv_layer(layer_idx), topk_indices, b.step_states, b.page_budgets)
     return o
 
 

@@ -237,6 +237,49 @@ class BatchedInferenceController:
         self._dense_handler = None
         self.kv_tables = self.meta_tables = self.step_states = None
         self.state_epoch = 0
+        self.page_budgets = None      # optional int32 [n_seqs] device tensor (set_page_budgets)
+        self._host_budgets = None
+        self.topk_dout_buffer = self.topk_dindices_buffer = None
+        self._planned = None
+
+    # ---- per-sequence page budgets + eager (host-planned) batched steps.  The reference keeps one controller and one
+    # page budget per request and loops over requests in Python (controller.py:39-41, :80-129: five list -> tensor
+    # copies per token per request); here a step of the whole batch is ONE small host -> device copy of the sequences'
+    # lengths, and every operator runs once for all sequences (quest_amd.utils.*_batched).
+    def set_page_budgets(self, budgets) -> None:
+        """Pages each sequence attends per step INCLUDING its current page (None: the constructor's budget for all).
+        A sequence with fewer pages than its budget attends all of them."""
+        if budgets is None:
+            self.page_budgets = self._host_budgets = None
+            return
+        budgets = [int(x) for x in budgets]
+        if len(budgets) != self.n_seqs or min(budgets) < 1:
+            raise ValueError("one page budget >= 1 per sequence")
+        self._host_budgets = budgets
+        self.page_budgets = torch.tensor(budgets, dtype=torch.int32, device=self.device)
+
+    def max_page_budget(self) -> int:
+        return max(self._host_budgets) if self._host_budgets is not None else self._page_budget
+
+    def begin_forward(self) -> None:
+        """Plan one eager decode step of the batch after ``prepare_metadata(1)``: upload the sequences' lengths
+        (``[n_seqs, 8]`` int32, one copy) and (re)plan the decode handler for the largest budget."""
+        if self.step_states is None:
+            raise RuntimeError("call enable_device_state() after the prefill")
+        self.sync_device_state()
+        budget = min(self.max_page_budget(), self.max_pages)
+        if self._planned != budget:
+            self._decode_handler.set_batch(self.n_seqs)
+            self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
+                                               self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
+            self._planned = budget
+            k = max(budget - 1, 1)
+            self.topk_dout_buffer = torch.zeros(self.n_seqs, self.num_heads, k, dtype=self.dtype, device=self.device)
+            self.topk_dindices_buffer = torch.zeros(self.n_seqs, self.num_heads, k, dtype=torch.int32, device=self.device)
+        self.inference_page_budget = budget
+
+    def end_forward(self) -> None:
+        pass  # nothing to release: tables, states and the handler's workspace persist across steps
 
     def kv_layer(self, layer_idx: int) -> torch.Tensor:
         return self.kv_pool.layer(layer_idx)
@@ -270,8 +313,9 @@ class BatchedInferenceController:
         the sparse regime), and optionally the batched full-KV decode over the per-sequence capacity."""
         # sequences shorter than the budget attend all of their pages (see InferenceController.begin_graph_decode)
         assert all(len(c.kv_cache.indicies) >= 1 for c in self.seqs), "prefill every sequence first"
-        budget = min(self._page_budget, self.max_pages)
+        budget = min(self.max_page_budget(), self.max_pages)
         self.inference_page_budget = budget
+        self._planned = budget
         self._decode_handler.set_batch(self.n_seqs)
         self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
                                            self.num_kv_heads, self.head_dim, self.page_size, self.dtype)

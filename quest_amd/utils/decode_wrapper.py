@@ -52,8 +52,12 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def set_batch(self, n_seqs: int) -> None:
         self._wrapper.set_batch(n_seqs)
 
-    def forward_fused_topk_batched(self, q, o, paged_kv_data, kv_tables, scores, state, max_n_scores: int) -> None:
-        self._wrapper.forward_fused_topk_batched(q, o, paged_kv_data, kv_tables, scores, state, max_n_scores)
+    def forward_fused_topk_batched(self, q, o, paged_kv_data, kv_tables, scores, state, max_n_scores: int,
+                                   budgets=None) -> None:
+        self._wrapper.forward_fused_topk_batched(q, o, paged_kv_data, kv_tables, scores, state, max_n_scores, budgets)
+
+    def forward_batched(self, q, o, paged_kv_data, indices, state, budgets=None) -> None:
+        self._wrapper.forward_batched(q, o, paged_kv_data, indices, state, budgets)
 
     def forward_shared_batched(self, q, o, paged_kv_data, kv_tables, state) -> None:
         self._wrapper.forward_shared_batched(q, o, paged_kv_data, kv_tables, state)

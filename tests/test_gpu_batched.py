@@ -290,3 +290,102 @@ def test_model_batched_generation_matches_single_sequence():
                 torch.testing.assert_close(out[i], logits[i][t + 1][0], rtol=3e-2, atol=3e-2)
     for i, c in enumerate(mb.model.bController.seqs):
         assert c.kv_cache.seqlen == lens[i] + n_new
+
+
+@pytest.mark.parametrize("Hq,Hkv,layout,D,lens,budgets", [
+    # ragged lengths, a budget per sequence: far below the page count, above it (-> all pages), exactly it, one page
+    (8, 8, 0, 128, (16 * 40 + 3, 16 * 9 + 16, 16 * 25 + 1, 5), (7, 30, 26, 4)),
+    (8, 2, 1, 128, (16 * 33 + 9, 16 * 12 + 2, 16 * 20 + 16), (12, 5, 21)),
+    (4, 4, 0, 64, (16 * 18 + 7, 16 * 50 + 16), (9, 3)),
+])
+def test_batched_eager_ops_with_per_sequence_budgets_match_single_sequence_ops(Hq, Hkv, layout, D, lens, budgets):
+    """The four operators of a decode step one by one for a whole batch, WITHOUT a captured graph and with a page budget
+    per sequence (replaces the reference's per-request loop, quest/utils/controller.py:80-129 + utils/__init__.py:141-276):
+    append_kv_batched / decode_estimate_batched / decode_topk_batched / decode_sparse_attn_batched must give, per sequence,
+    the bits of the single-sequence reference-signature operators run on that sequence alone with ITS budget; the fused
+    batched layer with budgets must select the same pages."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    layers, steps, n = 2, 20, len(lens)
+    cap = max(lens) + steps + 40
+    ks = [cuda(inputs(300 + i, L, Hq, Hkv, D)[1]) for i, L in enumerate(lens)]
+    vs = [cuda(inputs(300 + i, L, Hq, Hkv, D)[2]) for i, L in enumerate(lens)]
+    g = torch.Generator(device=dev).manual_seed(12)
+    new_q = torch.randn(steps, layers, n, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, layers, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, layers, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    singles = []
+    for i, L in enumerate(lens):
+        c = qu.InferenceController(layers, Hq, D, PAGE, budgets[i], cap, torch.float16, dev, num_kv_heads=Hkv, layout=layout,
+                                   shuffle_seed=70 + i)
+        _prefill(c, ks[i], vs[i], layers)
+        c._decode_handler.set_pages_per_chunk(2)
+        singles.append(c)
+    b = qu.BatchedInferenceController(n, layers, Hq, D, PAGE, max(budgets), cap, torch.float16, dev, num_kv_heads=Hkv,
+                                      layout=layout, shuffle_seed=5)
+    for i in range(n):
+        _prefill(b.seqs[i], ks[i], vs[i], layers)
+    b.set_page_budgets(budgets)
+    b.enable_device_state()
+    b._decode_handler.set_pages_per_chunk(2)
+
+    for t in range(steps):
+        # ---- single-sequence reference flow (host-planned, reference op signatures), one request after the other
+        ref_o, ref_sel = [], []
+        for i, c in enumerate(singles):
+            c.prepare_metadata(1)
+            c.begin_forward(1)
+            oo, ss = [], []
+            for l in range(layers):
+                q, k, v = new_q[t, l, i:i + 1], new_k[t, l, i:i + 1], new_v[t, l, i:i + 1]
+                qu.append_kv(k, v, c, l)
+                if c.need_estimate():
+                    est = qu.decode_estimate(q, c, l)
+                    qu.decode_topk(est, c)
+                    oo.append(qu.decode_sparse_attn(q, c, l, c.topk_dindices_buffer))
+                    ss.append(c.topk_dindices_buffer.clone())
+                else:  # within its budget: every page (QuestAttention.py:123-132)
+                    oo.append(qu.decode_sparse_attn(q, c, l, c.kv_indices_without_last))
+                    ss.append(None)
+            c.end_forward()
+            ref_o.append(torch.cat(oo))   # [layers, Hq, D]
+            ref_sel.append(ss)
+        # ---- the batch: one host -> device copy of the lengths, then one launch per operator for all sequences
+        b.prepare_metadata(1)
+        b.begin_forward()
+        for l in range(layers):
+            q, k, v = new_q[t, l], new_k[t, l], new_v[t, l]
+            qu.append_kv_batched(k, v, b, l)
+            est = qu.decode_estimate_batched(q, b, l)
+            qu.decode_topk_batched(est, b)
+            o = qu.decode_sparse_attn_batched(q, b, l, b.topk_dindices_buffer)
+            sel_i = torch.full((n, Hq, b.inference_page_budget - 1), -1, dtype=torch.int32, device=dev)
+            b._decode_handler.set_selection_out(None, sel_i)
+            o_fused = qu.decode_layer_batched(q, k, v, b, l, qu.score_scratch(b).zero_())  # (the append is idempotent)
+            b._decode_handler.set_selection_out(None, None)
+            for i, c in enumerate(singles):
+                pages = len(c.kv_cache.indicies)
+                k_i = min(budgets[i] - 1, pages - 1)
+                if ref_sel[i][l] is not None:
+                    assert k_i == budgets[i] - 1
+                    assert torch.equal(_logical_pages(b.seqs[i], b.topk_dindices_buffer[i, :, :k_i]),
+                                       _logical_pages(c, ref_sel[i][l])), f"token {t} seq {i} layer {l}: selected pages"
+                    assert torch.equal(_logical_pages(b.seqs[i], sel_i[i, :, :k_i]), _logical_pages(c, ref_sel[i][l]))
+                else:  # all pages, in table order
+                    want = torch.arange(pages - 1).expand(Hq, -1)
+                    assert torch.equal(_logical_pages(b.seqs[i], b.topk_dindices_buffer[i, :, :k_i]), want)
+                assert torch.equal(o[i], ref_o[i][l]) or ref_sel[i][l] is None, f"token {t} seq {i} layer {l}: output bits"
+                torch.testing.assert_close(o[i].float(), ref_o[i][l].float(), rtol=2e-3, atol=2e-3)
+                torch.testing.assert_close(o_fused[i].float(), ref_o[i][l].float(), rtol=2e-3, atol=2e-3)
+        b.end_forward()
+    for i, (c, s) in enumerate(zip(b.seqs, singles)):
+        assert c.kv_cache.seqlen == s.kv_cache.seqlen == lens[i] + steps
+
+
+def _logical_pages(ctl, phys):
+    """Physical page ids [H, k] -> logical page numbers of the controller's sequence (CPU int64)."""
+    table = ctl.kv_cache.indicies
+    inv = {p: j for j, p in enumerate(table)}
+    return torch.tensor([[inv[int(x)] for x in row] for row in phys.cpu().tolist()], dtype=torch.int64).reshape(phys.shape[0], -1)
