@@ -103,6 +103,10 @@ int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo_heads, uin
 int quest_append_estimate(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
                           uint32_t num_qo_heads, uint32_t n_out, quest_paged_kv_t metadata,
                           quest_stream_t stream);
+/* The same with a row stride for `o` (elements between the rows of consecutive query heads; 0 = n_out). */
+int quest_append_estimate_strided(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                  uint32_t num_qo_heads, uint32_t n_out, uint32_t o_stride, quest_paged_kv_t metadata,
+                                  quest_stream_t stream);
 
 /*
  * topk_filtering (bsk_ops.h:38-43, topk.cu:7-46 -> decode_select_k, decode_select_k.cuh:25-62,
@@ -161,6 +165,15 @@ int quest_decode_forward_shared(quest_decode_handler_t* h, const void* q, void* 
 int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
                                     uint32_t num_qo_heads, const void* scores, uint32_t n_scores,
                                     void* topk_val_out, int32_t* topk_idx_out, float* lse, quest_stream_t stream);
+/* The same with a row stride for `scores` (elements; 0 = n_scores).  The reference's score tensor is a contiguous
+ * [num_qo_heads][pages - 1] (quest/utils/__init__.py:171-205), whose rows are only 2-byte aligned; rows padded to a
+ * multiple of 8 columns (16 bytes: quest_append_estimate_strided writes them) let the front end fetch a thread's
+ * scores with one vector load and are REQUIRED beyond 4096 pages (QUEST_EUNSUPPORTED otherwise: callers then issue
+ * quest_topk_filtering + quest_decode_forward). */
+int quest_decode_forward_fused_topk_strided(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                            uint32_t num_qo_heads, const void* scores, uint32_t n_scores,
+                                            uint32_t score_stride, void* topk_val_out, int32_t* topk_idx_out, float* lse,
+                                            quest_stream_t stream);
 
 /*
  * Device-resident step state (host planning rewrite).  The reference rebuilds page-table

@@ -41,6 +41,18 @@ def _check_input(x: torch.Tensor, name: str) -> None:
         raise RuntimeError(f"{name} must be contiguous")
 
 
+def _check_rows(x: torch.Tensor, name: str) -> None:
+    """A 2-D CUDA tensor whose rows are contiguous (a padded score buffer's ``[:, :n]`` view qualifies)."""
+    if not _CHECKS_ON:
+        return
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < x.size(1):
+        raise RuntimeError(f"{name} must be 2-D with contiguous rows")
+
+
 def _check_dim(d: int, x: torch.Tensor, name: str) -> None:
     if _CHECKS_ON and x.dim() != d:
         raise RuntimeError(f"{name} must be a {d}D tensor")
@@ -217,9 +229,8 @@ def append_estimate(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_len: int,
     _check_append(k, v, kv_data, kv_indices, kv_indptr, metadata_data, metadata_indices, metadata_indptr, layout)
     _check_eq(k.size(0), 1, "k.size(0), 1")
     _check_input(q, "q")
-    _check_input(o, "o")
+    _check_rows(o, "o")  # [Hq, n_out], rows possibly padded (a view of a wider buffer)
     _check_dim(3, q, "q")
-    _check_dim(2, o, "o")
     _check_eq(q.size(0), 1, "q.size(0), 1")
     _check_eq(o.size(0), q.size(1), "o.size(0), num_heads")
     _check_half(k, "Append_kv_cache_decode")
@@ -227,8 +238,8 @@ def append_estimate(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_len: int,
     kv = _paged(kv_data, kv_indices, kv_indptr, kv_last_page_len, kv_last_page_idx, layout)
     meta = _paged(metadata_data, metadata_indices, metadata_indptr, metadata_last_page_len, metadata_last_page_idx,
                   layout)
-    check(lib.quest_append_estimate(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1), o.size(1),
-                                    meta, _stream(k)), "append_estimate")
+    check(lib.quest_append_estimate_strided(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1),
+                                            o.size(1), o.stride(0), meta, _stream(k)), "append_estimate")
 
 
 # ---- state-driven (graph-replayable) forms: EXTENSIONS, see include/quest_hip.h quest_step_state_t
@@ -539,10 +550,9 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         _check_input(o, "o")
         _check_input(paged_kv_data, "paged_kv_data")
         _check_input(page_table, "page_table")
-        _check_input(scores, "scores")
+        _check_rows(scores, "scores")  # [Hq, n_scores], rows possibly padded (decode_append_estimate's output)
         _check_dim(3, q, "q")
         _check_dim(1, page_table, "page_table")
-        _check_dim(2, scores, "scores")
         _check_dim(5, paged_kv_data, "paged_kv_data")
         _check_eq(scores.size(0), q.size(1), "scores.size(0), num_qo_heads")
         _check_eq(page_table.size(0), scores.size(1) + 1, "page_table.size(0), n_scores + 1")
@@ -550,8 +560,8 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         _check_half(q, "BatchDecodeWithPagedKVCache")
         _check_half(scores, "BatchDecodeWithPagedKVCache")
         kv = _paged(paged_kv_data, page_table, None, paged_kv_last_page_len, paged_kv_last_page_idx, self._layout)
-        code = lib.quest_decode_forward_fused_topk(
-            self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), scores.data_ptr(), scores.size(1),
+        code = lib.quest_decode_forward_fused_topk_strided(
+            self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), scores.data_ptr(), scores.size(1), scores.stride(0),
             topk_val_out.data_ptr() if topk_val_out is not None else None,
             topk_idx_out.data_ptr() if topk_idx_out is not None else None, None, _stream(q))
         if code == -2:  # QUEST_EUNSUPPORTED: chunk larger than the fused front end stages

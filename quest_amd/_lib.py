@@ -47,6 +47,7 @@ SIGNATURES = {
     "quest_append_kv_cache_prefill": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, PagedKV, c_vp]),
     "quest_estimate_attn_score": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp]),
     "quest_append_estimate": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp]),
+    "quest_append_estimate_strided": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, c_u32, PagedKV, c_vp]),
     "quest_topk_filtering": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
     "quest_decode_handler_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_u32]),
     "quest_decode_handler_destroy": (None, [c_vp]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "quest_decode_forward_shared": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp]),
     "quest_decode_forward_fused_topk": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_vp, c_vp,
                                                         c_vp, c_vp]),
+    "quest_decode_forward_fused_topk_strided": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32, c_vp,
+                                                                c_vp, c_vp, c_vp]),
     "quest_step_state_advance": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
     "quest_append_estimate_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, c_u32, PagedKV, c_vp,
                                                   c_vp]),

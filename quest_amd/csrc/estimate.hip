@@ -71,7 +71,7 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     constexpr int R = kWave / (D / kVec);
     constexpr uint32_t ROWS = kEstWaves * est_iter<G>() * R;
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
-    if (!tail.state) tail.o_stride = n_out;
+    if (!tail.state && tail.o_stride == 0) tail.o_stride = n_out;  // contiguous rows unless the caller pads them
     const uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec), ew = ROWS / hw;
     tail.tile_heads = hw;
     tail.tile_log2 = (uint32_t)__builtin_ctz(hw);
@@ -188,10 +188,10 @@ extern "C" int quest_append_estimate_batched(const void* k, const void* v, quest
     return append_estimate_state(k, v, kv, q, o, num_qo_heads, o_stride, max_n_out, metadata, state, batch, stream);
 }
 
-extern "C" int quest_append_estimate(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
-                                     uint32_t num_qo_heads, uint32_t n_out, quest_paged_kv_t metadata,
-                                     quest_stream_t stream) {
-    if (!k || !v) return QUEST_EINVAL;
+extern "C" int quest_append_estimate_strided(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                             uint32_t num_qo_heads, uint32_t n_out, uint32_t o_stride,
+                                             quest_paged_kv_t metadata, quest_stream_t stream) {
+    if (!k || !v || (o_stride != 0 && o_stride < n_out)) return QUEST_EINVAL;
     if (int e = check_pool(kv)) return e;
     if (int e = check_pool(metadata)) return e;
     if (kv.num_heads != metadata.num_heads || kv.head_dim != metadata.head_dim) return QUEST_EINVAL;
@@ -200,5 +200,12 @@ extern "C" int quest_append_estimate(const void* k, const void* v, quest_paged_k
     tail.key = (const uint16_t*)k;
     tail.value = (const uint16_t*)v;
     tail.enabled = 1;
+    tail.o_stride = o_stride;
     return estimate_entry(q, o, num_qo_heads, n_out, metadata, tail, (hipStream_t)stream);
+}
+
+extern "C" int quest_append_estimate(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                     uint32_t num_qo_heads, uint32_t n_out, quest_paged_kv_t metadata,
+                                     quest_stream_t stream) {
+    return quest_append_estimate_strided(k, v, kv, q, o, num_qo_heads, n_out, 0, metadata, stream);
 }

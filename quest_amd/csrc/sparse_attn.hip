@@ -467,11 +467,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         if (!kv.indices || h->n_sel == 0 || h->n_sel > n_scores) return QUEST_EINVAL;
         if (n_scores > QUEST_TOPK_MAX_ROW) return QUEST_ETOOLARGE;
         if (h->pages_per_chunk > (uint32_t)kFusedMaxPpc) return QUEST_EUNSUPPORTED;
-        // beyond 4096 pages the per-workgroup selection (>= 32 keys per thread, repeated by every
-        // workgroup of the head) costs more than the stand-alone top-k launch it replaces (measured at
-        // 8191 pages: 33.7 vs 28.2 us) -> tell the caller to take the two-launch path.  State-driven
-        // launches pass a capacity, not a length (the work follows the live length), so they are exempt.
-        if (!state && n_scores > 8u * 8u * kWave) return QUEST_EUNSUPPORTED;
+        // (rows beyond 4096 columns need the second-generation front end, i.e. aligned score rows: checked below)
     } else if (h->n_sel > 0 && (!kv.indices || (!state && kv.page_budget < h->n_sel))) {
         return QUEST_EINVAL;  // (state-driven: one shared list, row stride kv.page_budget == 0)
     }
@@ -685,13 +681,21 @@ extern "C" int quest_decode_forward_shared_dyn(quest_decode_handler_t* h, const 
     return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream);
 }
 
+extern "C" int quest_decode_forward_fused_topk_strided(quest_decode_handler_t* h, const void* q, void* o,
+                                                       quest_paged_kv_t kv, uint32_t num_qo_heads, const void* scores,
+                                                       uint32_t n_scores, uint32_t score_stride, void* topk_val_out,
+                                                       int32_t* topk_idx_out, float* lse, quest_stream_t stream) {
+    if (!scores || (score_stride != 0 && score_stride < n_scores)) return QUEST_EINVAL;
+    return decode_entry(h, q, o, kv, num_qo_heads, scores, n_scores, topk_val_out, topk_idx_out, lse,
+                        (hipStream_t)stream, score_stride);
+}
+
 extern "C" int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
                                                uint32_t num_qo_heads, const void* scores, uint32_t n_scores,
                                                void* topk_val_out, int32_t* topk_idx_out, float* lse,
                                                quest_stream_t stream) {
-    if (!scores) return QUEST_EINVAL;
-    return decode_entry(h, q, o, kv, num_qo_heads, scores, n_scores, topk_val_out, topk_idx_out, lse,
-                        (hipStream_t)stream);
+    return quest_decode_forward_fused_topk_strided(h, q, o, kv, num_qo_heads, scores, n_scores, 0, topk_val_out,
+                                                   topk_idx_out, lse, stream);
 }
 
 extern "C" int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q, void* o,

@@ -102,6 +102,8 @@ def decode_estimate(q: torch.Tensor, iController: InferenceController, layer_idx
 
 def decode_topk(estimated_attn_score: torch.Tensor, iController: InferenceController) -> None:
     """Pick the ``budget - 1`` best pages per head into ``iController.topk_dindices_buffer``."""
+    if not estimated_attn_score.is_contiguous():  # decode_append_estimate's padded rows
+        estimated_attn_score = estimated_attn_score.contiguous()
     _kernels.topk_filtering(estimated_attn_score, iController.kv_indices_without_last, iController.topk_dout_buffer,
                             iController.topk_dindices_buffer, iController.topk_buf,
                             iController.inference_page_budget - 1)
@@ -135,9 +137,13 @@ def decode_sparse_attn(q: torch.Tensor, iController: InferenceController, layer_
 
 def decode_append_estimate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
                            layer_idx: int) -> torch.Tensor:
-    """``append_kv(k, v)`` + ``decode_estimate(q)`` in one launch; returns the scores ``[Hq, n_pages-1]``."""
+    """``append_kv(k, v)`` + ``decode_estimate(q)`` in one launch; returns the scores ``[Hq, n_pages-1]`` -- a VIEW of a
+    buffer whose rows are padded to a multiple of 8 columns (16 bytes), which is what lets ``decode_topk_sparse_attn`` run
+    its vector-load front ends and serve rows beyond 4096 pages in one launch (the reference's contiguous layout,
+    utils/__init__.py:171-205, has 2-byte aligned rows).  ``.contiguous()`` gives the reference layout back."""
     meta = iController.metadata_cache
-    o = torch.empty((iController.num_heads, meta.seqlen - 1), dtype=q.dtype, device=q.device)
+    n_out = meta.seqlen - 1
+    o = torch.empty((iController.num_heads, (n_out + 7) // 8 * 8), dtype=q.dtype, device=q.device)[:, :n_out]
     a = _append_args(iController, layer_idx)
     _kernels.append_estimate(k, v, a[0], a[1], a[2], a[3], a[4], q, o, a[5], a[6], a[7], a[8], a[9], a[10])
     return o

@@ -75,9 +75,11 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     ctl.prepare_metadata(1)
     ctl.begin_forward(1)
     assert ctl.need_estimate() and ctl.inference_page_budget == B
-    # ---- eager route: fused append+estimate, then (fused front end refused at 8191 columns) top-k + attention
+    # ---- eager route through the drop-in API: fused append+estimate into 16-byte aligned score rows, then top-k +
+    # attention in ONE launch (the second-generation front end serves the 8191-column rows; the reference's contiguous
+    # [Hq, 8191] layout -- odd row stride -- takes two launches, checked below)
     est = qu.decode_append_estimate(q, k[-1:], v[-1:], ctl, 0)
-    assert est.shape == (Hq, n_pages - 1)
+    assert est.shape == (Hq, n_pages - 1) and est.stride(0) % 8 == 0
     kp = k.view(n_pages, PAGE, Hkv, D)
     meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]  # [n_meta, 2, S, Hkv, D]
     assert torch.equal(meta[:, 0].reshape(-1, Hkv, D)[:n_pages], kp.amax(1))
@@ -90,6 +92,18 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     o = qu.decode_topk_sparse_attn(q, est, ctl, 0, write_topk=True)
     assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei), "selected pages differ from the oracle"
     assert np.array_equal(U16(ctl.topk_dout_buffer.cpu().numpy()), U16(ev))
+    o_chk = torch.empty_like(q)
+    assert ctl._decode_handler.forward_fused_topk(q, o_chk, ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last, est, None, None,
+                                                  ctl.kv_cache.last_page_len, ctl.kv_last_page_idx), "fused launch refused"
+    assert torch.equal(o_chk, o)
+    est_ref_layout = est.contiguous()  # the reference's layout: rows of 8191 fp16, 2-byte aligned
+    assert not ctl._decode_handler.forward_fused_topk(q, o_chk, ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last,
+                                                      est_ref_layout, None, None, ctl.kv_cache.last_page_len,
+                                                      ctl.kv_last_page_idx)
+    ctl.topk_dindices_buffer.fill_(-1)
+    o_two = qu.decode_topk_sparse_attn(q, est_ref_layout, ctl, 0)  # stand-alone top-k + index-list attention
+    assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
+    torch.testing.assert_close(o_two.float(), o.float(), rtol=2e-3, atol=2e-3)
     ctl.end_forward()
     o_ref = _torch_attention(q[0], k, v, _logical(kv_table, ei), L)
     torch.testing.assert_close(o[0].float(), o_ref, rtol=5e-3, atol=5e-3)
