@@ -341,6 +341,29 @@ int quest_apply_rope_in_place(void* q, void* k, uint32_t n, uint32_t past_kv_len
 int quest_rms_norm_forward(const void* input, const void* weight, void* output, uint32_t rows,
                            uint32_t cols, float epsilon, quest_stream_t stream);
 
+/*
+ * Decode-token projections of a Llama decoder layer around the attention path, fused (EXTENSION; csrc/decode_layer.hip).
+ * The reference leaves them to cuBLAS + PyTorch kernels: RMSNorm (quest/ops/csrc/rms_norm.cu:82-213 via
+ * quest/models/llama.py:72), q/k/v projections + RoPE (QuestAttention.py:64-70, decode_page.cuh:644-728), o_proj (:118),
+ * residual adds and the SwiGLU MLP (llama.py LlamaMLP).  All vectors / matrices fp16, row-major weights [out][in]
+ * (torch.nn.Linear.weight), fp32 accumulation, batch 1.
+ *   quest_decode_norm_gemv     out[out_dim] = W . rmsnorm(x; gamma, eps)      (gamma NULL: out = W . x)
+ *   quest_decode_gemv_residual h[out_dim]  += W . x                           (in place on the residual stream)
+ *   quest_decode_mlp_gate_up   act[intermediate] = silu(Wg . n) * (Wu . n),   n = rmsnorm(h; gamma, eps)
+ *   quest_decode_qkv_rope      q, k, v = Wq . n, Wk . n, Wv . n with rotate-half RoPE on q and k at position
+ *                              state->seq_len - 1 (call after quest_step_state_advance), n = rmsnorm(h; gamma, eps)
+ */
+int quest_decode_norm_gemv(const void* x, const void* gamma, float eps, const void* w, void* out, uint32_t in_dim,
+                           uint32_t out_dim, quest_stream_t stream);
+int quest_decode_gemv_residual(const void* x, const void* w, void* h, uint32_t in_dim, uint32_t out_dim,
+                               quest_stream_t stream);
+int quest_decode_mlp_gate_up(const void* h, const void* gamma, float eps, const void* w_gate, const void* w_up, void* act,
+                             uint32_t hidden, uint32_t intermediate, quest_stream_t stream);
+int quest_decode_qkv_rope(const void* h, const void* gamma, float eps, const void* wq, const void* wk, const void* wv,
+                          void* q, void* k, void* v, uint32_t hidden, uint32_t num_qo_heads, uint32_t num_kv_heads,
+                          uint32_t head_dim, float rope_scale, float rope_theta, const quest_step_state_t* state,
+                          quest_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,6 +242,76 @@ def append_estimate(k, v, kv_data, kv_indices, kv_indptr, kv_last_page_len: int,
                                             o.size(1), o.stride(0), meta, _stream(k)), "append_estimate")
 
 
+# ---- decode-token projections of a decoder layer, fused (EXTENSION: csrc/decode_layer.hip)
+
+def _check_vec(x, n: int, name: str) -> None:
+    _check_input(x, name)
+    _check_eq(x.numel(), n, f"{name}.numel(), {n}")
+    _check_half(x, name)
+
+
+def _check_weight(w, out_dim: int, in_dim: int, name: str) -> None:
+    _check_input(w, name)
+    _check_dim(2, w, name)
+    _check_eq(tuple(w.shape), (out_dim, in_dim), f"{name}.shape, (out, in)")
+    _check_half(w, name)
+
+
+def decode_norm_gemv(x, gamma, eps: float, w, out) -> None:
+    """``out = w @ rmsnorm(x; gamma, eps)`` (``gamma`` None: ``out = w @ x``); x ``[in]``, w ``[out, in]``, out ``[out]``."""
+    out_dim, in_dim = w.shape
+    _check_vec(x, in_dim, "x")
+    _check_vec(out, out_dim, "out")
+    _check_weight(w, out_dim, in_dim, "w")
+    if gamma is not None:
+        _check_vec(gamma, in_dim, "gamma")
+    check(lib.quest_decode_norm_gemv(x.data_ptr(), gamma.data_ptr() if gamma is not None else None, float(eps),
+                                     w.data_ptr(), out.data_ptr(), in_dim, out_dim, _stream(x)), "decode_norm_gemv")
+
+
+def decode_gemv_residual(x, w, h) -> None:
+    """``h += w @ x`` in place; x ``[in]``, w ``[out, in]``, h ``[out]``."""
+    out_dim, in_dim = w.shape
+    _check_vec(x, in_dim, "x")
+    _check_vec(h, out_dim, "h")
+    _check_weight(w, out_dim, in_dim, "w")
+    check(lib.quest_decode_gemv_residual(x.data_ptr(), w.data_ptr(), h.data_ptr(), in_dim, out_dim, _stream(x)),
+          "decode_gemv_residual")
+
+
+def decode_mlp_gate_up(h, gamma, eps: float, w_gate, w_up, act) -> None:
+    """``act = silu(w_gate @ n) * (w_up @ n)`` with ``n = rmsnorm(h; gamma, eps)``."""
+    inter, hidden = w_gate.shape
+    _check_vec(h, hidden, "h")
+    _check_vec(gamma, hidden, "gamma")
+    _check_vec(act, inter, "act")
+    _check_weight(w_gate, inter, hidden, "w_gate")
+    _check_weight(w_up, inter, hidden, "w_up")
+    check(lib.quest_decode_mlp_gate_up(h.data_ptr(), gamma.data_ptr(), float(eps), w_gate.data_ptr(), w_up.data_ptr(),
+                                       act.data_ptr(), hidden, inter, _stream(h)), "decode_mlp_gate_up")
+
+
+def decode_qkv_rope(h, gamma, eps: float, wq, wk, wv, q, k, v, head_dim: int, rope_scale: float, rope_theta: float,
+                    state) -> None:
+    """q ``[1, Hq, D]``, k / v ``[1, Hkv, D]`` = projections of ``rmsnorm(h; gamma, eps)`` with RoPE on q and k at the
+    position ``state.seq_len - 1`` (the device-resident step state, after ``step_state_advance``)."""
+    hidden = wq.size(1)
+    _check_vec(h, hidden, "h")
+    _check_vec(gamma, hidden, "gamma")
+    _check_weight(wq, wq.size(0), hidden, "wq")
+    _check_weight(wk, wk.size(0), hidden, "wk")
+    _check_weight(wv, wk.size(0), hidden, "wv")
+    _check_vec(q, wq.size(0), "q")
+    _check_vec(k, wk.size(0), "k")
+    _check_vec(v, wk.size(0), "v")
+    _check_input(state, "state")
+    _check_eq(wq.size(0) % head_dim, 0, "wq.size(0) % head_dim, 0")
+    check(lib.quest_decode_qkv_rope(h.data_ptr(), gamma.data_ptr(), float(eps), wq.data_ptr(), wk.data_ptr(),
+                                    wv.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), hidden,
+                                    wq.size(0) // head_dim, wk.size(0) // head_dim, int(head_dim), float(rope_scale),
+                                    float(rope_theta), state.data_ptr(), _stream(h)), "decode_qkv_rope")
+
+
 # ---- state-driven (graph-replayable) forms: EXTENSIONS, see include/quest_hip.h quest_step_state_t
 
 STEP_STATE_INTS = 8  # int32 fields of quest_step_state_t

@@ -87,6 +87,11 @@ SIGNATURES = {
     "quest_decode_set_selection_out": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "quest_decode_set_front_end": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "quest_apply_rope_in_place": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp]),
+    "quest_decode_norm_gemv": (ctypes.c_int, [c_vp, c_vp, c_f32, c_vp, c_vp, c_u32, c_u32, c_vp]),
+    "quest_decode_gemv_residual": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp]),
+    "quest_decode_mlp_gate_up": (ctypes.c_int, [c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp]),
+    "quest_decode_qkv_rope": (ctypes.c_int, [c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32,
+                                              c_u32, c_f32, c_f32, c_vp, c_vp]),
     "quest_rms_norm_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp]),
 }
 

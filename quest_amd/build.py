@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libquest_hip.so")
-SOURCES = ["append.hip", "estimate.hip", "topk.hip", "sparse_attn.hip", "rope_norm.hip"]
+SOURCES = ["append.hip", "estimate.hip", "topk.hip", "sparse_attn.hip", "rope_norm.hip", "decode_layer.hip"]
 HEADERS = ["quest_common.cuh", "topk_select.cuh", "topk_bitmap.cuh", "append_device.cuh", "estimate_device.cuh", "decode_device.cuh", os.path.join("..", "..", "include", "quest_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function",

@@ -115,6 +115,38 @@ class LlamaDecoderLayer(nn.Module):
         hidden_states = hidden_states + h
         return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
 
+    def forward_dyn_fused(self, h: torch.Tensor, iController, scores, dense: bool, ws: "DecodeWorkspace") -> torch.Tensor:
+        """``forward_dyn`` in 4 launches besides the attention's: RMSNorm + q/k/v projections + RoPE, o_proj + residual,
+        RMSNorm + gate/up + SiLU*up, down_proj + residual (csrc/decode_layer.hip; EXTENSION).  ``h`` ``[hidden]`` is the
+        residual stream, updated IN PLACE; batch 1, fp16."""
+        from .. import _kernels
+
+        a, m = self.self_attn, self.mlp
+        _kernels.decode_qkv_rope(h, self.input_layernorm.weight, self.input_layernorm.variance_epsilon, a.q_proj.weight,
+                                 a.k_proj.weight, a.v_proj.weight, ws.q, ws.k, ws.v, a.head_dim, a.rope_scale,
+                                 a.rope_theta, iController.step_state)
+        if dense:
+            attn = qutils.decode_layer_dense_dyn(ws.q, ws.k, ws.v, iController, a.layer_idx)
+        else:
+            attn = qutils.decode_layer_dyn(ws.q, ws.k, ws.v, iController, a.layer_idx, scores)
+        _kernels.decode_gemv_residual(attn, a.o_proj.weight, h)
+        _kernels.decode_mlp_gate_up(h, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon,
+                                    m.gate_proj.weight, m.up_proj.weight, ws.act)
+        _kernels.decode_gemv_residual(ws.act, m.down_proj.weight, h)
+        return h
+
+
+class DecodeWorkspace:
+    """Scratch of the fused decode layer (one set for the whole model: layers run one after the other)."""
+
+    def __init__(self, config: LlamaConfig, dtype, device):
+        d = config.hidden_size // config.num_attention_heads
+        self.q = torch.empty(1, config.num_attention_heads, d, dtype=dtype, device=device)
+        self.k = torch.empty(1, config.num_key_value_heads, d, dtype=dtype, device=device)
+        self.v = torch.empty(1, config.num_key_value_heads, d, dtype=dtype, device=device)
+        self.act = torch.empty(config.intermediate_size, dtype=dtype, device=device)
+        self.h = torch.empty(config.hidden_size, dtype=dtype, device=device)
+
 
 class LlamaModel(nn.Module):
     def __init__(self, config: LlamaConfig, fused: bool = True):
@@ -155,6 +187,16 @@ class LlamaModel(nn.Module):
             h = layer.forward_dyn(h, ctl, scores, dense=idx < self._quest_skip_layer)
         return self.norm(h)
 
+
+    def forward_decode_dyn_fused(self, h: torch.Tensor, scores: torch.Tensor, ws: DecodeWorkspace) -> torch.Tensor:
+        """``forward_decode_dyn`` with the fused decode layer; returns the residual stream ``[hidden]`` BEFORE the final
+        norm (the caller fuses that into its lm_head launch)."""
+        ctl = self.iController
+        qutils.step_advance_dyn(ctl)
+        ws.h.copy_(h.reshape(-1))
+        for idx, layer in enumerate(self.layers):
+            layer.forward_dyn_fused(ws.h, ctl, scores, idx < self._quest_skip_layer, ws)
+        return ws.h
 
     def forward_decode_batched(self, h: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
         """One decode token of every sequence of ``self.bController`` (``h``: ``[n, 1, hidden]``)."""
@@ -284,8 +326,11 @@ class LlamaForCausalLM(nn.Module):
         return self.lm_head(h[:, -1:, :])  # decode only needs the last position
 
     # ------------------------------------------------------------------ one hipGraph per generated token
-    def capture_decode_graph(self) -> None:
-        """Capture ONE decode step (all layers + lm_head) and keep it for ``decode_graph_step``.  Call after
+    def capture_decode_graph(self, fused_layers: Optional[bool] = None) -> None:
+        """Capture ONE decode step (all layers + lm_head) and keep it for ``decode_graph_step``.  ``fused_layers``
+        (default: on for fp16 models unless ``QUEST_FUSED_LAYER=0``): the decoder layers' projections, norms, RoPE,
+        activation and residual adds run as 4 fused HIP launches per layer (csrc/decode_layer.hip) instead of ~14
+        rocBLAS / PyTorch launches.  Call after
         the prompt has been processed (any length: while the cache holds fewer pages than the budget the
         sparse layers attend all of them, like the reference's full-attention branch).  The
         graph reads its input from ``self.graph_input`` ``[1, 1, hidden]`` and leaves the logits in
@@ -297,9 +342,25 @@ class LlamaForCausalLM(nn.Module):
         ctl.begin_graph_decode(dense_layers=m._quest_skip_layer > 0)
         self.graph_input = torch.zeros(1, 1, self.config.hidden_size, dtype=self.lm_head.weight.dtype, device=dev)
         self._graph_scores = qutils.score_scratch(ctl)
+        if fused_layers is None:
+            import os
 
-        def step():
-            return self.lm_head(m.forward_decode_dyn(self.graph_input, self._graph_scores))
+            fused_layers = os.environ.get("QUEST_FUSED_LAYER", "1") != "0"
+        fused_layers = fused_layers and self.lm_head.weight.dtype == torch.float16
+        self.fused_layers = fused_layers
+        if fused_layers:
+            from .. import _kernels
+
+            ws = DecodeWorkspace(self.config, torch.float16, dev)
+            logits = torch.empty(1, 1, self.config.vocab_size, dtype=torch.float16, device=dev)
+
+            def step():
+                hs = m.forward_decode_dyn_fused(self.graph_input, self._graph_scores, ws)
+                _kernels.decode_norm_gemv(hs, m.norm.weight, m.norm.variance_epsilon, self.lm_head.weight, logits)
+                return logits
+        else:
+            def step():
+                return self.lm_head(m.forward_decode_dyn(self.graph_input, self._graph_scores))
 
         # Warm-up (allocator, rocBLAS workspaces) runs a real step on a dummy input: it advances the device
         # state and folds the dummy key into the current page's (max, min) metadata entry.  K/V bytes it wrote

@@ -209,6 +209,7 @@ def main():
            "speedup": results["dense"] / results["quest"],
            "reference_published": "RTX 6000 Ada, ctx 32768 FP16: 36.8 ms -> 21.2 ms @ budget 2048 (1.74x)"}
     if gen_ms:
+        out["generation_fused_decoder_layers"] = os.environ.get("QUEST_FUSED_LAYER", "1") != "0"
         out["generated_tokens"] = a.generate
         out["ms_per_generated_token_quest"] = gen_ms["quest"]
         out["ms_per_generated_token_full_kv"] = gen_ms["dense"]
