@@ -351,7 +351,8 @@ class LlamaForCausalLM(nn.Module):
         if fused_layers:
             from .. import _kernels
 
-            ws = DecodeWorkspace(self.config, torch.float16, dev)
+            # (kept on self: the captured launches hold these buffers' addresses)
+            ws = self._graph_ws = DecodeWorkspace(self.config, torch.float16, dev)
             logits = torch.empty(1, 1, self.config.vocab_size, dtype=torch.float16, device=dev)
 
             def step():
