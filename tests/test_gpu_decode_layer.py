@@ -84,10 +84,13 @@ def test_qkv_rope_vs_fp32(Hq, Hkv, D, pos, scale, theta):
     torch.testing.assert_close(v.float().view(-1), wv.float() @ n, **tol)
 
 
-@pytest.mark.parametrize("kv_heads,inter", [(4, 1376), (2, 1024)])
-def test_fused_decode_graph_matches_the_unfused_module_path(kv_heads, inter):
+@pytest.mark.parametrize("kv_heads,inter,budget_pages", [(4, 1376, 64), (2, 1024, 64), (4, 1376, 6)])
+def test_fused_decode_graph_matches_the_unfused_module_path(kv_heads, inter, budget_pages):
     """One hipGraph replay per token with the fused decoder layers vs the same with nn.Linear / rms_norm_forward /
-    apply_rope_in_place / PyTorch activation and adds: logits over 24 generated positions, dense and sparse layers."""
+    apply_rope_in_place / PyTorch activation and adds: logits over 24 generated positions.  With a budget that covers the
+    cache every layer attends all pages and the two paths differ by fp16 rounding only; with 6 of 21 pages the sparse
+    layers' page selection is a discrete function of q, so a rounding-level difference can swap a page at a few
+    positions -- there the bulk of the positions must agree and none may be far off."""
     from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
     import quest_amd.utils as qu
 
@@ -113,7 +116,7 @@ def test_fused_decode_graph_matches_the_unfused_module_path(kv_heads, inter):
         with torch.device(dev):
             model = LlamaForCausalLM(cfg).half()
         model.load_state_dict(ref_model.state_dict())
-        model.quest_init(16, ctx + steps + 64, token_budget=16 * 6)
+        model.quest_init(16, ctx + steps + 64, token_budget=16 * budget_pages)
         ctl = model.model.iController
         ctl.prepare_metadata(ctx)
         ctl.begin_forward(ctx)
@@ -131,5 +134,8 @@ def test_fused_decode_graph_matches_the_unfused_module_path(kv_heads, inter):
         assert ctl.kv_cache.seqlen == ctx + steps
     assert torch.isfinite(logits[True]).all()
     scale = float(logits[False].abs().max())
-    err = float((logits[True] - logits[False]).abs().max())
-    assert err < 2e-2 * scale + 2e-2, (err, scale)
+    err = (logits[True] - logits[False]).abs().flatten(1).max(1).values  # per generated position
+    if budget_pages >= 64:
+        assert float(err.max()) < 1e-2 * scale, (err.tolist(), scale)
+    else:
+        assert float(err.median()) < 1e-2 * scale and float(err.max()) < 0.2 * scale, (err.tolist(), scale)
