@@ -68,7 +68,9 @@ def test_hf_checkpoint_logits_match_transformers(tmp_path, kv_heads, rope):
         tok = ref32.logits[0, -1].argmax()
     assert m.model.iController.kv_cache.seqlen == 150 + n_new
 
-    # the same checkpoint on the Quest sparse path (budget 4 pages of 16 tokens): eager == graph replay, finite
+    # the same checkpoint on the Quest sparse path (budget 4 pages of 16 tokens): eager == graph replay of the same
+    # module-by-module step (bit for bit), finite.  (The fused decoder layers of the default graph differ from the
+    # module path by fp16 rounding: tests/test_gpu_decode_layer.py.)
     outs = []
     for graph in (False, True):
         q = LlamaForCausalLM.from_pretrained(d, device=dev)
@@ -76,7 +78,7 @@ def test_hf_checkpoint_logits_match_transformers(tmp_path, kv_heads, rope):
         with torch.inference_mode():
             lg = q(input_ids=prompt.to(dev))
             if graph:
-                q.capture_decode_graph()
+                q.capture_decode_graph(fused_layers=False)
             seq = []
             for t in range(12):
                 tk = lg[0, -1].argmax().view(1, 1)
