@@ -232,10 +232,13 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
 // selection instead of waiting for one another.
 //
 // (chunk, hq, seq) are the workgroup's coordinates.
-template <int D, int S_T, int FC, int NW>
+// VF >= 0: the front-end variant (DecodeParams.vec_front) is a compile-time constant and the other variants' code is
+// not part of the kernel (the generic fused kernel carries all four: 27 KiB of code against 11 for one).
+template <int D, int S_T, int FC, int NW, int VF = -1>
 __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_t chunk, const uint32_t hq, const uint32_t seq,
                                                    const uint32_t num_qo_heads) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
+    const uint32_t vec_front = VF >= 0 ? (uint32_t)VF : p.vec_front;
     // wave index as an SGPR so per-wave control flow below is scalar branching
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
@@ -290,7 +293,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         const int4 live = *(p.state ? reinterpret_cast<const int4*>(sv.state)
                                     : reinterpret_cast<const int4*>(p.q));  // seq_len, n_pages, kv_last_page_len, kv_last_page_idx
         uint4 own_keys = make_uint4(0u, 0u, 0u, 0u), own_ids[2] = {own_keys, own_keys};  // vec_front == 3
-        const bool own_cols = FC == 8 && p.vec_front == 3;
+        const bool own_cols = FC == 8 && vec_front == 3;
         // the thread's own contiguous columns (vec_front 3): their page ids (1-2 x 16 bytes) and 16 bytes of scores per
         // lane (8 at 4 columns per thread) -- a coalesced sweep of the row -- all of it kept in registers
         const uint32_t own_c0 = threadIdx.x * p.cpt, own_cc = own_c0 < n_cap ? own_c0 : 0u;
@@ -319,7 +322,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 own_keys.x = k2.x, own_keys.y = k2.y;
             }
             fe2_clear<NT>(sm);
-        } else if (p.vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
+        } else if (vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
             fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
             fe2_clear<NT>(sm);
         }
@@ -332,7 +335,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         }
         plan_slots();
         const uint32_t n = p.n_scores;
-        if (n > 0 && p.vec_front == 2) {
+        if (n > 0 && vec_front == 2) {
             QUEST_STAMP(1);
             const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
             const bool ids_staged = p.stage_ids && fe2_has_ids(FC);
@@ -372,7 +375,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                     if ((uint32_t)i < cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
                 }
                 QUEST_STAMP(1);
-            } else if (p.vec_front == 1) {
+            } else if (vec_front == 1) {
                 // aligned score rows: the granule loads issued at the top of the kernel (fe2_issue) feed the staging arrays
                 if constexpr (fe2_has_ids(FC)) mm = fe1_stage_vector<NT, FC / 4>(raw, keys_s, stage_ids ? ids_s : nullptr, n_cap, n);
                 QUEST_STAMP(1);
@@ -497,7 +500,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 k[t] = ld8_kv(b0 + lane_off + t * step);
                 v[t] = ld8_kv(b0 + lane_off + t * step + p.st.v_off);
             }
-            if (has1) {  // wave-uniform
+            if (has1) {  // wave-uniform (a likely-taken hint here cost 3.5 us per batched launch: measured, r3j)
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     k[T + t] = ld8_kv(b1 + lane_off + t * step);

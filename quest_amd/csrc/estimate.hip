@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimat
         q += (size_t)seq * meta.num_heads * G * D;
         meta.indices += (size_t)seq * tail.meta_table_stride;
     }
-    if (blockIdx.x >= tail.est_blocks) {
+    if (QUEST_UNLIKELY(blockIdx.x >= tail.est_blocks)) {  // the few append blocks at the end of the grid
         tail.key += (size_t)seq * meta.num_heads * D;
         tail.value += (size_t)seq * meta.num_heads * D;
         if (tail.state) {

@@ -110,11 +110,16 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
         // and serialises the round trips.  Clamped rows re-read the last entry (tail tiles only).
         ecl[j] = e < n_cap ? e : n_cap - 1;
     }
-    if ((S & (EW - 1)) == 0) {
+    // live length of a state-driven launch: requested together with the page-table entry (one scalar round trip for
+    // both; from the table's first word when there is no state -- a load under a branch would be waited for on its own)
+    const int32_t live_pages = ld_uniform_i32(tail.state ? &tail.state->n_pages : idx);
+    if (QUEST_LIKELY((S & (EW - 1)) == 0)) {
         // the tile's EW consecutive entries (and the clamped ones of a tail tile) lie in ONE metadata page: a
         // single wave-uniform (scalar) table load instead of a vector load per row at the head of the
         // table -> metadata dependency chain
-        const size_t pg = (size_t)idx[e0 / S];
+        int32_t pg_raw = ld_uniform_i32(idx + e0 / S), live_dep = live_pages;
+        asm volatile("" : "+s"(pg_raw), "+s"(live_dep));  // both requested before either is waited for (no sinking)
+        const size_t pg = (size_t)pg_raw;
 #pragma unroll
         for (int j = 0; j < kEstIter; ++j) page[j] = pg;
     } else {
@@ -122,7 +127,7 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
         for (int j = 0; j < kEstIter; ++j) page[j] = (size_t)idx[ecl[j] / S];
     }
     if (tail.state) {  // live length (<= n_cap); whole tiles past it have nothing to do
-        n_out = (uint32_t)(tail.state->n_pages - 1);
+        n_out = (uint32_t)(live_pages - 1);  // (same register as live_dep above: already there)
         if (TPB == 1 && e0 >= n_out) return;
     }
     half8 mx[kEstIter], mn[kEstIter];
@@ -164,7 +169,7 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
     literal = __builtin_amdgcn_readfirstlane(literal);
 
     // (3) scores
-    if (!literal) {
+    if (QUEST_LIKELY(!literal)) {
 #pragma unroll
         for (int j = 0; j < kEstIter; ++j) {
             const half8 hi = __builtin_elementwise_max(mx[j], mn[j]), lo = __builtin_elementwise_min(mx[j], mn[j]);

@@ -41,6 +41,13 @@ __host__ __device__ inline PoolStrides pool_strides(const quest_paged_kv_t& p) {
 }
 
 __device__ __forceinline__ half8 ld8(const half_t* p) { return *reinterpret_cast<const half8*>(p); }
+// Load of a WAVE-UNIFORM address from memory that nobody writes during the kernel (page tables, the step state): through
+// the constant address space, i.e. an s_load (scalar cache) into an SGPR -- the compiler otherwise emits a 64-lane
+// vector load of one address, with the vector path's latency, at the head of the table -> data dependency chain.
+__device__ __forceinline__ int32_t ld_uniform_i32(const int32_t* p) {
+    typedef const int32_t __attribute__((address_space(4))) * cptr;
+    return *(cptr)(uintptr_t)p;
+}
 // Streaming (read-once) 16 B load: `nt` cache policy, for K/V pages and metadata that no other
 // workgroup re-reads (MI355X guide, nt-weights row: issued->landed -18 % on once-read streams).
 __device__ __forceinline__ half8 ld8_stream(const half_t* p) {
@@ -223,6 +230,19 @@ __device__ __forceinline__ uint32_t half_key(uint16_t b) {
 }
 
 }  // namespace quest
+
+// Branch-weight hints for rarely taken paths (the append role of the estimate grid, the literal-form estimate).  They
+// are kept OUT of the attention kernel: marking its second-slot branch as likely cost 3.5 us per batched launch and 1.2
+// at cfg 4 (gpurun_out/r3j_*), and hints on its cold front-end fallbacks bought nothing.  What does pay there is code
+// SIZE: the 12 KiB instantiation that holds only the front-end variant in use is 0.57 us per launch faster than the
+// generic 27 KiB kernel (sparse_decode_kernel's VF parameter).  -DQUEST_NO_LAYOUT_HINTS turns the hints off (A/B).
+#ifdef QUEST_NO_LAYOUT_HINTS
+#define QUEST_UNLIKELY(x) (x)
+#define QUEST_LIKELY(x) (x)
+#else
+#define QUEST_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define QUEST_LIKELY(x) __builtin_expect(!!(x), 1)
+#endif
 
 #define QUEST_LAUNCH_CHECK()                  \
     do {                                      \

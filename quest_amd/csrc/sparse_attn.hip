@@ -31,12 +31,12 @@ namespace quest {
 // heads of a kv-head group select overlapping page sets (measured: 21 % of their pages are shared, scripts/gqa_overlap.py),
 // so their workgroups should sit on the SAME XCD, at the same time: the host picks `xcd_period` such that grid rows
 // y, y + period, y + 2 period, ... (same XCD for every chunk index) serve a run of consecutive query heads.
-template <int D, int S_T, int FC, int NW>
+template <int D, int S_T, int FC, int NW, int VF = -1>
 __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
     QUEST_DECODE_HEAD_TAKE(p);
     uint32_t hq = blockIdx.y;
     if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (a_num_qo_heads / p.xcd_period) + hq / p.xcd_period;
-    sparse_decode_body<D, S_T, FC, NW>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+    sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,6 +422,16 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
                             hipStream_t s, uint32_t n_seqs) {
     dim3 grid(h->n_chunks, num_qo_heads, n_seqs);
     const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0) : 0;  // the table has n_scores + 1 entries, staged in granules of 4
+    // the register-ownership front end (vec_front 3: single-sequence rows of <= 4096 pages, the headline shape) as its own
+    // compact instantiation; QUEST_FE_SPECIALIZE=0 launches the generic kernel instead (A/B)
+    static const bool specialize = [] { const char* e = getenv("QUEST_FE_SPECIALIZE"); return !e || atoi(e) != 0; }();
+    if constexpr (FC == 8) {
+        if (specialize && p.page_size == 16 && waves == 8 && p.vec_front == 3) {
+            hipLaunchKernelGGL((sparse_decode_kernel<D, 16, 8, 8, 3>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
+            QUEST_LAUNCH_CHECK();
+            goto merge;
+        }
+    }
     if (p.page_size == 16 && waves == 8)
         hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
     else if (p.page_size == 16)
@@ -429,6 +439,7 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     else
         hipLaunchKernelGGL((sparse_decode_kernel<D, 0, FC, 4>), grid, dim3(4 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
     QUEST_LAUNCH_CHECK();
+merge:
     if (h->n_chunks > 1 && !h->skip_merge) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride);
