@@ -422,14 +422,27 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
                             hipStream_t s, uint32_t n_seqs) {
     dim3 grid(h->n_chunks, num_qo_heads, n_seqs);
     const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0) : 0;  // the table has n_scores + 1 entries, staged in granules of 4
-    // the register-ownership front end (vec_front 3: single-sequence rows of <= 4096 pages, the headline shape) as its own
-    // compact instantiation; QUEST_FE_SPECIALIZE=0 launches the generic kernel instead (A/B)
+    // The common (keys per thread, front-end variant) pairs of 8-wave page-16 launches as their own compact
+    // instantiations -- the generic kernel carries all four front-end variants (27 KiB of code; the one-variant kernels
+    // are 10-14 KiB) and measured 0.57 us per launch slower at the headline shape:
+    //   FC 8,  variant 3: single-sequence rows <= 4096 pages, keys and page ids straight into registers (cfg 3)
+    //   FC 8,  variant 1: the same rows in batched launches, staging arrays fed by vector loads (cfg 3 x 8, cfg 5)
+    //   FC 16 / 32, variant 2: second-generation front end of long rows (cfg 4)
+    // QUEST_FE_SPECIALIZE=0 launches the generic kernel instead (A/B).
     static const bool specialize = [] { const char* e = getenv("QUEST_FE_SPECIALIZE"); return !e || atoi(e) != 0; }();
-    if constexpr (FC == 8) {
-        if (specialize && p.page_size == 16 && waves == 8 && p.vec_front == 3) {
-            hipLaunchKernelGGL((sparse_decode_kernel<D, 16, 8, 8, 3>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
-            QUEST_LAUNCH_CHECK();
-            goto merge;
+    if (specialize && p.page_size == 16 && waves == 8) {
+        constexpr int VFA = FC == 8 ? 3 : 2, VFB = FC == 8 ? 1 : 2;
+        if constexpr (FC == 8 || FC == 16 || FC == 32) {
+            if (p.vec_front == (uint32_t)VFA) {
+                hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFA>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
+                QUEST_LAUNCH_CHECK();
+                goto merge;
+            }
+            if (VFB != VFA && p.vec_front == (uint32_t)VFB) {
+                hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFB>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
+                QUEST_LAUNCH_CHECK();
+                goto merge;
+            }
         }
     }
     if (p.page_size == 16 && waves == 8)
