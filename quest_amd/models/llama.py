@@ -231,8 +231,16 @@ class LlamaForCausalLM(nn.Module):
         with open(os.path.join(path, "config.json")) as f:
             hf = json.load(f)
         cfg = LlamaConfig.from_hf_dict(hf)
-        with torch.device(device):
-            model = cls(cfg, fused=fused).to(dtype)
+        # parameters are created directly in `dtype` on `device` and left uninitialised (every one of them is overwritten
+        # from the checkpoint below, or reported missing): no fp32 copy of the model, no random-init pass
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            with torch.device("meta"):
+                model = cls(cfg, fused=fused)
+            model = model.to_empty(device=device)
+        finally:
+            torch.set_default_dtype(prev)
         index = os.path.join(path, "model.safetensors.index.json")
         if os.path.exists(index):
             with open(index) as f:
@@ -253,6 +261,10 @@ class LlamaForCausalLM(nn.Module):
                         if t.shape != params[name].shape:
                             raise ValueError(f"{name}: checkpoint shape {tuple(t.shape)} != model {tuple(params[name].shape)}")
                         params[name].copy_(t)
+                        if t.dtype != params[name].dtype and t.dtype in (torch.bfloat16, torch.float32) \
+                                and not bool(torch.isfinite(params[name]).all()):
+                            # e.g. a bf16 checkpoint whose values exceed fp16's range (the kernels are fp16 like the reference's)
+                            raise ValueError(f"{name}: {t.dtype} values overflow {params[name].dtype}")
                         seen.add(name)
         missing = set(params) - seen
         if missing == {"lm_head.weight"} and hf.get("tie_word_embeddings", False):
