@@ -22,8 +22,11 @@
 namespace quest {
 
 constexpr int kGvWaves = 4;   // waves per workgroup
-constexpr int kGvRows = 4;    // row-dots per wave
-constexpr int kGvUnroll = 4;  // iterations (x 64 lanes x 16 B x kGvRows rows) in flight
+// Row-dots per wave (RW) and iterations in flight (U; x 64 lanes x 16 B x RW rows) are template parameters: RW = 4 / U = 4
+// for the wide launches (gate/up, lm_head), RW = 2 / U = 8 for q/k/v, RW = 1 / U = 8 for the 4096-row o_proj and
+// down_proj -- the host picks the largest RW that still gives ~1000 workgroups, i.e. 3-4 resident per CU: with 256
+// workgroups of 4 x 4 rows the 4096-row projections ran at 3.9 TB/s (one workgroup per CU, 64 KiB in flight), against
+// 5.8 TB/s for gate/up (profiles/r03_e2e_kernel_stats_before_row_split.csv).
 
 enum GemvMode { kGvPlain = 0, kGvResidual = 1, kGvSiluMul = 2, kGvQkvRope = 3 };
 
@@ -53,8 +56,9 @@ __device__ __forceinline__ float dot8(const half8& a, const half8& b, float acc)
     return acc;
 }
 
-template <int MODE>
+template <int MODE, int kGvRows, int kGvUnroll>
 __global__ __launch_bounds__(kGvWaves* kWave) void gemv_kernel(GemvArgs p) {
+    static_assert(MODE == kGvPlain || MODE == kGvResidual || kGvRows % 2 == 0, "pairs of row-dots stay in one wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
     half_t* x_s = reinterpret_cast<half_t*>(gv_smem);  // in_dim halves, zero-padded to a multiple of 64 * 8 * kGvUnroll
     __shared__ float s_part[kGvWaves];
@@ -196,16 +200,29 @@ __global__ __launch_bounds__(kGvWaves* kWave) void gemv_kernel(GemvArgs p) {
     }
 }
 
-template <int MODE>
-static int launch_gemv(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) {
+template <int MODE, int RW, int U>
+static int launch_gemv_rw(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) {
     const uint32_t n_vec = p.in_dim / kVec, iters = (n_vec + kWave - 1) / kWave;
-    const uint32_t outer = (iters + kGvUnroll - 1) / kGvUnroll;
-    const size_t lds = (size_t)outer * kGvUnroll * kWave * kVec * sizeof(half_t);
+    const uint32_t outer = (iters + U - 1) / U;
+    const size_t lds = (size_t)outer * U * kWave * kVec * sizeof(half_t);
     if (lds > 60 * 1024) return QUEST_EUNSUPPORTED;  // in_dim <= 30720
-    const uint32_t per_wg = kGvWaves * kGvRows;
-    hipLaunchKernelGGL((gemv_kernel<MODE>), dim3((virtual_rows + per_wg - 1) / per_wg), dim3(kGvWaves * kWave), lds, s, p);
+    const uint32_t per_wg = kGvWaves * RW;
+    hipLaunchKernelGGL((gemv_kernel<MODE, RW, U>), dim3((virtual_rows + per_wg - 1) / per_wg), dim3(kGvWaves * kWave), lds, s, p);
     QUEST_LAUNCH_CHECK();
     return 0;
+}
+
+// the largest rows-per-wave that still fills the chip with ~4 workgroups per CU
+template <int MODE>
+static int launch_gemv(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) {
+    constexpr uint32_t kWant = 1000;
+    if (virtual_rows / (kGvWaves * 4) >= kWant) return launch_gemv_rw<MODE, 4, 4>(p, virtual_rows, s);
+    if constexpr (MODE == kGvPlain || MODE == kGvResidual) {
+        if (virtual_rows / (kGvWaves * 2) >= kWant) return launch_gemv_rw<MODE, 2, 8>(p, virtual_rows, s);
+        return launch_gemv_rw<MODE, 1, 8>(p, virtual_rows, s);
+    } else {
+        return launch_gemv_rw<MODE, 2, 8>(p, virtual_rows, s);
+    }
 }
 
 }  // namespace quest
