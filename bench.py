@@ -115,7 +115,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-RENDEZVOUS_TIMEOUT_S = 120  # init_process_group / collectives: a peer that never shows up must not stall the node
+RENDEZVOUS_TIMEOUT_S = 300  # init_process_group / collectives: a peer that never shows up must not stall the node (the
+# other ranks also wait this long at the closing barrier while rank 0 takes its per-operator side measurements: ~10 s)
 
 
 def launch_ranks(n, poll_s=0.1):
