@@ -21,13 +21,11 @@
 
 namespace quest {
 
-constexpr int kGvWaves = 4;   // waves per workgroup
-// Row-dots per wave (RW) and iterations in flight (U; x 64 lanes x 16 B x RW rows) are template parameters: RW = 4 / U = 4
-// for the wide launches (gate/up, lm_head), RW = 2 / U = 8 for q/k/v, RW = 1 / U = 8 for the 4096-row o_proj and
-// down_proj -- the host picks the largest RW that still gives ~1000 workgroups, i.e. 3-4 resident per CU: with 256
-// workgroups of 4 x 4 rows the 4096-row projections ran at 3.9 TB/s (one workgroup per CU, 64 KiB in flight), against
-// 5.8 TB/s for gate/up (profiles/r03_e2e_kernel_stats_before_row_split.csv).
-
+// Workgroup shape: NWV waves, RW row-dots per wave, U iterations (x 64 lanes x 16 B x RW rows) in flight -- template
+// parameters picked by the host (launch_gemv): 8-wave workgroups so that the input vector is staged in LDS once per
+// 8-32 rows (with 4-wave, 4-row workgroups the 22 KiB vector of down_proj was re-staged 1024 times: +26 % of L2 traffic),
+// and the largest RW that still gives >= 2 workgroups per CU.  Round-3 history (profiles/r03_e2e_kernel_stats*.csv):
+// 4 x 4 rows everywhere -> o_proj / down_proj at 3.9 TB/s (256 workgroups: one per CU); 1 row per wave there -> 4.5-4.9.
 enum GemvMode { kGvPlain = 0, kGvResidual = 1, kGvSiluMul = 2, kGvQkvRope = 3 };
 
 struct GemvArgs {
@@ -56,8 +54,8 @@ __device__ __forceinline__ float dot8(const half8& a, const half8& b, float acc)
     return acc;
 }
 
-template <int MODE, int kGvRows, int kGvUnroll>
-__global__ __launch_bounds__(kGvWaves* kWave) void gemv_kernel(GemvArgs p) {
+template <int MODE, int kGvWaves, int kGvRows, int kGvUnroll>
+__global__ __launch_bounds__(kGvWaves* kWave, kGvWaves / 2) void gemv_kernel(GemvArgs p) {  // 2 workgroups per CU
     static_assert(MODE == kGvPlain || MODE == kGvResidual || kGvRows % 2 == 0, "pairs of row-dots stay in one wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
     half_t* x_s = reinterpret_cast<half_t*>(gv_smem);  // in_dim halves, zero-padded to a multiple of 64 * 8 * kGvUnroll
@@ -96,17 +94,41 @@ __global__ __launch_bounds__(kGvWaves* kWave) void gemv_kernel(GemvArgs p) {
         wrow[r] = p.w[live[r] ? m : 0] + (size_t)row[r] * p.in_dim;
     }
 
-    // ---- the first weight loads leave before the input vector is staged (they do not depend on it)
+    // ---- the first weight loads leave before the input vector is staged (they do not depend on it).  Addressing: the
+    // row base is wave-uniform (forced into an SGPR pair, advanced per round), the lane's part one 32-bit offset, the slot
+    // an immediate -- except in the last round of a row whose length is not a multiple of a round, where the vector index
+    // is clamped (kClamp).  A round = kGvUnroll slots x 64 lanes x 16 bytes per row.
+    constexpr uint32_t kRoundHalves = kGvUnroll * kWave * kVec;
+    const uint32_t full = n_vec / (kGvUnroll * kWave);  // rounds whose every slot lies inside the row for every lane
     half8 wv[kGvUnroll][kGvRows];
-    auto issue = [&](uint32_t o) {
+    const uint32_t lane_off = lane * kVec;
+    const half_t* rbase[kGvRows];
 #pragma unroll
-        for (int u = 0; u < kGvUnroll; ++u) {
-            const uint32_t v = lane + (o * kGvUnroll + u) * kWave, vc = v < n_vec ? v : n_vec - 1;  // clamped, unconditional
+    for (int r = 0; r < kGvRows; ++r) {
+        const uintptr_t a = (uintptr_t)wrow[r];
+        rbase[r] = (const half_t*)(((uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                                   (uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)a));
+    }
+    // request round `o` of every row into slot u (kClamp: the round may reach past the row's end)
+    auto issue = [&](uint32_t o, int u, auto clamp_c) {
+        constexpr bool kClamp = decltype(clamp_c)::value;
+        if constexpr (!kClamp) {
+            const uint32_t off = lane_off + (uint32_t)u * (kWave * kVec);
 #pragma unroll
-            for (int r = 0; r < kGvRows; ++r) wv[u][r] = ld8_stream(wrow[r] + (size_t)vc * kVec);
+            for (int r = 0; r < kGvRows; ++r) wv[u][r] = ld8_stream(rbase[r] + (size_t)o * kRoundHalves + off);
+        } else {
+            const uint32_t v = lane + (o * kGvUnroll + (uint32_t)u) * kWave, vc = v < n_vec ? v : n_vec - 1;
+#pragma unroll
+            for (int r = 0; r < kGvRows; ++r) wv[u][r] = ld8_stream(rbase[r] + (size_t)vc * kVec);
         }
     };
-    issue(0);
+    if (full > 0) {  // block-uniform
+#pragma unroll
+        for (int u = 0; u < kGvUnroll; ++u) issue(0, u, std::false_type{});
+    } else {
+#pragma unroll
+        for (int u = 0; u < kGvUnroll; ++u) issue(0, u, std::true_type{});
+    }
 
     // ---- input vector -> LDS (RMSNorm prologue: x * rsqrt(mean(x^2) + eps) * gamma, rounded to fp16 like the
     // stand-alone rms_norm_forward's output)
@@ -143,21 +165,31 @@ __global__ __launch_bounds__(kGvWaves* kWave) void gemv_kernel(GemvArgs p) {
     __syncthreads();
 
     // ---- stream the rows: a slot is re-issued for the next round as soon as it has been consumed (loads complete in
-    // order, so the wait for slot u leaves the younger ones in flight)
+    // order, so the wait for slot u leaves the younger ones in flight).  Three copies of the round body keep the
+    // steady state free of per-slot branches: next round full / next round clamped / last round.
     float acc[kGvRows] = {};
+    auto consume = [&](uint32_t o, int u) {
+        const uint32_t v = lane + (o * kGvUnroll + (uint32_t)u) * kWave;
+        const half8 xv = ld8(x_s + (size_t)v * kVec);  // zero beyond in_dim: clamped weight vectors contribute nothing
+#pragma unroll
+        for (int r = 0; r < kGvRows; ++r) acc[r] = dot8(wv[u][r], xv, acc[r]);
+    };
     for (uint32_t o = 0; o < outer; ++o) {
-        const bool more = o + 1 < outer;  // block-uniform
+        if (o + 1 < full) {
 #pragma unroll
-        for (int u = 0; u < kGvUnroll; ++u) {
-            const uint32_t v = lane + (o * kGvUnroll + u) * kWave;
-            const half8 xv = ld8(x_s + (size_t)v * kVec);  // zero beyond in_dim: clamped weight vectors contribute nothing
-#pragma unroll
-            for (int r = 0; r < kGvRows; ++r) acc[r] = dot8(wv[u][r], xv, acc[r]);
-            if (more) {
-                const uint32_t vn = v + kGvUnroll * kWave, vc = vn < n_vec ? vn : n_vec - 1;
-#pragma unroll
-                for (int r = 0; r < kGvRows; ++r) wv[u][r] = ld8_stream(wrow[r] + (size_t)vc * kVec);
+            for (int u = 0; u < kGvUnroll; ++u) {
+                consume(o, u);
+                issue(o + 1, u, std::false_type{});
             }
+        } else if (o + 1 < outer) {
+#pragma unroll
+            for (int u = 0; u < kGvUnroll; ++u) {
+                consume(o, u);
+                issue(o + 1, u, std::true_type{});
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kGvUnroll; ++u) consume(o, u);
         }
     }
 #pragma unroll
@@ -200,28 +232,30 @@ __global__ __launch_bounds__(kGvWaves* kWave) void gemv_kernel(GemvArgs p) {
     }
 }
 
-template <int MODE, int RW, int U>
+template <int MODE, int NWV, int RW, int U>
 static int launch_gemv_rw(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) {
     const uint32_t n_vec = p.in_dim / kVec, iters = (n_vec + kWave - 1) / kWave;
     const uint32_t outer = (iters + U - 1) / U;
     const size_t lds = (size_t)outer * U * kWave * kVec * sizeof(half_t);
     if (lds > 60 * 1024) return QUEST_EUNSUPPORTED;  // in_dim <= 30720
-    const uint32_t per_wg = kGvWaves * RW;
-    hipLaunchKernelGGL((gemv_kernel<MODE, RW, U>), dim3((virtual_rows + per_wg - 1) / per_wg), dim3(kGvWaves * kWave), lds, s, p);
+    const uint32_t per_wg = NWV * RW;
+    hipLaunchKernelGGL((gemv_kernel<MODE, NWV, RW, U>), dim3((virtual_rows + per_wg - 1) / per_wg), dim3(NWV * kWave), lds, s, p);
     QUEST_LAUNCH_CHECK();
     return 0;
 }
 
-// the largest rows-per-wave that still fills the chip with ~4 workgroups per CU
+// 8-wave workgroups, 8 loads of 16 bytes in flight per lane (RW x U = 8: <= 100 VGPRs, two workgroups = 16 waves = 128 KiB
+// in flight per CU, the attention kernel's shape; 16 per lane needed 146-176 VGPRs and spilled under the 128 cap);
+// the largest rows-per-wave that still gives two workgroups per CU (512)
 template <int MODE>
 static int launch_gemv(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) {
-    constexpr uint32_t kWant = 1000;
-    if (virtual_rows / (kGvWaves * 4) >= kWant) return launch_gemv_rw<MODE, 4, 4>(p, virtual_rows, s);
+    constexpr uint32_t kWant = 512;
+    if (virtual_rows / (8 * 4) >= kWant) return launch_gemv_rw<MODE, 8, 4, 2>(p, virtual_rows, s);
     if constexpr (MODE == kGvPlain || MODE == kGvResidual) {
-        if (virtual_rows / (kGvWaves * 2) >= kWant) return launch_gemv_rw<MODE, 2, 8>(p, virtual_rows, s);
-        return launch_gemv_rw<MODE, 1, 8>(p, virtual_rows, s);
+        if (virtual_rows / (8 * 2) >= kWant) return launch_gemv_rw<MODE, 8, 2, 4>(p, virtual_rows, s);
+        return launch_gemv_rw<MODE, 8, 1, 8>(p, virtual_rows, s);
     } else {
-        return launch_gemv_rw<MODE, 2, 8>(p, virtual_rows, s);
+        return launch_gemv_rw<MODE, 8, 2, 4>(p, virtual_rows, s);
     }
 }
 
