@@ -95,20 +95,14 @@ __global__ __launch_bounds__(kGvWaves* kWave, kGvWaves / 2) void gemv_kernel(Gem
     }
 
     // ---- the first weight loads leave before the input vector is staged (they do not depend on it).  Addressing: the
-    // row base is wave-uniform (forced into an SGPR pair, advanced per round), the lane's part one 32-bit offset, the slot
+    // row base is wave-uniform (an SGPR pair, advanced per round), the lane's part one 32-bit offset, the slot
     // an immediate -- except in the last round of a row whose length is not a multiple of a round, where the vector index
     // is clamped (kClamp).  A round = kGvUnroll slots x 64 lanes x 16 bytes per row.
     constexpr uint32_t kRoundHalves = kGvUnroll * kWave * kVec;
     const uint32_t full = n_vec / (kGvUnroll * kWave);  // rounds whose every slot lies inside the row for every lane
     half8 wv[kGvUnroll][kGvRows];
     const uint32_t lane_off = lane * kVec;
-    const half_t* rbase[kGvRows];
-#pragma unroll
-    for (int r = 0; r < kGvRows; ++r) {
-        const uintptr_t a = (uintptr_t)wrow[r];
-        rbase[r] = (const half_t*)(((uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
-                                   (uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)a));
-    }
+    const half_t* const* rbase = wrow;  // (already wave-uniform for the compiler: built from blockIdx and the SGPR wave index)
     // request round `o` of every row into slot u (kClamp: the round may reach past the row's end)
     auto issue = [&](uint32_t o, int u, auto clamp_c) {
         constexpr bool kClamp = decltype(clamp_c)::value;
