@@ -320,3 +320,82 @@ def test_hf_checkpoint_round_trip_and_hf_interop(tmp_path):
     save_file(sd, os.path.join(d2, "model.safetensors"), metadata={"format": "pt"})
     with pytest.raises(KeyError, match="unexpected tensor"):
         LlamaForCausalLM.from_pretrained(d2, device=torch.device("cpu"))
+
+
+def test_round3_entry_points_validate_arguments_without_gpu():
+    """The round-3 C-ABI entries (batched operators, strided fused launches, fused decoder-layer launches) return
+    argument errors before any launch (no GPU needed)."""
+    import ctypes
+
+    from quest_amd._lib import Batch, PagedKV, lib
+
+    empty = PagedKV()
+    one = ctypes.c_void_p(16)
+    b1 = Batch(1, 0, 0, 0, None)
+    assert lib.quest_estimate_attn_score_batched(one, one, 32, 8, 16, empty, one, b1, None) == -1   # o_stride < max_n_out
+    assert lib.quest_estimate_attn_score_batched(one, one, 32, 16, 8, empty, None, b1, None) == -1  # no state
+    assert lib.quest_topk_filtering_batched(None, 16, 8, one, one, one, 4, 32, 5, one, b1, None) == -1
+    assert lib.quest_topk_filtering_batched(one, 4, 8, one, one, one, 4, 32, 5, one, b1, None) == -1   # stride < max pages
+    assert lib.quest_topk_filtering_batched(one, 20000, 20000, one, one, one, 4, 32, 5, one, b1, None) == -4  # > QUEST_TOPK_MAX_ROW
+    b2 = Batch(2, 4, 0, 0, None)
+    assert lib.quest_topk_filtering_batched(one, 16, 8, one, one, one, 4, 32, 5, one, b2, None) == -1  # table stride < pages
+    assert lib.quest_decode_forward_batched(None, one, one, empty, 32, one, 4, one, b1, None, None) == -1
+    assert lib.quest_append_estimate_strided(None, None, empty, one, one, 32, 10, 16, empty, None) == -1
+    kv = PagedKV(data=16, indices=16, indptr=16, num_heads=32, page_size=16, head_dim=128, page_budget=0,
+                 last_page_len=1, last_page_idx=0, layout=0)
+    assert lib.quest_append_estimate_strided(one, one, kv, one, one, 32, 10, 4, kv, None) == -1     # o_stride < n_out
+    h = ctypes.c_void_p()
+    assert lib.quest_decode_handler_create(ctypes.byref(h), 0) == 0
+    assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, one, 10, 4, None, None, None, None) == -1
+    assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, None, 10, 16, None, None, None, None) == -1
+    assert lib.quest_decode_set_front_end(h, 3) == 0 and lib.quest_decode_set_front_end(h, 4) == -1
+    lib.quest_decode_handler_destroy(h)
+    # fused decoder-layer launches
+    assert lib.quest_decode_norm_gemv(None, None, 0.0, one, one, 64, 8, None) == -1
+    assert lib.quest_decode_norm_gemv(one, None, 0.0, one, one, 60, 8, None) == -2          # in_dim % 8
+    assert lib.quest_decode_gemv_residual(one, one, None, 64, 8, None) == -1
+    assert lib.quest_decode_mlp_gate_up(one, None, 1e-5, one, one, one, 64, 128, None) == -1  # the MLP launch needs gamma
+    assert lib.quest_decode_qkv_rope(one, one, 1e-5, one, one, one, one, one, one, 512, 4, 4, 128, 1.0, 1e4, None, None) == -1
+    assert lib.quest_decode_qkv_rope(one, one, 1e-5, one, one, one, one, one, one, 512, 4, 4, 128, 0.0, 1e4, one, None) == -1
+    assert b"r3" in lib.quest_build_info()
+
+
+def test_batched_controller_page_budgets_host_logic():
+    from quest_amd.utils import BatchedInferenceController
+
+    bc = BatchedInferenceController(3, 1, 4, 128, 16, 5, 200, torch.float16, "cpu", num_kv_heads=2)
+    assert bc.max_page_budget() == 5 and bc.page_budgets is None
+    bc.set_page_budgets([3, 9, 4])
+    assert bc.max_page_budget() == 9 and bc.page_budgets.tolist() == [3, 9, 4] and bc.page_budgets.dtype == torch.int32
+    with pytest.raises(ValueError):
+        bc.set_page_budgets([3, 9])       # one per sequence
+    with pytest.raises(ValueError):
+        bc.set_page_budgets([3, 0, 4])    # >= 1: the current page is always attended
+    bc.set_page_budgets(None)
+    assert bc.max_page_budget() == 5 and bc.page_budgets is None
+    with pytest.raises(RuntimeError, match="enable_device_state"):
+        bc.begin_forward()                # eager batched steps need the device-resident tables / states
+
+
+def test_kernel_sweep_table_and_side_flags():
+    import importlib.util
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.parse(["--kernel-sweep"])
+    assert a.kernel_sweep and not a.no_side and a.side_steps == 100
+    assert bench.parse(["--no-side"]).no_side
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import kbench_reference_rows as sweep
+
+    # the byte accounting of the reference bench (bench_batch_decode.cu:82-86) for its published 128-page row
+    r = sweep.row("attention seqlen=4096 page_budget=128", 10.0, 32 * 128 * 2 + 128 * 2 * 32 * 16 * 128 * 2 + 8 + 32 * 127 * 4,
+                  32 * 128 * 2, published_rtx6000ada={"us": 63.551, "GBps": 528.5, "pct_of_its_peak": 55.05})
+    assert abs(r["read_MiB"] - 32.023) < 1e-3          # the figure the reference's plot prints
+    md = sweep.markdown({"rows": [r]})
+    assert "63.551 us" in md and md.count("\n") == 2
+    assert sweep.LONGBENCH_LEN == (5819, 15370, 11984, 14101, 24723, 8154) and sweep.LONGBENCH_BUDGET[4] == 4096
