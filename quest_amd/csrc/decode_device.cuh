@@ -292,6 +292,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         // (unconditional, from q's bytes when there is no state: a load under a branch is waited for at the join)
         const int4 live = *(p.state ? reinterpret_cast<const int4*>(sv.state)
                                     : reinterpret_cast<const int4*>(p.q));  // seq_len, n_pages, kv_last_page_len, kv_last_page_idx
+
         uint4 own_keys = make_uint4(0u, 0u, 0u, 0u), own_ids[2] = {own_keys, own_keys};  // vec_front == 3
         const bool own_cols = FC == 8 && vec_front == 3;
         // the thread's own contiguous columns (vec_front 3): their page ids (1-2 x 16 bytes) and 16 bytes of scores per
@@ -315,22 +316,28 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 }
         }
         if (own_cols) {
-            if (p.cpt == 8) {
-                own_keys = *reinterpret_cast<const uint4*>(srow + own_cc);
-            } else {
-                const uint2 k2 = *reinterpret_cast<const uint2*>(srow + own_cc);
-                own_keys.x = k2.x, own_keys.y = k2.y;
+            {   // two UNCONDITIONAL 8-byte loads (the second one repeats the first when the thread owns 4 columns): a
+                // 16-byte load under `if (cpt == 8)` was compiled as "upper half under the branch, s_waitcnt vmcnt(0) at
+                // the join, then the lower half" -- two serialised round trips in front of the selection at every shape
+                // whose capacity exceeds 2048 pages (the bench's: cpt = 8)
+                const uint2 lo = *reinterpret_cast<const uint2*>(srow + own_cc);
+                const uint2 hi = *reinterpret_cast<const uint2*>(srow + own_cc + (p.cpt == 8 ? 4u : 0u));
+                own_keys = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
             fe2_clear<NT>(sm);
         } else if (vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
             fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
             fe2_clear<NT>(sm);
         }
+        // the per-sequence budget of a batched launch (from q's first bytes when there is none): requested here, after the
+        // vector loads above have left, so that its round trip -- the pointer sits at the end of the argument struct --
+        // runs under theirs instead of being fetched and waited for at its use
+        const int32_t budget_raw = ld_uniform_i32(p.budgets ? p.budgets + seq : reinterpret_cast<const int32_t*>(p.q));
         if (p.state) {  // live lengths
             p.n_scores = (uint32_t)(live.y - 1);
             p.last_page_len = (uint32_t)live.z;
             p.last_page_idx = live.w;
-            if (p.budgets) p.n_sel = min(p.n_sel, (uint32_t)max(p.budgets[seq] - 1, 0));
+            if (p.budgets) p.n_sel = min(p.n_sel, (uint32_t)max(budget_raw - 1, 0));
             p.n_sel = min(p.n_sel, p.n_scores);
         }
         plan_slots();
@@ -411,17 +418,17 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 }
             }
             }
+#ifdef QUEST_TIMELINE
+            long long sub[9] = {};
+#else
+            long long* const sub = nullptr;
+#endif
             topk_publish_range<NT>(sm, mm);
             QUEST_STAMP(2);
             __syncthreads();
             QUEST_STAMP(3);
             if (!direct) topk_load_keys<FC>(keys_s, c0, n, cpt, key);
-#ifdef QUEST_TIMELINE
-            long long sub[9] = {};
             TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, sub);
-#else
-            TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt);
-#endif
 #ifdef QUEST_TIMELINE
             for (int i = 0; i < 9; ++i) sub_out[i] = sub[i];
 #endif

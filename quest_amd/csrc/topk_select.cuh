@@ -128,6 +128,30 @@ __device__ __forceinline__ void topk_load_keys(const uint16_t* keys_s, uint32_t 
     do { } while (0)
 #endif
 
+// Shared tail of the selection routines: with T / need known (cur), count the thread's keys above and at the threshold
+// and turn the block-wide exclusive prefix into the cursor (output slot of the thread's first selected column, rank of
+// its first tied column).
+template <int NT, int C>
+__device__ __forceinline__ TopkCursor topk_finish(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t cpt,
+                                                 TopkCursor cur, long long* sub) {
+    const uint32_t c0 = threadIdx.x * cpt;
+    uint32_t gt = 0, eq = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const bool in = (uint32_t)i < cpt && c0 + i < n;
+        gt += in && key[i] > cur.T;
+        eq += in && key[i] == cur.T;
+    }
+    const uint32_t packed = gt | (eq << 16);  // both totals < 65536 (n <= 16384)
+    QUEST_SUBSTAMP(7);
+    const uint32_t before = block_scan_incl<NT>(packed, sm.wave_tot[1]) - packed;
+    QUEST_SUBSTAMP(8);
+    cur.eq_rank = before >> 16;
+    cur.pos = (before & 0xffffu) + (cur.eq_rank < cur.need ? cur.eq_rank : cur.need);
+    (void)sub;
+    return cur;
+}
+
 template <int NT, int C>
 __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k,
                                                   uint32_t cpt, long long* sub = nullptr) {
@@ -229,21 +253,13 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
         cur.need = sm.misc[3];
     }
 
-    uint32_t gt = 0, eq = 0;
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const bool in = (uint32_t)i < cpt && c0 + i < n;
-        gt += in && key[i] > cur.T;
-        eq += in && key[i] == cur.T;
-    }
-    const uint32_t packed = gt | (eq << 16);  // both totals < 65536 (n <= 16384)
-    QUEST_SUBSTAMP(7);
-    const uint32_t before = block_scan_incl<NT>(packed, sm.wave_tot[1]) - packed;
-    QUEST_SUBSTAMP(8);
-    cur.eq_rank = before >> 16;
-    cur.pos = (before & 0xffffu) + (cur.eq_rank < cur.need ? cur.eq_rank : cur.need);
-    return cur;
+    return topk_finish<NT, C>(sm, key, n, cpt, cur, sub);
 }
+
+// (A low-bits variant -- bins = key & 2047, so that the range publish and the histogram atomics share one barrier, with
+// the cleared histogram published under the score loads' latency -- was built in round 3 for the register-ownership front
+// end: bit-identical, 0.75 us FASTER per workgroup in the warm in-kernel timeline, 0.7-0.8 us SLOWER per launch in the
+// bench (12.80 vs 12.02 us; no fallback taken, no extra registers; unexplained).  Removed)
 
 // Advance the cursor over one owned column (in column order); returns true when the column is
 // selected, in which case `slot` is its output position.
