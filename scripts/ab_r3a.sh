@@ -1,4 +1,6 @@
 #!/bin/bash
+# Historical (round 3, gpurun_out/r3a_*): needs the round-2 tree as a worktree (`git worktree add --detach build/r02tree <r02 commit>` + `python -m quest_amd.build` there)
+# and the in-kernel-merge build of commit 7c41f29 (QUEST_MERGE=inline|launch); kept as the record of how DESIGN.md 3.4's figures were taken.
 # Round-3 A/B on one box: r02 tree (build/r02tree) vs this tree with the in-kernel merge and with the merge launch.
 set -o pipefail
 mkdir -p gpurun_out

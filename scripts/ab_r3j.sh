@@ -1,4 +1,5 @@
 #!/bin/bash
+# Historical (round 3, gpurun_out/r3j_*): libquest_hip_nohints.so = `build_variant(..., ["-DQUEST_NO_LAYOUT_HINTS"])` of the tree that still had hints in the attention kernel.
 set -o pipefail
 O=$PWD/gpurun_out; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/r3j_tests.log 2>&1 || { tail -30 $O/r3j_tests.log; exit 1; }

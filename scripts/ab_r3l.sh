@@ -1,4 +1,5 @@
 #!/bin/bash
+# Needs the round-2 tree as a worktree under build/r02tree (see ab_r3a.sh).
 set -o pipefail
 O=$PWD/gpurun_out; mkdir -p $O
 for rep in 1 2; do
