@@ -18,6 +18,9 @@
 // launch carries a RMSNorm prologue -- every workgroup recomputes the 8 KiB reduction rather than pay a launch for it),
 // the weight loads of the first round are issued BEFORE the prologue so its latency hides under them.  HBM-bound
 // (weights read exactly once): 4.9-5.7 TB/s at Llama-2-7B shapes; no MFMA: M = 1.
+#include <cstdio>
+#include <cstdlib>
+
 #include "quest_common.cuh"
 
 namespace quest {
@@ -241,12 +244,28 @@ static int launch_gemv_rw(const GemvArgs& p, uint32_t virtual_rows, hipStream_t 
 
 // 8-wave workgroups, 8 loads of 16 bytes in flight per lane (RW x U = 8: <= 100 VGPRs, two workgroups = 16 waves = 128 KiB
 // in flight per CU, the attention kernel's shape; 16 per lane needed 146-176 VGPRs and spilled under the 128 cap);
-// the largest rows-per-wave that still gives two workgroups per CU (512)
+// the largest rows-per-wave that still gives two workgroups per CU (512).  QUEST_GEMV_CFG="RW,U" forces one of the
+// built shapes (tuning).
 template <int MODE>
 static int launch_gemv(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) {
     constexpr uint32_t kWant = 512;
+    static const int forced = [] {
+        const char* e = getenv("QUEST_GEMV_CFG");
+        int rw = 0, u = 0;
+        return e && sscanf(e, "%d,%d", &rw, &u) == 2 ? rw * 100 + u : 0;
+    }();
+    constexpr bool kPairs = !(MODE == kGvPlain || MODE == kGvResidual);  // row-dots come in pairs: RW even
+    switch (forced) {
+        case 402: return launch_gemv_rw<MODE, 8, 4, 2>(p, virtual_rows, s);
+        case 404: return launch_gemv_rw<MODE, 8, 4, 4>(p, virtual_rows, s);
+        case 204: return launch_gemv_rw<MODE, 8, 2, 4>(p, virtual_rows, s);
+        case 208: return launch_gemv_rw<MODE, 8, 2, 8>(p, virtual_rows, s);
+        case 108: if constexpr (!kPairs) return launch_gemv_rw<MODE, 8, 1, 8>(p, virtual_rows, s); break;
+        case 116: if constexpr (!kPairs) return launch_gemv_rw<MODE, 8, 1, 16>(p, virtual_rows, s); break;
+        default: break;
+    }
     if (virtual_rows / (8 * 4) >= kWant) return launch_gemv_rw<MODE, 8, 4, 2>(p, virtual_rows, s);
-    if constexpr (MODE == kGvPlain || MODE == kGvResidual) {
+    if constexpr (!kPairs) {
         if (virtual_rows / (8 * 2) >= kWant) return launch_gemv_rw<MODE, 8, 2, 4>(p, virtual_rows, s);
         return launch_gemv_rw<MODE, 8, 1, 8>(p, virtual_rows, s);
     } else {
