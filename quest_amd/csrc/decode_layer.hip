@@ -257,11 +257,13 @@ static int launch_gemv(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) 
     constexpr bool kPairs = !(MODE == kGvPlain || MODE == kGvResidual);  // row-dots come in pairs: RW even
     switch (forced) {
         case 402: return launch_gemv_rw<MODE, 8, 4, 2>(p, virtual_rows, s);
-        case 404: return launch_gemv_rw<MODE, 8, 4, 4>(p, virtual_rows, s);
         case 204: return launch_gemv_rw<MODE, 8, 2, 4>(p, virtual_rows, s);
-        case 208: return launch_gemv_rw<MODE, 8, 2, 8>(p, virtual_rows, s);
+        case 401: return launch_gemv_rw<MODE, 8, 4, 1>(p, virtual_rows, s);
+        case 202: return launch_gemv_rw<MODE, 8, 2, 2>(p, virtual_rows, s);
+        case 201: return launch_gemv_rw<MODE, 8, 2, 1>(p, virtual_rows, s);
+        case 104: if constexpr (!kPairs) return launch_gemv_rw<MODE, 8, 1, 4>(p, virtual_rows, s); break;
+        case 102: if constexpr (!kPairs) return launch_gemv_rw<MODE, 8, 1, 2>(p, virtual_rows, s); break;
         case 108: if constexpr (!kPairs) return launch_gemv_rw<MODE, 8, 1, 8>(p, virtual_rows, s); break;
-        case 116: if constexpr (!kPairs) return launch_gemv_rw<MODE, 8, 1, 16>(p, virtual_rows, s); break;
         default: break;
     }
     if (virtual_rows / (8 * 4) >= kWant) return launch_gemv_rw<MODE, 8, 4, 2>(p, virtual_rows, s);
