@@ -435,7 +435,8 @@ def step_op_times(w, a, bpl, reps=10):
     alg = n * (bpl["attn"] + bpl["topk"])
     achieved = alg / (t_ts_kernel * 1e-6) / 1e9
     waves = 8 if (a.page_size == 16 and max_n > 1024) or os.environ.get("QUEST_DEC_WAVES") == "8" else 4
-    fc = max(8, 1 << (max(1, -(-max_n // (waves * 64))) - 1).bit_length())
+    per_thread = max(1, -(-max_n // (waves * 64)))
+    fc = 8 if per_thread <= 8 else 16 if per_thread <= 16 else 24 if per_thread <= 24 else 32 if per_thread <= 32 else 64
     ops = {"append_estimate_us": t_ae, "topk_sparse_attn_plus_merge_us": t_ts, "topk_sparse_attn_kernel_only_us": t_ts_kernel,
            "append_estimate_gbs": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9,
            "append_estimate_frac_of_hbm_peak": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9 / HBM_PEAK_GBS,

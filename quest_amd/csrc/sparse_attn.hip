@@ -432,7 +432,7 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     static const bool specialize = [] { const char* e = getenv("QUEST_FE_SPECIALIZE"); return !e || atoi(e) != 0; }();
     if (specialize && p.page_size == 16 && waves == 8) {
         constexpr int VFA = FC == 8 ? 3 : 2, VFB = FC == 8 ? 1 : 2;
-        if constexpr (FC == 8 || FC == 16 || FC == 32) {
+        if constexpr (FC == 8 || FC == 16 || FC == 24 || FC == 32) {
             if (p.vec_front == (uint32_t)VFA) {
                 hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFA>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
                 QUEST_LAUNCH_CHECK();
@@ -469,6 +469,7 @@ static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, u
         case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, waves, s, n_seqs);
         case 8: return launch_decode_fc<D, 8>(h, p, num_qo_heads, waves, s, n_seqs);
         case 16: return launch_decode_fc<D, 16>(h, p, num_qo_heads, waves, s, n_seqs);
+        case 24: return launch_decode_fc<D, 24>(h, p, num_qo_heads, waves, s, n_seqs);
         case 32: return launch_decode_fc<D, 32>(h, p, num_qo_heads, waves, s, n_seqs);
         case 64: return launch_decode_fc<D, 64>(h, p, num_qo_heads, waves, s, n_seqs);
         default: return QUEST_EUNSUPPORTED;
@@ -586,7 +587,11 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         if (kv.page_size == 16 && n_scores > 4u * 4u * kWave) waves = 8;
         const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
         const uint32_t per_thread = (n_scores + nt - 1) / nt;
-        fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : per_thread <= 32 ? 32 : 64;
+        // (24: rows of 8193-12288 columns at 512 threads -- cfg 4's capacity of ~8320 pages needs 17 keys per thread; the
+        // 32-key instantiation carries two more dead load / histogram / bitmap rounds in every unrolled phase.
+        // QUEST_FC24=0 takes the 32-key instantiation instead: A/B)
+        static const bool fc24 = [] { const char* e = getenv("QUEST_FC24"); return !e || atoi(e) != 0; }();
+        fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : (per_thread <= 24 && fc24) ? 24 : per_thread <= 32 ? 32 : 64;
         // ownership chunk: a multiple of 4 columns when the register capacity allows, so a thread's keys are one
         // 8/16-byte LDS read (topk_load_keys)
         const uint32_t r4 = (per_thread + 3) / 4 * 4;
