@@ -363,6 +363,24 @@ int quest_decode_qkv_rope(const void* h, const void* gamma, float eps, const voi
                           void* q, void* k, void* v, uint32_t hidden, uint32_t num_qo_heads, uint32_t num_kv_heads,
                           uint32_t head_dim, float rope_scale, float rope_theta, const quest_step_state_t* state,
                           quest_stream_t stream);
+/*
+ * The same four launches for n_tokens <= 16 decode tokens at once -- one per sequence of a batch (the reference asserts
+ * batch size 1; BatchedInferenceController): x / h `[n_tokens][in]`, outputs `[n_tokens][out]` (q / k / v
+ * `[n_tokens][heads][head_dim]`), all contiguous; `states` = n_tokens consecutive quest_step_state_t records (the batched
+ * step state), token i rotated at states[i].seq_len - 1.  The weights are read once for the whole batch (MFMA row-dots:
+ * weights = A operand, tokens = the 16 columns of B); head_dim % 16 == 0 for the q/k/v launch.
+ */
+int quest_decode_norm_gemv_batched(const void* x, const void* gamma, float eps, const void* w, void* out, uint32_t in_dim,
+                                   uint32_t out_dim, uint32_t n_tokens, quest_stream_t stream);
+int quest_decode_gemv_residual_batched(const void* x, const void* w, void* h, uint32_t in_dim, uint32_t out_dim,
+                                       uint32_t n_tokens, quest_stream_t stream);
+int quest_decode_mlp_gate_up_batched(const void* h, const void* gamma, float eps, const void* w_gate, const void* w_up,
+                                     void* act, uint32_t hidden, uint32_t intermediate, uint32_t n_tokens,
+                                     quest_stream_t stream);
+int quest_decode_qkv_rope_batched(const void* h, const void* gamma, float eps, const void* wq, const void* wk,
+                                  const void* wv, void* q, void* k, void* v, uint32_t hidden, uint32_t num_qo_heads,
+                                  uint32_t num_kv_heads, uint32_t head_dim, float rope_scale, float rope_theta,
+                                  const quest_step_state_t* states, uint32_t n_tokens, quest_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -312,6 +312,89 @@ def decode_qkv_rope(h, gamma, eps: float, wq, wk, wv, q, k, v, head_dim: int, ro
                                     float(rope_theta), state.data_ptr(), _stream(h)), "decode_qkv_rope")
 
 
+# ---- the fused decode-layer launches for n <= 16 tokens (one per sequence of a batch)
+
+MAX_BATCHED_TOKENS = 16
+
+
+def _check_mat(x, n: int, cols: int, name: str) -> None:
+    _check_input(x, name)
+    _check_eq(x.numel(), n * cols, f"{name}.numel(), {n} * {cols}")
+    _check_half(x, name)
+
+
+def _check_tokens(n: int) -> None:
+    if not 1 <= n <= MAX_BATCHED_TOKENS:
+        raise RuntimeError(f"batched decode-layer launches take 1..{MAX_BATCHED_TOKENS} tokens, got {n}")
+
+
+def decode_norm_gemv_batched(x, gamma, eps: float, w, out) -> None:
+    """``out[i] = w @ rmsnorm(x[i]; gamma, eps)`` (``gamma`` None: no norm); x ``[n, in]``, out ``[n, out]``."""
+    out_dim, in_dim = w.shape
+    n = x.numel() // in_dim
+    _check_tokens(n)
+    _check_mat(x, n, in_dim, "x")
+    _check_mat(out, n, out_dim, "out")
+    _check_weight(w, out_dim, in_dim, "w")
+    if gamma is not None:
+        _check_vec(gamma, in_dim, "gamma")
+    check(lib.quest_decode_norm_gemv_batched(x.data_ptr(), gamma.data_ptr() if gamma is not None else None, float(eps),
+                                             w.data_ptr(), out.data_ptr(), in_dim, out_dim, n, _stream(x)),
+          "decode_norm_gemv_batched")
+
+
+def decode_gemv_residual_batched(x, w, h) -> None:
+    """``h[i] += w @ x[i]`` in place; x ``[n, in]``, h ``[n, out]``."""
+    out_dim, in_dim = w.shape
+    n = x.numel() // in_dim
+    _check_tokens(n)
+    _check_mat(x, n, in_dim, "x")
+    _check_mat(h, n, out_dim, "h")
+    _check_weight(w, out_dim, in_dim, "w")
+    check(lib.quest_decode_gemv_residual_batched(x.data_ptr(), w.data_ptr(), h.data_ptr(), in_dim, out_dim, n, _stream(x)),
+          "decode_gemv_residual_batched")
+
+
+def decode_mlp_gate_up_batched(h, gamma, eps: float, w_gate, w_up, act) -> None:
+    """``act[i] = silu(w_gate @ n_i) * (w_up @ n_i)``, ``n_i = rmsnorm(h[i]; gamma, eps)``; h ``[n, hidden]``."""
+    inter, hidden = w_gate.shape
+    n = h.numel() // hidden
+    _check_tokens(n)
+    _check_mat(h, n, hidden, "h")
+    _check_vec(gamma, hidden, "gamma")
+    _check_mat(act, n, inter, "act")
+    _check_weight(w_gate, inter, hidden, "w_gate")
+    _check_weight(w_up, inter, hidden, "w_up")
+    check(lib.quest_decode_mlp_gate_up_batched(h.data_ptr(), gamma.data_ptr(), float(eps), w_gate.data_ptr(),
+                                               w_up.data_ptr(), act.data_ptr(), hidden, inter, n, _stream(h)),
+          "decode_mlp_gate_up_batched")
+
+
+def decode_qkv_rope_batched(h, gamma, eps: float, wq, wk, wv, q, k, v, head_dim: int, rope_scale: float,
+                            rope_theta: float, states) -> None:
+    """q ``[n, Hq, D]``, k / v ``[n, Hkv, D]`` = projections of ``rmsnorm(h[i]; gamma, eps)``, RoPE on q and k at
+    ``states[i].seq_len - 1`` (``states``: the batched step state ``[n, 8]`` int32)."""
+    hidden = wq.size(1)
+    n = h.numel() // hidden
+    _check_tokens(n)
+    _check_mat(h, n, hidden, "h")
+    _check_vec(gamma, hidden, "gamma")
+    _check_weight(wq, wq.size(0), hidden, "wq")
+    _check_weight(wk, wk.size(0), hidden, "wk")
+    _check_weight(wv, wk.size(0), hidden, "wv")
+    _check_mat(q, n, wq.size(0), "q")
+    _check_mat(k, n, wk.size(0), "k")
+    _check_mat(v, n, wk.size(0), "v")
+    _check_input(states, "states")
+    _check_eq(states.numel(), n * STEP_STATE_INTS, "states.numel(), n * 8")
+    _check_eq(wq.size(0) % head_dim, 0, "wq.size(0) % head_dim, 0")
+    check(lib.quest_decode_qkv_rope_batched(h.data_ptr(), gamma.data_ptr(), float(eps), wq.data_ptr(), wk.data_ptr(),
+                                            wv.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), hidden,
+                                            wq.size(0) // head_dim, wk.size(0) // head_dim, int(head_dim),
+                                            float(rope_scale), float(rope_theta), states.data_ptr(), n, _stream(h)),
+          "decode_qkv_rope_batched")
+
+
 # ---- state-driven (graph-replayable) forms: EXTENSIONS, see include/quest_hip.h quest_step_state_t
 
 STEP_STATE_INTS = 8  # int32 fields of quest_step_state_t

@@ -275,6 +275,249 @@ static int launch_gemv(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same four launches for n <= 16 decode tokens at once (one per sequence of a batch: BatchedInferenceController).
+// The weights are still read exactly once, so the launch is as HBM-bound as the batch-1 one, but 8 tokens x 2 flops per
+// weight no longer fit the vector ALUs next to the loads (44 TFLOP/s of v_dot2 at 5.5 TB/s): the products go through the
+// matrix cores -- in the one MFMA shape whose operand layout IS a coalesced row sweep.
+//
+//   v_mfma_f32_4x4x4_16B_f16 = 16 independent 4 x 4 x 4 products, lane 4b + i holding row i of block b's A, lane 4b + j
+//   column j of its B (4 halves each), lane 4b + j column j of its D (4 floats).  With block = a k chunk, A = 4 tokens and
+//   B = 4 weight rows, a lane (b, j) loads 16 contiguous bytes of weight row j at k = 128 s + 8 b: one wave instruction
+//   reads 4 rows x 256 contiguous bytes -- full 128-byte lines, like the batch-1 kernel -- and feeds two MFMAs (k halves)
+//   per token group with no staging and no shuffle.  (The 16 x 16 x 32 shape, first version of this kernel, wants 16 rows
+//   x 64 bytes per instruction: twice the lines per byte through the texture addresser -- 3.1 TB/s against 5.1-5.6.)
+//   The tokens' inputs are loaded the same way (lane (b, i): token i, same k chunk; L2 hits, 4 tokens x 256 bytes per
+//   instruction), 0.5 input bytes per weight byte at 8 tokens x 16 rows; the RMSNorm prologue is applied to that
+//   fragment in registers (x * inv_rms[token] * gamma, rounded to fp16 like rms_norm_forward), gamma from LDS.
+//
+//   workgroup = 16 consecutive (virtual) weight rows (4 quads) x the whole reduction, split over its NW waves by k: wave w
+//   takes the 128-wide k steps w, w + NW, ...; U steps in flight per lane.  The 16 k chunks of a lane's accumulators meet
+//   by DPP at the end of the wave, the waves' 16 x n tiles in LDS; 128 threads then own one (token, row pair) each and
+//   run the same epilogues as the batch-1 kernel.  TG = token groups of 4 (n <= 4 TG).
+struct SkinnyArgs {
+    GemvArgs g;              // x: [n_tokens][x_stride], out[i]: [n_tokens][out_stride[i]], residual like out[0]
+    uint32_t n_tokens;       // 1..16
+    uint32_t x_stride;       // halves between the inputs of consecutive tokens
+    uint32_t out_stride[3];  // halves between the outputs of consecutive tokens
+    uint32_t state_stride;   // kGvQkvRope: quest_step_state_t records between consecutive tokens' states (batched state: 1)
+};
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+// (matrix, row) of virtual row vr of a launch (the batch-1 kernel's order: gate / up interleaved; rotation pairs adjacent)
+template <int MODE>
+__device__ __forceinline__ bool skinny_row(const GemvArgs& p, uint32_t vr, uint32_t& m, uint32_t& rr) {
+    bool live;
+    m = 0;
+    if constexpr (MODE == kGvSiluMul) {
+        m = vr & 1u, rr = vr >> 1, live = rr < p.rows[0];
+    } else {
+        while (m < 2 && vr >= p.rows[m]) vr -= p.rows[m], ++m;
+        live = vr < p.rows[m], rr = vr;
+        if constexpr (MODE == kGvQkvRope) {
+            const uint32_t hd = p.head_dim, head = rr / hd, j = rr % hd;
+            rr = head * hd + (j >> 1) + (j & 1u) * (hd / 2);
+        }
+    }
+    return live;
+}
+
+template <int MODE, int NW, int U, int TG>
+__global__ __launch_bounds__(NW* kWave, 2) void skinny_kernel(SkinnyArgs a) {  // 8 waves per CU: <= 256 VGPRs
+    const GemvArgs& p = a.g;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+    half_t* gamma_s = reinterpret_cast<half_t*>(sk_smem);  // RMSNorm weight (in_dim halves; launches with a prologue only)
+    __shared__ float s_ss[4 * TG][NW];                     // per token, per wave: sum of squares
+    __shared__ float s_part[NW][16][4 * TG];               // the waves' partial tiles [row][token]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t j = lane & 3u, blk = lane >> 2;  // B column (weight row of a quad) = A row (token of a group); k chunk
+
+    // ---- the lane's four weight rows (quad q: virtual row 16 block + 4 q + j) and TG input rows (token 4 t + j)
+    const half_t* wrow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t m, rr;
+        const bool live = skinny_row<MODE>(p, blockIdx.x * 16u + 4u * (uint32_t)q + j, m, rr);
+        wrow[q] = p.w[live ? m : 0] + (size_t)(live ? rr : 0u) * p.in_dim;  // dead rows read row 0 (never written out)
+    }
+    const half_t* xrow[TG];
+    bool tok[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        tok[t] = 4u * (uint32_t)t + j < a.n_tokens;
+        xrow[t] = p.x + (size_t)(tok[t] ? 4u * (uint32_t)t + j : 0u) * a.x_stride;
+    }
+    const bool norm = p.gamma != nullptr;  // block-uniform
+
+    const uint32_t n_steps = (p.in_dim + 127u) / 128u;
+    const uint32_t mine = wave < n_steps ? (n_steps - wave + NW - 1) / NW : 0u;  // this wave's steps
+    half8 wv[U][4], xv[U][TG];
+    auto issue = [&](uint32_t s, int u) {
+        const uint32_t k0 = (wave + NW * s) * 128u + blk * 8u;
+        const uint32_t kc = k0 < p.in_dim ? k0 : 0u;  // clamped; masked at use
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[u][q] = ld8_stream(wrow[q] + kc);
+#pragma unroll
+        for (int t = 0; t < TG; ++t) xv[u][t] = ld8(xrow[t] + kc);
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) issue((uint32_t)u, u);
+
+    // ---- RMSNorm prologue: 1 / rms of every token (every workgroup recomputes them; their loads queue behind the first
+    // weight fragments)
+    float inv[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) inv[t] = 1.0f;
+    if (norm) {
+        const uint32_t n_vec = p.in_dim / kVec;
+        for (uint32_t t = 0; t < a.n_tokens; ++t) {
+            float ss = 0.f;
+            for (uint32_t v = tid; v < n_vec; v += NW * kWave) {
+                const float8 xf = to_f32(ld8(p.x + (size_t)t * a.x_stride + (size_t)v * kVec));
+#pragma unroll
+                for (int i = 0; i < kVec; ++i) ss = __builtin_fmaf(xf[i], xf[i], ss);
+            }
+            ss = wave_allreduce_sum(ss, (int)lane);
+            if (lane == 0) s_ss[t][wave] = ss;
+        }
+        for (uint32_t v = tid; v < n_vec; v += NW * kWave) st8(gamma_s + (size_t)v * kVec, ld8(p.gamma + (size_t)v * kVec));
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+            if (tok[t]) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += s_ss[4 * t + j][w];
+                inv[t] = 1.0f / sqrtf(tot / (float)p.in_dim + p.eps);
+            }
+    }
+
+    // ---- stream
+    float4_t acc[4][TG];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[q][t] = float4_t{0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](uint32_t s, int u) {
+        const uint32_t k0 = (wave + NW * s) * 128u + blk * 8u;
+        const bool in = k0 < p.in_dim;
+        float8 gf;
+        if (norm) gf = to_f32(ld8(gamma_s + (in ? k0 : 0u)));
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            half8 b = xv[u][t];
+            if (norm) {
+                const float8 xf = to_f32(b);
+                float8 rr;
+#pragma unroll
+                for (int i = 0; i < kVec; ++i) rr[i] = xf[i] * inv[t] * gf[i];
+                b = __builtin_convertvector(rr, half8);
+            }
+            if (!tok[t] || !in) b = (half8)(half_t)0;  // dead token / past the row's end: contributes nothing
+            const half4_t b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half8 w8 = wv[u][q];
+                const half4_t w0 = {w8[0], w8[1], w8[2], w8[3]}, w1 = {w8[4], w8[5], w8[6], w8[7]};
+                acc[q][t] = __builtin_amdgcn_mfma_f32_4x4x4f16(b0, w0, acc[q][t], 0, 0, 0);  // A = tokens, B = weight rows
+                acc[q][t] = __builtin_amdgcn_mfma_f32_4x4x4f16(b1, w1, acc[q][t], 0, 0, 0);
+            }
+        }
+    };
+    const uint32_t rounds = (mine + U - 1) / U;
+    for (uint32_t o = 0; o < rounds; ++o) {
+        if (o + 1 < rounds) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                consume(o * U + (uint32_t)u, u);
+                issue((o + 1) * U + (uint32_t)u, u);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) consume(o * U + (uint32_t)u, u);
+        }
+    }
+    // ---- the 16 k chunks of the wave meet: lanes 4 b + j over b (distances 4, 8 inside a row of 16 lanes, then 16, 32);
+    // D element e of acc[q][t] at lane (b, j) = token 4 t + e, row 4 q + j
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[q][t][e];
+                v += dpp_f<kDppRowRor + 8>(v);
+                v += dpp_f<kDppRowRor + 4>(v);
+                v += lane_xor<16>(v, (int)lane);
+                v += lane_xor<32>(v, (int)lane);
+                if (lane < 4u) s_part[wave][4 * q + lane][4 * t + e] = v;
+            }
+    __syncthreads();
+
+    // ---- 128 threads: (token, row pair)
+    if (tid >= 128u) return;
+    const uint32_t token = tid & 15u, pair = tid >> 4;
+    if (token >= a.n_tokens) return;
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v0 += s_part[w][2u * pair][token], v1 += s_part[w][2u * pair + 1u][token];
+    // the pair's two virtual rows -> (matrix, row)
+    uint32_t mat[2], row[2];
+    bool live[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) live[i] = skinny_row<MODE>(p, blockIdx.x * 16u + 2u * pair + (uint32_t)i, mat[i], row[i]);
+    if constexpr (MODE == kGvPlain) {
+        if (live[0]) p.out[mat[0]][(size_t)token * a.out_stride[mat[0]] + row[0]] = (half_t)v0;
+        if (live[1]) p.out[mat[1]][(size_t)token * a.out_stride[mat[1]] + row[1]] = (half_t)v1;
+    } else if constexpr (MODE == kGvResidual) {
+        const size_t base = (size_t)token * a.out_stride[0];
+        if (live[0]) p.out[0][base + row[0]] = (half_t)((float)p.residual[base + row[0]] + v0);
+        if (live[1]) p.out[0][base + row[1]] = (half_t)((float)p.residual[base + row[1]] + v1);
+    } else if constexpr (MODE == kGvSiluMul) {
+        if (live[0]) p.out[0][(size_t)token * a.out_stride[0] + row[0]] = (half_t)(v0 / (1.0f + __expf(-v0)) * v1);
+    } else {  // kGvQkvRope: rows come in (d, d + D/2) pairs of one head of one matrix
+        if (!live[0]) return;
+        half_t* o = p.out[mat[0]] + (size_t)token * a.out_stride[mat[0]];
+        if (mat[0] < 2) {
+            const float pos = (float)(p.state[(size_t)token * a.state_stride].seq_len - 1);
+            const uint32_t d = row[0] % p.head_dim;
+            const float freq = p.rcp_scale * exp2f(p.log2_rcp_theta * (float)(2 * d) / (float)p.head_dim);
+            float sn, cs;
+            sincosf(pos * freq, &sn, &cs);
+            o[row[0]] = (half_t)(v0 * cs - v1 * sn);
+            o[row[1]] = (half_t)(v1 * cs + v0 * sn);
+        } else {
+            o[row[0]] = (half_t)v0;
+            o[row[1]] = (half_t)v1;
+        }
+    }
+}
+
+// 16 waves per workgroup (one per CU) when the launch has fewer than two 8-wave workgroups per CU (o_proj / down_proj of a
+// 4096-wide model: 256 blocks of 16 rows), 8 waves otherwise.  QUEST_SKINNY_CFG="NW,U" forces a built shape (tuning).
+// One 8-wave workgroup per CU (two waves per SIMD: 256 VGPRs each -- U x (4 + TG) fragments of 16 bytes in flight per lane
+// next to 16 TG accumulators; 128 KiB of weights in flight per CU at U = 4, the batch-1 kernel's figure.  16 waves at 128
+// VGPRs spilled from TG = 2 on).
+template <int MODE, int TG>
+static int launch_skinny_tg(const SkinnyArgs& a, uint32_t blocks, size_t lds, hipStream_t s) {
+    constexpr int U = TG <= 2 ? 4 : 2;
+    hipLaunchKernelGGL((skinny_kernel<MODE, 8, U, TG>), dim3(blocks), dim3(8 * kWave), lds, s, a);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+template <int MODE>
+static int launch_skinny(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_t s) {
+    const uint32_t blocks = (virtual_rows + 15u) / 16u;
+    const size_t lds = a.g.gamma ? (size_t)a.g.in_dim * sizeof(half_t) : 0;
+    if (lds > 48 * 1024) return QUEST_EUNSUPPORTED;  // in_dim <= 24576 with a RMSNorm prologue
+    if (a.n_tokens <= 4) return launch_skinny_tg<MODE, 1>(a, blocks, lds, s);
+    if (a.n_tokens <= 8) return launch_skinny_tg<MODE, 2>(a, blocks, lds, s);
+    return launch_skinny_tg<MODE, 4>(a, blocks, lds, s);
+}
+
 }  // namespace quest
 
 using namespace quest;
@@ -324,4 +567,61 @@ extern "C" int quest_decode_qkv_rope(const void* h, const void* gamma, float eps
     p.out[0] = (half_t*)q, p.out[1] = (half_t*)k, p.out[2] = (half_t*)v;
     p.head_dim = head_dim, p.rcp_scale = 1.0f / rope_scale, p.log2_rcp_theta = -log2f(rope_theta), p.state = state;
     return launch_gemv<kGvQkvRope>(p, p.rows[0] + p.rows[1] + p.rows[2], (hipStream_t)stream);
+}
+
+// ---- the same for n_tokens <= 16 decode tokens (x: [n_tokens][in_dim], outputs [n_tokens][out_dim], contiguous)
+extern "C" int quest_decode_norm_gemv_batched(const void* x, const void* gamma, float eps, const void* w, void* out,
+                                              uint32_t in_dim, uint32_t out_dim, uint32_t n_tokens, quest_stream_t stream) {
+    if (!x || !w || !out || in_dim == 0 || out_dim == 0) return QUEST_EINVAL;
+    SkinnyArgs a{};
+    GemvArgs& p = a.g;
+    p.x = (const half_t*)x, p.gamma = (const half_t*)gamma, p.eps = eps, p.in_dim = in_dim;
+    p.w[0] = (const half_t*)w, p.rows[0] = out_dim, p.out[0] = (half_t*)out;
+    a.n_tokens = n_tokens, a.x_stride = in_dim, a.out_stride[0] = out_dim;
+    return launch_skinny<kGvPlain>(a, out_dim, (hipStream_t)stream);
+}
+
+extern "C" int quest_decode_gemv_residual_batched(const void* x, const void* w, void* h, uint32_t in_dim, uint32_t out_dim,
+                                                  uint32_t n_tokens, quest_stream_t stream) {
+    if (!x || !w || !h || in_dim == 0 || out_dim == 0) return QUEST_EINVAL;
+    SkinnyArgs a{};
+    GemvArgs& p = a.g;
+    p.x = (const half_t*)x, p.in_dim = in_dim;
+    p.w[0] = (const half_t*)w, p.rows[0] = out_dim, p.out[0] = (half_t*)h, p.residual = (const half_t*)h;
+    a.n_tokens = n_tokens, a.x_stride = in_dim, a.out_stride[0] = out_dim;
+    return launch_skinny<kGvResidual>(a, out_dim, (hipStream_t)stream);
+}
+
+extern "C" int quest_decode_mlp_gate_up_batched(const void* h, const void* gamma, float eps, const void* w_gate,
+                                                const void* w_up, void* act, uint32_t hidden, uint32_t intermediate,
+                                                uint32_t n_tokens, quest_stream_t stream) {
+    if (!h || !gamma || !w_gate || !w_up || !act || hidden == 0 || intermediate == 0) return QUEST_EINVAL;
+    SkinnyArgs a{};
+    GemvArgs& p = a.g;
+    p.x = (const half_t*)h, p.gamma = (const half_t*)gamma, p.eps = eps, p.in_dim = hidden;
+    p.w[0] = (const half_t*)w_gate, p.w[1] = (const half_t*)w_up, p.rows[0] = p.rows[1] = intermediate;
+    p.out[0] = (half_t*)act;
+    a.n_tokens = n_tokens, a.x_stride = hidden, a.out_stride[0] = intermediate;
+    return launch_skinny<kGvSiluMul>(a, 2 * intermediate, (hipStream_t)stream);
+}
+
+extern "C" int quest_decode_qkv_rope_batched(const void* h, const void* gamma, float eps, const void* wq, const void* wk,
+                                             const void* wv, void* q, void* k, void* v, uint32_t hidden,
+                                             uint32_t num_qo_heads, uint32_t num_kv_heads, uint32_t head_dim,
+                                             float rope_scale, float rope_theta, const quest_step_state_t* states,
+                                             uint32_t n_tokens, quest_stream_t stream) {
+    if (!h || !gamma || !wq || !wk || !wv || !q || !k || !v || !states) return QUEST_EINVAL;
+    if (hidden == 0 || num_qo_heads == 0 || num_kv_heads == 0 || rope_scale == 0.f || rope_theta <= 0.f) return QUEST_EINVAL;
+    if (head_dim % 16 != 0) return QUEST_EUNSUPPORTED;  // a 16-row block = 8 rotation pairs of ONE head of ONE matrix
+    SkinnyArgs a{};
+    GemvArgs& p = a.g;
+    p.x = (const half_t*)h, p.gamma = (const half_t*)gamma, p.eps = eps, p.in_dim = hidden;
+    p.w[0] = (const half_t*)wq, p.w[1] = (const half_t*)wk, p.w[2] = (const half_t*)wv;
+    p.rows[0] = num_qo_heads * head_dim, p.rows[1] = p.rows[2] = num_kv_heads * head_dim;
+    p.out[0] = (half_t*)q, p.out[1] = (half_t*)k, p.out[2] = (half_t*)v;
+    p.head_dim = head_dim, p.rcp_scale = 1.0f / rope_scale, p.log2_rcp_theta = -log2f(rope_theta), p.state = states;
+    a.n_tokens = n_tokens, a.x_stride = hidden;
+    a.out_stride[0] = p.rows[0], a.out_stride[1] = p.rows[1], a.out_stride[2] = p.rows[2];
+    a.state_stride = 1;
+    return launch_skinny<kGvQkvRope>(a, p.rows[0] + p.rows[1] + p.rows[2], (hipStream_t)stream);
 }
