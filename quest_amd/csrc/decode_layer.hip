@@ -496,11 +496,9 @@ __global__ __launch_bounds__(NW* kWave, 2) void skinny_kernel(SkinnyArgs a) {  /
     }
 }
 
-// 16 waves per workgroup (one per CU) when the launch has fewer than two 8-wave workgroups per CU (o_proj / down_proj of a
-// 4096-wide model: 256 blocks of 16 rows), 8 waves otherwise.  QUEST_SKINNY_CFG="NW,U" forces a built shape (tuning).
 // One 8-wave workgroup per CU (two waves per SIMD: 256 VGPRs each -- U x (4 + TG) fragments of 16 bytes in flight per lane
-// next to 16 TG accumulators; 128 KiB of weights in flight per CU at U = 4, the batch-1 kernel's figure.  16 waves at 128
-// VGPRs spilled from TG = 2 on).
+// next to 16 TG accumulators; 128 KiB of weights in flight per CU at U = 4.  16 waves at 128 VGPRs spilled from TG = 2 on).
+// The fallback of the persistent kernel below: any n x in_dim, inputs from L2 (3.0-3.8 TB/s at 8 tokens).
 template <int MODE, int TG>
 static int launch_skinny_tg(const SkinnyArgs& a, uint32_t blocks, size_t lds, hipStream_t s) {
     constexpr int U = TG <= 2 ? 4 : 2;
@@ -516,6 +514,406 @@ static int launch_skinny(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_t
     if (a.n_tokens <= 4) return launch_skinny_tg<MODE, 1>(a, blocks, lds, s);
     if (a.n_tokens <= 8) return launch_skinny_tg<MODE, 2>(a, blocks, lds, s);
     return launch_skinny_tg<MODE, 4>(a, blocks, lds, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The n-token launches proper: ONE 16-wave workgroup per CU, resident for the whole launch, with the tokens' inputs --
+// normalised once -- in ITS LDS (8 tokens x 4096 x 2 bytes = 64 KiB of the CU's 160), so that the weight stream is the
+// only thing that crosses the memory system: the first n-token kernel above re-reads the inputs from L2 for every 16 rows
+// (0.5 bytes per weight byte, and a RMSNorm per fragment); the batch-1 kernel with 8 accumulators per row-dot spends the
+// vector ALUs (61 us against 32 for the gate/up launch).
+//
+//   task = one quad of weight rows (the B operand of the 4x4x4 MFMA: lane (b, j) = 16 bytes of row j at k chunk b, a
+//   fully coalesced 4 x 256-byte sweep) x one of `ks` interleaved k slices (k steps slice, slice + ks, ...: at most CM
+//   per task).  A wave holds TWO sets of CM fragments: it requests the next task's set, then consumes the current one
+//   against the A fragments (lane (b, i) = token i, chunk b) read from LDS -- row stride = 64 bytes mod 256, conflict-free
+//   for ds_read_b128's four 16-lane groups -- so a task's loads fly during the previous task's MFMAs, its k-chunk
+//   reduction (8 TG values by DPP), and the round's barrier.  The 16 waves of the workgroup = 16 / ks quads x ks slices;
+//   the slices of a quad meet in LDS (double-buffered, one barrier per round), (quad, row pair, token) threads run the
+//   batch-1 kernel's epilogues.  Rounds: quad = (round x workgroups + workgroup) x (16 / ks) + wave / ks.
+//
+//   Inputs too large for LDS (down_proj: 8 x 11008 x 2 = 172 KiB) are staged in `phases` k ranges (template PH), two LDS
+//   buffers, the accumulators living across the phases -- only with one round per launch (the host picks ks and phases
+//   accordingly): the next range's inputs are requested BEFORE the next weight set and stored after the current set's
+//   MFMAs, one barrier per phase.
+//
+//   Order of requests (in-kernel stamps, scripts/ps_timeline.py): a CU's memory pipeline takes about half of the
+//   workgroup's first 16 x 8 KiB of weight requests before the later waves' loads stall at issue for 4 us, and loads
+//   return in order -- inputs requested behind weights arrived after 5-8 us with the whole workgroup waiting at the
+//   staging barrier.  So: every wave requests its share of the inputs, a bare barrier makes that true for all 16 before
+//   any weight request, the inputs are normalised and stored (L2 latency), and only then do the weights start.
+#ifndef QUEST_PS_WAVES
+#define QUEST_PS_WAVES 16
+#endif
+constexpr int kPsWaves = QUEST_PS_WAVES, kCM = 4;  // kCM: k steps per task = fragments per set (two sets of 8 spill next to the inputs' registers)
+constexpr int kXV = 64 / kPsWaves;     // input vectors (16 bytes) per thread and staged range (4096 per workgroup)
+constexpr int kPsPerCu = 16 / kPsWaves; // workgroups per CU
+struct PersistPlan {
+    uint32_t ks, ks_log2;     // k slices per quad (power of two <= 16)
+    uint32_t rounds, phases;  // phases > 1 => rounds == 1
+    uint32_t spp;             // 128-wide k steps per phase
+    uint32_t x_row;           // halves between tokens in LDS (>= 128 spp, = 32 mod 128)
+    uint32_t x_buf;           // halves between the two input buffers (phases > 1)
+    uint32_t n_quads;
+    uint32_t vpp_magic;       // ceil(2^32 / (16 spp)): e / (16 spp) = umulhi(e, magic) for e < 2^16
+};
+
+template <int MODE, int TG, int CM, bool PH>
+__global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs a, PersistPlan pl) {
+    const GemvArgs& p = a.g;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
+    half_t* x_s = reinterpret_cast<half_t*>(ps_smem);  // [PH ? 2 : 1][4 TG][x_row] (normalised) inputs of a k range
+    __shared__ float s_inv[4 * TG];
+    __shared__ float s_part[2][kPsWaves][4][4 * TG];  // [buffer][wave = quad slot x slice][row of the quad][token]
+    // kGvQkvRope: (cos, sin) of every (token, frequency), computed once per workgroup while the first weights are on their
+    // way -- sincosf's large-argument path in the epilogue of every round held the epilogue wave, hence the whole
+    // workgroup at the next barrier, for ~0.8 us per round (qkv launch: 27.8 -> 23 us without the epilogues)
+    constexpr int kRopeMaxHalfD = 128;
+    __shared__ float2 s_rope[MODE == kGvQkvRope ? 4 * TG * kRopeMaxHalfD : 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef QUEST_PS_TIMELINE  // tuning build: s_memtime stamps of (workgroup 0 | last, wave 0 | 15) -> p.out[2] (16 x 4 x int64)
+    long long ps_t[16];
+    int ps_n = 0;
+#define PS_STAMP() do { if (ps_n < 16) ps_t[ps_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PS_STAMP() do {} while (0)
+#endif
+    PS_STAMP();
+    const uint32_t j = lane & 3u, blk = lane >> 2;
+    const uint32_t ks = pl.ks, slice = wave & (ks - 1u), qslot = wave >> pl.ks_log2, qw = kPsWaves >> pl.ks_log2;
+    const bool norm = !PH && p.gamma != nullptr;  // (a RMSNorm needs the whole row: the host plans one phase)
+    const uint32_t n_steps = (p.in_dim + 127u) / 128u;
+    // workgroup barrier that publishes LDS only: __syncthreads() also waits for the global loads in flight (vmcnt(0))
+    // whenever global stores are pending -- the epilogue's -- which would drain the prefetched set every round
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // segment = round (PH false) or phase (PH true)
+    const uint32_t n_seg = PH ? pl.phases : pl.rounds;
+    auto seg_quad = [&](uint32_t seg) { return ((PH ? 0u : seg) * gridDim.x + blockIdx.x) * qw + qslot; };
+    auto seg_step0 = [&](uint32_t seg) { return (PH ? seg : 0u) * pl.spp; };  // first k step of the segment's range
+    auto row_ptr = [&](uint32_t quad) -> const half_t* {
+        uint32_t m, rr;
+        const bool live = quad < pl.n_quads && skinny_row<MODE>(p, 4u * quad + j, m, rr);
+        return p.w[live ? m : 0] + (size_t)(live ? rr : 0u) * p.in_dim;  // dead rows read row 0 (never written out)
+    };
+    // Every call requests exactly CM fragments, whatever the task: steps past the slice's end and quads past the matrix
+    // re-read cached bytes.  (A load under a branch makes the compiler's s_waitcnt bookkeeping assume it may not have been
+    // issued: every later wait for an OLDER load became vmcnt(0) -- the consumption of a set waited for the set requested
+    // just before it, i.e. nothing was in flight under the MFMAs.  For the same reason the requests past the last segment
+    // are issued all the same -- one cached line -- instead of being guarded.)
+    half8 wa[CM], wb[CM];
+    auto issue = [&](half8 (&w)[CM], uint32_t seg) {
+        const bool real = seg < n_seg;  // block-uniform; past the end: CM requests of ONE cached line, nobody waits for them
+        const half_t* wrow = real ? row_ptr(seg_quad(seg)) : p.w[0];
+        const uint32_t s0 = seg_step0(seg), s1 = real ? min(s0 + pl.spp, n_steps) : 0u;
+#pragma unroll
+        for (int i = 0; i < CM; ++i) {
+            const uint32_t st = s0 + slice + ks * (uint32_t)i, k0 = st * 128u + blk * 8u;
+            w[i] = ld8_stream(wrow + (st < s1 && k0 < p.in_dim ? k0 : 0u));
+        }
+    };
+
+    // ---- inputs of the k range of a segment: element e = tid + 1024 i -> (token e / vpp, vector e % vpp), vpp = 16 spp
+    // vectors per token and range (the host guarantees tokens x vpp <= kXV x 1024); always kXV loads (clamped)
+    const uint32_t vpp = pl.spp * 16u, x_tot = a.n_tokens * vpp;
+    half8 xr[kXV];
+    auto x_load = [&](uint32_t seg) {
+        const uint32_t k_base = seg < n_seg ? seg_step0(seg) * 128u : p.in_dim;  // past the end: kXV requests of x[0]
+#pragma unroll
+        for (int i = 0; i < kXV; ++i) {
+            const uint32_t e = tid + (uint32_t)i * kPsWaves * kWave, t = __umulhi(e, pl.vpp_magic), k0 = k_base + (e - t * vpp) * kVec;
+            const bool in = e < x_tot && k0 < p.in_dim;
+            xr[i] = ld8(p.x + (in ? (size_t)t * a.x_stride + k0 : (size_t)0));
+        }
+    };
+    auto x_store = [&](uint32_t seg, half_t* dst) {  // zero for dead tokens and past the row's end
+        const uint32_t k_base = seg_step0(seg) * 128u;
+#pragma unroll
+        for (int i = 0; i < kXV; ++i) {
+            const uint32_t e = tid + (uint32_t)i * kPsWaves * kWave, t = __umulhi(e, pl.vpp_magic), v = e - t * vpp;
+            if (e >= 4u * TG * vpp) continue;
+            half8 o = xr[i];
+            const bool in = e < x_tot && k_base + v * kVec < p.in_dim;
+            if (norm && in) {
+                const float8 xf = to_f32(o), g = to_f32(ld8(p.gamma + k_base + v * kVec));
+                const float inv = s_inv[t];
+                float8 rr;
+#pragma unroll
+                for (int c = 0; c < kVec; ++c) rr[c] = xf[c] * inv * g[c];
+                o = __builtin_convertvector(rr, half8);
+            }
+            st8(dst + (size_t)t * pl.x_row + (size_t)v * kVec, in ? o : (half8)(half_t)0);
+        }
+    };
+
+    // ---- prologue: inputs first (see above)
+    x_load(0);
+    __builtin_amdgcn_s_barrier();
+    PS_STAMP();
+    if (norm) {  // 1 / rms per token: a thread's vector i lies in ONE token; per-token totals through LDS atomics
+        if (tid < 4u * TG) s_inv[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kXV; ++i) {
+            const uint32_t e = tid + (uint32_t)i * kPsWaves * kWave, t = __umulhi(e, pl.vpp_magic);
+            float ss = 0.f;
+            if (e < x_tot && (e - t * vpp) * kVec < p.in_dim) {  // (one phase: the range starts at k = 0)
+                const float8 xf = to_f32(xr[i]);
+#pragma unroll
+                for (int c = 0; c < kVec; ++c) ss = __builtin_fmaf(xf[c], xf[c], ss);
+            }
+            // lanes of a wave hold at most two tokens (vpp >= 64): reduce each side, one atomic per side
+            const uint32_t t0 = __builtin_amdgcn_readfirstlane(t);
+            const float s_lo = wave_allreduce_sum(t == t0 ? ss : 0.f, (int)lane), s_hi = wave_allreduce_sum(t == t0 ? 0.f : ss, (int)lane);
+            if (lane == 0 && t0 < 4u * TG) atomicAdd(&s_inv[t0], s_lo);
+            if (lane == 0 && t0 + 1u < 4u * TG) atomicAdd(&s_inv[t0 + 1u], s_hi);
+        }
+        __syncthreads();
+        if (tid < 4u * TG) s_inv[tid] = 1.0f / sqrtf(s_inv[tid] / (float)p.in_dim + p.eps);
+        __syncthreads();
+    }
+    x_store(0, x_s);
+    PS_STAMP();
+    lds_barrier();
+    issue(wa, 0);
+    PS_STAMP();
+    if constexpr (MODE == kGvQkvRope) {  // published by the first round's barrier
+        const uint32_t half_d = p.head_dim / 2u;
+        for (uint32_t e = tid; e < a.n_tokens * half_d; e += kPsWaves * kWave) {
+            const uint32_t t = e / half_d, d = e % half_d;
+            const float pos = (float)(p.state[(size_t)t * a.state_stride].seq_len - 1);
+            const float freq = p.rcp_scale * exp2f(p.log2_rcp_theta * (float)(2 * d) / (float)p.head_dim);
+            float sn, cs;
+            sincosf(pos * freq, &sn, &cs);
+            s_rope[t * kRopeMaxHalfD + d] = make_float2(cs, sn);
+        }
+    }
+
+    float4_t acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) acc[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](const half8 (&w)[CM], uint32_t seg) {
+        if (seg_quad(seg) >= pl.n_quads) return;  // wave-uniform
+        const uint32_t s0 = seg_step0(seg), s1 = min(s0 + pl.spp, n_steps);
+        const half_t* xb = x_s + (PH ? (size_t)(seg & 1u) * pl.x_buf : (size_t)0);
+#pragma unroll
+        for (int i = 0; i < CM; ++i) {
+            const uint32_t st = s0 + slice + ks * (uint32_t)i;
+            if (st < s1) {  // wave-uniform
+                const uint32_t kl = (st - s0) * 128u + blk * 8u;  // k inside the staged range
+                const half8 w8 = w[i];
+                const half4_t w0 = {w8[0], w8[1], w8[2], w8[3]}, w1 = {w8[4], w8[5], w8[6], w8[7]};
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const half8 x8 = ld8(xb + (size_t)(4u * (uint32_t)t + j) * pl.x_row + kl);
+                    const half4_t x0 = {x8[0], x8[1], x8[2], x8[3]}, x1 = {x8[4], x8[5], x8[6], x8[7]};
+                    acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(x0, w0, acc[t], 0, 0, 0);  // A = tokens, B = weight rows
+                    acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(x1, w1, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // the k slices of the quads meet; epilogue (end of a round / of the last phase)
+    auto finish = [&](uint32_t seg) {
+#ifdef QUEST_PS_NO_FINISH  // timing experiment (wrong results): no reduction, no barrier, no epilogue
+        return;
+#endif
+        const uint32_t buf = seg & 1u;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // D element e at lane (b, j) = token 4 t + e, row j of the quad; sum over b
+                float v = acc[t][e];
+                v += dpp_f<kDppRowRor + 8>(v);
+                v += dpp_f<kDppRowRor + 4>(v);
+                v += lane_xor<16>(v, (int)lane);
+                v += lane_xor<32>(v, (int)lane);
+                if (lane < 4u) s_part[buf][wave][lane][4 * t + e] = v;
+                acc[t][e] = 0.f;
+            }
+        lds_barrier();
+        // (quad slot, row pair, token) threads
+        const uint32_t token = tid & 15u, pair = (tid >> 4) & 1u, qs = tid >> 5;
+        if (qs >= qw || token >= a.n_tokens) return;
+        const uint32_t quad = ((PH ? 0u : seg) * gridDim.x + blockIdx.x) * qw + qs;
+        if (quad >= pl.n_quads) return;
+        float v0 = 0.f, v1 = 0.f;
+        for (uint32_t sl = 0; sl < ks; ++sl) {
+            v0 += s_part[buf][qs * ks + sl][2u * pair][token];
+            v1 += s_part[buf][qs * ks + sl][2u * pair + 1u][token];
+        }
+        uint32_t mat[2], row[2];
+        bool live[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) live[i] = skinny_row<MODE>(p, 4u * quad + 2u * pair + (uint32_t)i, mat[i], row[i]);
+        if constexpr (MODE == kGvPlain) {
+            if (live[0]) p.out[mat[0]][(size_t)token * a.out_stride[mat[0]] + row[0]] = (half_t)v0;
+            if (live[1]) p.out[mat[1]][(size_t)token * a.out_stride[mat[1]] + row[1]] = (half_t)v1;
+        } else if constexpr (MODE == kGvResidual) {
+            const size_t base = (size_t)token * a.out_stride[0];
+            if (live[0]) p.out[0][base + row[0]] = (half_t)((float)p.residual[base + row[0]] + v0);
+            if (live[1]) p.out[0][base + row[1]] = (half_t)((float)p.residual[base + row[1]] + v1);
+        } else if constexpr (MODE == kGvSiluMul) {
+            if (live[0]) p.out[0][(size_t)token * a.out_stride[0] + row[0]] = (half_t)(v0 / (1.0f + __expf(-v0)) * v1);
+        } else {  // kGvQkvRope: rows come in (d, d + D/2) pairs of one head of one matrix
+            if (!live[0]) return;
+            half_t* o = p.out[mat[0]] + (size_t)token * a.out_stride[mat[0]];
+            if (mat[0] < 2) {
+                const float2 r = s_rope[token * kRopeMaxHalfD + row[0] % p.head_dim];  // row[0] % head_dim < D / 2
+                const float cs = r.x, sn = r.y;
+                o[row[0]] = (half_t)(v0 * cs - v1 * sn);
+                o[row[1]] = (half_t)(v1 * cs + v0 * sn);
+            } else {
+                o[row[0]] = (half_t)v0;
+                o[row[1]] = (half_t)v1;
+            }
+        }
+    };
+    // Segment s: request segment s + 1 (inputs first, in phases), consume the set of s, let the slices meet.  A CU's memory
+    // pipeline holds ~64 KiB of requests; a wave whose requests do not fit stalls at issue.  Requested HERE, after the
+    // previous segment's barrier, a stalled wave holds nobody up; requested two segments ahead, right after the
+    // consumption and before the barrier, the stall sat in front of the barrier: 40.3 us instead of 36.8 for the gate/up
+    // launch (more in flight than the pipeline holds buys nothing).
+    auto body = [&](const half8 (&cur)[CM], half8 (&nxt)[CM], uint32_t sg) {
+        if constexpr (PH) x_load(sg + 1);
+        issue(nxt, sg + 1);
+        PS_STAMP();
+        consume(cur, sg);
+        PS_STAMP();
+        if constexpr (PH) {
+            // the other input buffer was last read in phase s - 1, which everybody left at that phase's barrier
+            if (sg + 1 < n_seg) x_store(sg + 1, x_s + (size_t)((sg + 1) & 1u) * pl.x_buf);
+            lds_barrier();
+        } else {
+            finish(sg);
+        }
+        PS_STAMP();
+    };
+    for (uint32_t seg = 0;; seg += 2) {  // wa holds segment seg; leaves by break (no merge with loads behind it)
+        body(wa, wb, seg);
+        if (seg + 1 >= n_seg) break;
+        body(wb, wa, seg + 1);
+        if (seg + 2 >= n_seg) break;
+    }
+    if constexpr (PH) finish(n_seg - 1);
+#ifdef QUEST_PS_NO_FINISH
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) keep += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+        if (keep == 1234.5f) p.out[0][0] = (half_t)1;
+    }
+#endif
+    PS_STAMP();
+#ifdef QUEST_PS_TIMELINE
+    if (lane == 0 && (wave == 0 || wave == kPsWaves - 1) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && p.out[2]) {
+        long long* o = reinterpret_cast<long long*>(p.out[2]) + ((blockIdx.x ? 2 : 0) + (wave ? 1 : 0)) * 16;
+        for (int i = 0; i < 16; ++i) o[i] = i < ps_n ? ps_t[i] : 0;
+    }
+#endif
+}
+
+// dynamic LDS a workgroup may ask for: the CU's 160 KiB less the kernel's static arrays (s_part 2 TG KiB, the rotation table
+// 4 TG KiB) and some slack
+static size_t persist_lds_budget(uint32_t tg, bool rope) { return (size_t)(158 - tg * (2 + (rope ? 4 : 0))) * 1024 / kPsPerCu; }
+
+template <int MODE, int TG, int CM, bool PH>
+static int launch_persist_k(const SkinnyArgs& a, const PersistPlan& pl, uint32_t grid, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {  // more than 64 KiB of dynamic LDS needs the opt-in
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_kernel<MODE, TG, CM, PH>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)persist_lds_budget(TG, MODE == kGvQkvRope));
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((persist_kernel<MODE, TG, CM, PH>), dim3(grid), dim3(kPsWaves * kWave), lds, s, a, pl);
+    QUEST_LAUNCH_CHECK();
+    return 0;
+}
+template <int MODE, int TG>
+static int launch_persist_tg(const SkinnyArgs& a, const PersistPlan& pl, uint32_t grid, size_t lds, hipStream_t s) {
+    if (pl.phases > 1) {
+        if constexpr (MODE == kGvPlain || MODE == kGvResidual) return launch_persist_k<MODE, TG, kCM, true>(a, pl, grid, lds, s);
+        else return QUEST_EUNSUPPORTED;  // (launches with a RMSNorm are planned with one phase)
+    }
+    return launch_persist_k<MODE, TG, kCM, false>(a, pl, grid, lds, s);
+}
+
+static int persist_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
+// Plan of the persistent kernel, or false when the shape does not fit it (then: launch_skinny).
+static bool plan_persist(const SkinnyArgs& a, uint32_t virtual_rows, uint32_t tg, bool norm_or_pairs_only_one_phase, bool rope,
+                         PersistPlan& pl, uint32_t& grid, size_t& lds) {
+    const uint32_t n_steps = (a.g.in_dim + 127u) / 128u, tokens = 4u * tg;
+    const size_t kLdsBudget = persist_lds_budget(tg, rope);
+    pl.n_quads = (virtual_rows + 3u) / 4u;
+    grid = (uint32_t)persist_cus() * kPsPerCu;
+    for (uint32_t phases = 1; phases <= 16; ++phases) {
+        if (phases > 1 && norm_or_pairs_only_one_phase) return false;
+        const uint32_t spp = (n_steps + phases - 1) / phases;
+        if ((spp * phases - n_steps) >= spp) continue;  // an empty last phase
+        const uint32_t x_row = spp * 128u + 32u;  // + 64 bytes: = 64 mod 256 bytes
+        const size_t buf = (size_t)tokens * x_row * sizeof(half_t), need = buf * (phases > 1 ? 2 : 1);
+        if (need > kLdsBudget) continue;
+        if ((size_t)tokens * spp * 16u > (size_t)kXV * kPsWaves * kWave) continue;  // inputs of a range: <= kXV vectors per thread
+        if (spp * 16u < (uint32_t)kWave) return false;  // (the 1 / rms reduction assumes <= 2 tokens per wave sweep)
+        uint32_t ks = 1, lg = 0;
+        while (ks < (uint32_t)kPsWaves && (spp + ks - 1) / ks > (uint32_t)kCM) ks *= 2, ++lg;
+        if ((spp + ks - 1) / ks > (uint32_t)kCM) continue;
+        // more slices per quad = fewer quads per workgroup and round = more, smaller rounds: take the split whose last
+        // round is fullest (gate/up of a 4096-wide model: 5.4 rounds of 1024 quads -> 10.75 of 512), as long as a task
+        // keeps >= 2 loads per lane
+        auto rounds_of = [&](uint32_t k) { return (pl.n_quads + grid * ((uint32_t)kPsWaves / k) - 1) / (grid * ((uint32_t)kPsWaves / k)); };
+        auto eff_of = [&](uint32_t k) { return (double)pl.n_quads / ((double)rounds_of(k) * grid * ((uint32_t)kPsWaves / k)); };
+        static const bool deep = [] { const char* e = getenv("QUEST_PERSIST_DEEP"); return e && e[0] == '1'; }();
+        if (!deep)
+            for (uint32_t k = ks * 2, l = lg + 1; k <= (uint32_t)kPsWaves && (spp + k - 1) / k >= 2; k *= 2, ++l)
+                if (eff_of(k) > eff_of(ks) + 0.04) ks = k, lg = l;
+        const uint32_t rounds = rounds_of(ks);
+        if (phases > 1 && rounds > 1) continue;  // the accumulators live across phases: one round only; try more phases
+        pl.ks = ks, pl.ks_log2 = lg, pl.rounds = rounds, pl.phases = phases, pl.spp = spp, pl.x_row = x_row;
+        pl.x_buf = (uint32_t)(buf / sizeof(half_t));
+        pl.vpp_magic = (uint32_t)(0xffffffffu / (spp * 16u)) + 1u;
+        constexpr size_t kFloor = (kPsPerCu == 1 ? 81 : 54) * 1024;  // LDS floor: exactly kPsPerCu workgroups per CU
+        lds = need > kFloor ? need : (kFloor < kLdsBudget ? kFloor : kLdsBudget);
+        return true;
+    }
+    return false;
+}
+
+// QUEST_BATCHED_GEMV=skinny forces the first kernel (tuning / tests).
+template <int MODE>
+static int launch_batched(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_t s) {
+    if (a.n_tokens == 0 || a.n_tokens > 16) return QUEST_EINVAL;
+    if (a.g.in_dim % 8 != 0) return QUEST_EUNSUPPORTED;
+    static const bool force_skinny = [] {
+        const char* e = getenv("QUEST_BATCHED_GEMV");
+        return e && e[0] == 's';
+    }();
+    const uint32_t tg = a.n_tokens <= 4 ? 1 : (a.n_tokens <= 8 ? 2 : 4);
+    PersistPlan pl{};
+    uint32_t grid = 0;
+    size_t lds = 0;
+    // several input phases (down_proj): measured SLOWER than the first kernel at Llama-2-7B shapes (32.8 vs 23.8 us), kept
+    // for tuning behind QUEST_PERSIST_PHASES=1
+    static const bool allow_phases = [] { const char* e = getenv("QUEST_PERSIST_PHASES"); return e && e[0] == '1'; }();
+    const bool one_phase = !allow_phases || a.g.gamma != nullptr || !(MODE == kGvPlain || MODE == kGvResidual);
+    if (MODE == kGvQkvRope && a.g.head_dim > 256) return launch_skinny<MODE>(a, virtual_rows, s);  // (the LDS rotation table)
+    if (!force_skinny && plan_persist(a, virtual_rows, tg, one_phase, MODE == kGvQkvRope, pl, grid, lds)) {
+        if (tg == 1) return launch_persist_tg<MODE, 1>(a, pl, grid, lds, s);
+        if (tg == 2) return launch_persist_tg<MODE, 2>(a, pl, grid, lds, s);
+        return launch_persist_tg<MODE, 4>(a, pl, grid, lds, s);
+    }
+    return launch_skinny<MODE>(a, virtual_rows, s);
 }
 
 }  // namespace quest
@@ -578,7 +976,7 @@ extern "C" int quest_decode_norm_gemv_batched(const void* x, const void* gamma, 
     p.x = (const half_t*)x, p.gamma = (const half_t*)gamma, p.eps = eps, p.in_dim = in_dim;
     p.w[0] = (const half_t*)w, p.rows[0] = out_dim, p.out[0] = (half_t*)out;
     a.n_tokens = n_tokens, a.x_stride = in_dim, a.out_stride[0] = out_dim;
-    return launch_skinny<kGvPlain>(a, out_dim, (hipStream_t)stream);
+    return launch_batched<kGvPlain>(a, out_dim, (hipStream_t)stream);
 }
 
 extern "C" int quest_decode_gemv_residual_batched(const void* x, const void* w, void* h, uint32_t in_dim, uint32_t out_dim,
@@ -589,7 +987,10 @@ extern "C" int quest_decode_gemv_residual_batched(const void* x, const void* w, 
     p.x = (const half_t*)x, p.in_dim = in_dim;
     p.w[0] = (const half_t*)w, p.rows[0] = out_dim, p.out[0] = (half_t*)h, p.residual = (const half_t*)h;
     a.n_tokens = n_tokens, a.x_stride = in_dim, a.out_stride[0] = out_dim;
-    return launch_skinny<kGvResidual>(a, out_dim, (hipStream_t)stream);
+#ifdef QUEST_PS_TIMELINE
+    if (const char* e = getenv("QUEST_PS_DEBUG_PTR")) p.out[2] = reinterpret_cast<half_t*>(strtoull(e, nullptr, 0));
+#endif
+    return launch_batched<kGvResidual>(a, out_dim, (hipStream_t)stream);
 }
 
 extern "C" int quest_decode_mlp_gate_up_batched(const void* h, const void* gamma, float eps, const void* w_gate,
@@ -602,7 +1003,7 @@ extern "C" int quest_decode_mlp_gate_up_batched(const void* h, const void* gamma
     p.w[0] = (const half_t*)w_gate, p.w[1] = (const half_t*)w_up, p.rows[0] = p.rows[1] = intermediate;
     p.out[0] = (half_t*)act;
     a.n_tokens = n_tokens, a.x_stride = hidden, a.out_stride[0] = intermediate;
-    return launch_skinny<kGvSiluMul>(a, 2 * intermediate, (hipStream_t)stream);
+    return launch_batched<kGvSiluMul>(a, 2 * intermediate, (hipStream_t)stream);
 }
 
 extern "C" int quest_decode_qkv_rope_batched(const void* h, const void* gamma, float eps, const void* wq, const void* wk,
@@ -623,5 +1024,5 @@ extern "C" int quest_decode_qkv_rope_batched(const void* h, const void* gamma, f
     a.n_tokens = n_tokens, a.x_stride = hidden;
     a.out_stride[0] = p.rows[0], a.out_stride[1] = p.rows[1], a.out_stride[2] = p.rows[2];
     a.state_stride = 1;
-    return launch_skinny<kGvQkvRope>(a, p.rows[0] + p.rows[1] + p.rows[2], (hipStream_t)stream);
+    return launch_batched<kGvQkvRope>(a, p.rows[0] + p.rows[1] + p.rows[2], (hipStream_t)stream);
 }
