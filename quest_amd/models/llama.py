@@ -136,16 +136,40 @@ class LlamaDecoderLayer(nn.Module):
         return h
 
 
-class DecodeWorkspace:
-    """Scratch of the fused decode layer (one set for the whole model: layers run one after the other)."""
+    def forward_batched_fused(self, h: torch.Tensor, bController, scores, dense: bool, ws: "DecodeWorkspace") -> torch.Tensor:
+        """``forward_batched`` with the same 4 fused launches per layer as ``forward_dyn_fused``, each for all ``n``
+        tokens at once (the weights are read once per batch: csrc/decode_layer.hip persist_kernel).  ``h`` ``[n, hidden]``
+        is the residual stream, updated IN PLACE; fp16, n <= 16."""
+        from .. import _kernels
 
-    def __init__(self, config: LlamaConfig, dtype, device):
+        a, m = self.self_attn, self.mlp
+        _kernels.decode_qkv_rope_batched(h, self.input_layernorm.weight, self.input_layernorm.variance_epsilon,
+                                         a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, ws.q, ws.k, ws.v, a.head_dim,
+                                         a.rope_scale, a.rope_theta, bController.step_states)
+        if dense:
+            attn = qutils.decode_layer_dense_batched(ws.q, ws.k, ws.v, bController, a.layer_idx, out=ws.attn)
+        else:
+            attn = qutils.decode_layer_batched(ws.q, ws.k, ws.v, bController, a.layer_idx, scores, out=ws.attn)
+        _kernels.decode_gemv_residual_batched(attn, a.o_proj.weight, h)
+        _kernels.decode_mlp_gate_up_batched(h, self.post_attention_layernorm.weight,
+                                            self.post_attention_layernorm.variance_epsilon, m.gate_proj.weight,
+                                            m.up_proj.weight, ws.act)
+        _kernels.decode_gemv_residual_batched(ws.act, m.down_proj.weight, h)
+        return h
+
+
+class DecodeWorkspace:
+    """Scratch of the fused decode layer (one set for the whole model: layers run one after the other); ``n`` tokens
+    (sequences of a batch) per step."""
+
+    def __init__(self, config: LlamaConfig, dtype, device, n: int = 1):
         d = config.hidden_size // config.num_attention_heads
-        self.q = torch.empty(1, config.num_attention_heads, d, dtype=dtype, device=device)
-        self.k = torch.empty(1, config.num_key_value_heads, d, dtype=dtype, device=device)
-        self.v = torch.empty(1, config.num_key_value_heads, d, dtype=dtype, device=device)
-        self.act = torch.empty(config.intermediate_size, dtype=dtype, device=device)
-        self.h = torch.empty(config.hidden_size, dtype=dtype, device=device)
+        self.q = torch.empty(n, config.num_attention_heads, d, dtype=dtype, device=device)
+        self.k = torch.empty(n, config.num_key_value_heads, d, dtype=dtype, device=device)
+        self.v = torch.empty(n, config.num_key_value_heads, d, dtype=dtype, device=device)
+        self.attn = torch.empty(n, config.num_attention_heads, d, dtype=dtype, device=device)
+        self.act = torch.empty((n, config.intermediate_size) if n > 1 else (config.intermediate_size,), dtype=dtype, device=device)
+        self.h = torch.empty((n, config.hidden_size) if n > 1 else (config.hidden_size,), dtype=dtype, device=device)
 
 
 class LlamaModel(nn.Module):
@@ -196,6 +220,16 @@ class LlamaModel(nn.Module):
         ws.h.copy_(h.reshape(-1))
         for idx, layer in enumerate(self.layers):
             layer.forward_dyn_fused(ws.h, ctl, scores, idx < self._quest_skip_layer, ws)
+        return ws.h
+
+    def forward_decode_batched_fused(self, h: torch.Tensor, scores: torch.Tensor, ws: DecodeWorkspace) -> torch.Tensor:
+        """``forward_decode_batched`` with the fused n-token decoder layers; returns the residual stream ``[n, hidden]``
+        BEFORE the final norm (fused into the caller's lm_head launch)."""
+        b = self.bController
+        qutils.step_advance_batched(b)
+        ws.h.copy_(h.reshape(ws.h.shape))
+        for idx, layer in enumerate(self.layers):
+            layer.forward_batched_fused(ws.h, b, scores, idx < self._quest_skip_layer, ws)
         return ws.h
 
     def forward_decode_batched(self, h: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
@@ -432,9 +466,10 @@ class LlamaForCausalLM(nn.Module):
         finally:
             m.iController = None
 
-    def capture_decode_graph_batched(self) -> None:
+    def capture_decode_graph_batched(self, fused_layers: Optional[bool] = None) -> None:
         """Batched ``capture_decode_graph``: input ``self.graph_input`` ``[n, 1, hidden]``, logits
-        ``self.graph_logits`` ``[n, 1, vocab]``."""
+        ``self.graph_logits`` ``[n, 1, vocab]``.  ``fused_layers`` as in ``capture_decode_graph`` (default on for fp16
+        models and n <= 16 unless ``QUEST_FUSED_LAYER=0``): 4 fused launches per layer for the whole batch."""
         m, b = self.model, self.model.bController
         dev = next(self.parameters()).device
         b.enable_device_state()
@@ -442,9 +477,25 @@ class LlamaForCausalLM(nn.Module):
         n = b.n_seqs
         self.graph_input = torch.zeros(n, 1, self.config.hidden_size, dtype=self.lm_head.weight.dtype, device=dev)
         self._graph_scores = qutils.score_scratch(b)
+        if fused_layers is None:
+            import os
 
-        def step():
-            return self.lm_head(m.forward_decode_batched(self.graph_input, self._graph_scores))
+            fused_layers = os.environ.get("QUEST_FUSED_LAYER", "1") != "0"
+        from .. import _kernels
+
+        fused_layers = fused_layers and self.lm_head.weight.dtype == torch.float16 and n <= _kernels.MAX_BATCHED_TOKENS
+        self.fused_layers = fused_layers
+        if fused_layers:
+            ws = self._graph_ws = DecodeWorkspace(self.config, torch.float16, dev, n)  # (kept: the graph holds its addresses)
+            logits = torch.empty(n, 1, self.config.vocab_size, dtype=torch.float16, device=dev)
+
+            def step():
+                hs = m.forward_decode_batched_fused(self.graph_input, self._graph_scores, ws)
+                _kernels.decode_norm_gemv_batched(hs, m.norm.weight, m.norm.variance_epsilon, self.lm_head.weight, logits)
+                return logits
+        else:
+            def step():
+                return self.lm_head(m.forward_decode_batched(self.graph_input, self._graph_scores))
 
         # warm-up folds a dummy key into every sequence's current metadata entry: snapshot / restore those
         # pages (see capture_decode_graph)
