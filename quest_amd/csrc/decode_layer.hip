@@ -546,7 +546,8 @@ static int launch_skinny(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_t
 #define QUEST_PS_WAVES 16
 #endif
 constexpr int kPsWaves = QUEST_PS_WAVES, kCM = 4;  // kCM: k steps per task = fragments per set (two sets of 8 spill next to the inputs' registers)
-constexpr int kXV = 64 / kPsWaves;     // input vectors (16 bytes) per thread and staged range (4096 per workgroup)
+// input vectors (16 bytes) per thread and staged range: 4096 per workgroup, 8192 for 9-16 tokens
+constexpr int ps_input_vectors(int tg) { return (tg <= 2 ? 64 : 128) / kPsWaves; }
 constexpr int kPsPerCu = 16 / kPsWaves; // workgroups per CU
 struct PersistPlan {
     uint32_t ks, ks_log2;     // k slices per quad (power of two <= 16)
@@ -561,6 +562,7 @@ struct PersistPlan {
 template <int MODE, int TG, int CM, bool PH>
 __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs a, PersistPlan pl) {
     const GemvArgs& p = a.g;
+    constexpr int kXV = ps_input_vectors(TG);
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
     half_t* x_s = reinterpret_cast<half_t*>(ps_smem);  // [PH ? 2 : 1][4 TG][x_row] (normalised) inputs of a k range
     __shared__ float s_inv[4 * TG];
@@ -858,13 +860,13 @@ static bool plan_persist(const SkinnyArgs& a, uint32_t virtual_rows, uint32_t tg
     pl.n_quads = (virtual_rows + 3u) / 4u;
     grid = (uint32_t)persist_cus() * kPsPerCu;
     for (uint32_t phases = 1; phases <= 16; ++phases) {
-        if (phases > 1 && norm_or_pairs_only_one_phase) return false;
+        if (phases > 1 && (norm_or_pairs_only_one_phase || tg > 2)) return false;  // (9-16 tokens in phases: the inputs' registers spill)
         const uint32_t spp = (n_steps + phases - 1) / phases;
         if ((spp * phases - n_steps) >= spp) continue;  // an empty last phase
         const uint32_t x_row = spp * 128u + 32u;  // + 64 bytes: = 64 mod 256 bytes
         const size_t buf = (size_t)tokens * x_row * sizeof(half_t), need = buf * (phases > 1 ? 2 : 1);
         if (need > kLdsBudget) continue;
-        if ((size_t)tokens * spp * 16u > (size_t)kXV * kPsWaves * kWave) continue;  // inputs of a range: <= kXV vectors per thread
+        if ((size_t)tokens * spp * 16u > (size_t)ps_input_vectors((int)tg) * kPsWaves * kWave) continue;  // inputs of a range: <= kXV vectors per thread
         if (spp * 16u < (uint32_t)kWave) return false;  // (the 1 / rms reduction assumes <= 2 tokens per wave sweep)
         uint32_t ks = 1, lg = 0;
         while (ks < (uint32_t)kPsWaves && (spp + ks - 1) / ks > (uint32_t)kCM) ks *= 2, ++lg;
