@@ -357,6 +357,17 @@ def test_round3_entry_points_validate_arguments_without_gpu():
     assert lib.quest_decode_mlp_gate_up(one, None, 1e-5, one, one, one, 64, 128, None) == -1  # the MLP launch needs gamma
     assert lib.quest_decode_qkv_rope(one, one, 1e-5, one, one, one, one, one, one, 512, 4, 4, 128, 1.0, 1e4, None, None) == -1
     assert lib.quest_decode_qkv_rope(one, one, 1e-5, one, one, one, one, one, one, 512, 4, 4, 128, 0.0, 1e4, one, None) == -1
+    # ... and their n-token forms: 1..16 tokens, same argument rules (checked before anything is launched)
+    assert lib.quest_decode_norm_gemv_batched(None, None, 0.0, one, one, 64, 8, 8, None) == -1
+    assert lib.quest_decode_norm_gemv_batched(one, None, 0.0, one, one, 64, 8, 0, None) == -1
+    assert lib.quest_decode_norm_gemv_batched(one, None, 0.0, one, one, 64, 8, 17, None) == -1
+    assert lib.quest_decode_norm_gemv_batched(one, None, 0.0, one, one, 60, 8, 8, None) == -2   # in_dim % 8
+    assert lib.quest_decode_gemv_residual_batched(one, one, None, 64, 8, 8, None) == -1
+    assert lib.quest_decode_mlp_gate_up_batched(one, None, 1e-5, one, one, one, 64, 128, 8, None) == -1
+    assert lib.quest_decode_qkv_rope_batched(one, one, 1e-5, one, one, one, one, one, one, 512, 4, 4, 128, 1.0, 1e4, None, 8,
+                                             None) == -1
+    assert lib.quest_decode_qkv_rope_batched(one, one, 1e-5, one, one, one, one, one, one, 512, 4, 4, 72, 1.0, 1e4, one, 8,
+                                             None) == -2   # head_dim % 16
     assert b"r3" in lib.quest_build_info()
 
 
