@@ -532,39 +532,33 @@ static int launch_skinny(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_t
 //   the slices of a quad meet in LDS (double-buffered, one barrier per round), (quad, row pair, token) threads run the
 //   batch-1 kernel's epilogues.  Rounds: quad = (round x workgroups + workgroup) x (16 / ks) + wave / ks.
 //
-//   Inputs too large for LDS (down_proj: 8 x 11008 x 2 = 172 KiB) are staged in `phases` k ranges (template PH), two LDS
-//   buffers, the accumulators living across the phases -- only with one round per launch (the host picks ks and phases
-//   accordingly): the next range's inputs are requested BEFORE the next weight set and stored after the current set's
-//   MFMAs, one barrier per phase.
+//   Inputs too large for LDS (down_proj: 8 x 11008 x 2 = 172 KiB) take the first kernel.  (Staging them in k ranges through
+//   two LDS buffers, the accumulators living across the ranges, was built and measured: 32.8 us against that kernel's
+//   23.7 at 8 tokens -- removed.)
 //
 //   Order of requests (in-kernel stamps, scripts/ps_timeline.py): a CU's memory pipeline takes about half of the
 //   workgroup's first 16 x 8 KiB of weight requests before the later waves' loads stall at issue for 4 us, and loads
 //   return in order -- inputs requested behind weights arrived after 5-8 us with the whole workgroup waiting at the
 //   staging barrier.  So: every wave requests its share of the inputs, a bare barrier makes that true for all 16 before
 //   any weight request, the inputs are normalised and stored (L2 latency), and only then do the weights start.
-#ifndef QUEST_PS_WAVES
-#define QUEST_PS_WAVES 16
-#endif
-constexpr int kPsWaves = QUEST_PS_WAVES, kCM = 4;  // kCM: k steps per task = fragments per set (two sets of 8 spill next to the inputs' registers)
+constexpr int kPsWaves = 16, kCM = 4;  // kCM: k steps per task = fragments per set (two sets of 8 spill next to the inputs' registers)
 // input vectors (16 bytes) per thread and staged range: 4096 per workgroup, 8192 for 9-16 tokens
 constexpr int ps_input_vectors(int tg) { return (tg <= 2 ? 64 : 128) / kPsWaves; }
-constexpr int kPsPerCu = 16 / kPsWaves; // workgroups per CU
 struct PersistPlan {
     uint32_t ks, ks_log2;     // k slices per quad (power of two <= 16)
-    uint32_t rounds, phases;  // phases > 1 => rounds == 1
-    uint32_t spp;             // 128-wide k steps per phase
+    uint32_t rounds;
+    uint32_t spp;             // 128-wide k steps of a row
     uint32_t x_row;           // halves between tokens in LDS (>= 128 spp, = 32 mod 128)
-    uint32_t x_buf;           // halves between the two input buffers (phases > 1)
     uint32_t n_quads;
     uint32_t vpp_magic;       // ceil(2^32 / (16 spp)): e / (16 spp) = umulhi(e, magic) for e < 2^16
 };
 
-template <int MODE, int TG, int CM, bool PH>
+template <int MODE, int TG, int CM>
 __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs a, PersistPlan pl) {
     const GemvArgs& p = a.g;
     constexpr int kXV = ps_input_vectors(TG);
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
-    half_t* x_s = reinterpret_cast<half_t*>(ps_smem);  // [PH ? 2 : 1][4 TG][x_row] (normalised) inputs of a k range
+    half_t* x_s = reinterpret_cast<half_t*>(ps_smem);  // [4 TG][x_row] (normalised) inputs
     __shared__ float s_inv[4 * TG];
     __shared__ float s_part[2][kPsWaves][4][4 * TG];  // [buffer][wave = quad slot x slice][row of the quad][token]
     // kGvQkvRope: (cos, sin) of every (token, frequency), computed once per workgroup while the first weights are on their
@@ -584,16 +578,16 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     PS_STAMP();
     const uint32_t j = lane & 3u, blk = lane >> 2;
     const uint32_t ks = pl.ks, slice = wave & (ks - 1u), qslot = wave >> pl.ks_log2, qw = kPsWaves >> pl.ks_log2;
-    const bool norm = !PH && p.gamma != nullptr;  // (a RMSNorm needs the whole row: the host plans one phase)
+    const bool norm = p.gamma != nullptr;
     const uint32_t n_steps = (p.in_dim + 127u) / 128u;
     // workgroup barrier that publishes LDS only: __syncthreads() also waits for the global loads in flight (vmcnt(0))
     // whenever global stores are pending -- the epilogue's -- which would drain the prefetched set every round
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // segment = round (PH false) or phase (PH true)
-    const uint32_t n_seg = PH ? pl.phases : pl.rounds;
-    auto seg_quad = [&](uint32_t seg) { return ((PH ? 0u : seg) * gridDim.x + blockIdx.x) * qw + qslot; };
-    auto seg_step0 = [&](uint32_t seg) { return (PH ? seg : 0u) * pl.spp; };  // first k step of the segment's range
+    // segment = round
+    const uint32_t n_seg = pl.rounds;
+    auto seg_quad = [&](uint32_t seg) { return (seg * gridDim.x + blockIdx.x) * qw + qslot; };
+    auto seg_step0 = [&](uint32_t) { return 0u; };  // first k step of a segment's range (one range: the whole row)
     auto row_ptr = [&](uint32_t quad) -> const half_t* {
         uint32_t m, rr;
         const bool live = quad < pl.n_quads && skinny_row<MODE>(p, 4u * quad + j, m, rr);
@@ -698,7 +692,7 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     auto consume = [&](const half8 (&w)[CM], uint32_t seg) {
         if (seg_quad(seg) >= pl.n_quads) return;  // wave-uniform
         const uint32_t s0 = seg_step0(seg), s1 = min(s0 + pl.spp, n_steps);
-        const half_t* xb = x_s + (PH ? (size_t)(seg & 1u) * pl.x_buf : (size_t)0);
+        const half_t* xb = x_s;
 #pragma unroll
         for (int i = 0; i < CM; ++i) {
             const uint32_t st = s0 + slice + ks * (uint32_t)i;
@@ -718,9 +712,6 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     };
     // the k slices of the quads meet; epilogue (end of a round / of the last phase)
     auto finish = [&](uint32_t seg) {
-#ifdef QUEST_PS_NO_FINISH  // timing experiment (wrong results): no reduction, no barrier, no epilogue
-        return;
-#endif
         const uint32_t buf = seg & 1u;
 #pragma unroll
         for (int t = 0; t < TG; ++t)
@@ -738,7 +729,7 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
         // (quad slot, row pair, token) threads
         const uint32_t token = tid & 15u, pair = (tid >> 4) & 1u, qs = tid >> 5;
         if (qs >= qw || token >= a.n_tokens) return;
-        const uint32_t quad = ((PH ? 0u : seg) * gridDim.x + blockIdx.x) * qw + qs;
+        const uint32_t quad = (seg * gridDim.x + blockIdx.x) * qw + qs;
         if (quad >= pl.n_quads) return;
         float v0 = 0.f, v1 = 0.f;
         for (uint32_t sl = 0; sl < ks; ++sl) {
@@ -772,24 +763,17 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
             }
         }
     };
-    // Segment s: request segment s + 1 (inputs first, in phases), consume the set of s, let the slices meet.  A CU's memory
+    // Segment s: request segment s + 1, consume the set of s, let the slices meet.  A CU's memory
     // pipeline holds ~64 KiB of requests; a wave whose requests do not fit stalls at issue.  Requested HERE, after the
     // previous segment's barrier, a stalled wave holds nobody up; requested two segments ahead, right after the
     // consumption and before the barrier, the stall sat in front of the barrier: 40.3 us instead of 36.8 for the gate/up
     // launch (more in flight than the pipeline holds buys nothing).
     auto body = [&](const half8 (&cur)[CM], half8 (&nxt)[CM], uint32_t sg) {
-        if constexpr (PH) x_load(sg + 1);
         issue(nxt, sg + 1);
         PS_STAMP();
         consume(cur, sg);
         PS_STAMP();
-        if constexpr (PH) {
-            // the other input buffer was last read in phase s - 1, which everybody left at that phase's barrier
-            if (sg + 1 < n_seg) x_store(sg + 1, x_s + (size_t)((sg + 1) & 1u) * pl.x_buf);
-            lds_barrier();
-        } else {
-            finish(sg);
-        }
+        finish(sg);
         PS_STAMP();
     };
     for (uint32_t seg = 0;; seg += 2) {  // wa holds segment seg; leaves by break (no merge with loads behind it)
@@ -798,15 +782,6 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
         body(wb, wa, seg + 1);
         if (seg + 2 >= n_seg) break;
     }
-    if constexpr (PH) finish(n_seg - 1);
-#ifdef QUEST_PS_NO_FINISH
-    {
-        float keep = 0.f;
-#pragma unroll
-        for (int t = 0; t < TG; ++t) keep += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-        if (keep == 1234.5f) p.out[0][0] = (half_t)1;
-    }
-#endif
     PS_STAMP();
 #ifdef QUEST_PS_TIMELINE
     if (lane == 0 && (wave == 0 || wave == kPsWaves - 1) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && p.out[2]) {
@@ -818,29 +793,21 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
 
 // dynamic LDS a workgroup may ask for: the CU's 160 KiB less the kernel's static arrays (s_part 2 TG KiB, the rotation table
 // 4 TG KiB) and some slack
-static size_t persist_lds_budget(uint32_t tg, bool rope) { return (size_t)(158 - tg * (2 + (rope ? 4 : 0))) * 1024 / kPsPerCu; }
+static size_t persist_lds_budget(uint32_t tg, bool rope) { return (size_t)(158 - tg * (2 + (rope ? 4 : 0))) * 1024; }
 
-template <int MODE, int TG, int CM, bool PH>
-static int launch_persist_k(const SkinnyArgs& a, const PersistPlan& pl, uint32_t grid, size_t lds, hipStream_t s) {
+template <int MODE, int TG>
+static int launch_persist_tg(const SkinnyArgs& a, const PersistPlan& pl, uint32_t grid, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {  // more than 64 KiB of dynamic LDS needs the opt-in
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_kernel<MODE, TG, CM, PH>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_kernel<MODE, TG, kCM>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)persist_lds_budget(TG, MODE == kGvQkvRope));
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL((persist_kernel<MODE, TG, CM, PH>), dim3(grid), dim3(kPsWaves * kWave), lds, s, a, pl);
+    hipLaunchKernelGGL((persist_kernel<MODE, TG, kCM>), dim3(grid), dim3(kPsWaves * kWave), lds, s, a, pl);
     QUEST_LAUNCH_CHECK();
     return 0;
-}
-template <int MODE, int TG>
-static int launch_persist_tg(const SkinnyArgs& a, const PersistPlan& pl, uint32_t grid, size_t lds, hipStream_t s) {
-    if (pl.phases > 1) {
-        if constexpr (MODE == kGvPlain || MODE == kGvResidual) return launch_persist_k<MODE, TG, kCM, true>(a, pl, grid, lds, s);
-        else return QUEST_EUNSUPPORTED;  // (launches with a RMSNorm are planned with one phase)
-    }
-    return launch_persist_k<MODE, TG, kCM, false>(a, pl, grid, lds, s);
 }
 
 static int persist_cus() {
@@ -853,43 +820,31 @@ static int persist_cus() {
 }
 
 // Plan of the persistent kernel, or false when the shape does not fit it (then: launch_skinny).
-static bool plan_persist(const SkinnyArgs& a, uint32_t virtual_rows, uint32_t tg, bool norm_or_pairs_only_one_phase, bool rope,
-                         PersistPlan& pl, uint32_t& grid, size_t& lds) {
-    const uint32_t n_steps = (a.g.in_dim + 127u) / 128u, tokens = 4u * tg;
-    const size_t kLdsBudget = persist_lds_budget(tg, rope);
+static bool plan_persist(const SkinnyArgs& a, uint32_t virtual_rows, uint32_t tg, bool rope, PersistPlan& pl, uint32_t& grid,
+                         size_t& lds) {
+    const uint32_t spp = (a.g.in_dim + 127u) / 128u, tokens = 4u * tg;  // 128-wide k steps of a row
+    const size_t budget = persist_lds_budget(tg, rope);
     pl.n_quads = (virtual_rows + 3u) / 4u;
-    grid = (uint32_t)persist_cus() * kPsPerCu;
-    for (uint32_t phases = 1; phases <= 16; ++phases) {
-        if (phases > 1 && (norm_or_pairs_only_one_phase || tg > 2)) return false;  // (9-16 tokens in phases: the inputs' registers spill)
-        const uint32_t spp = (n_steps + phases - 1) / phases;
-        if ((spp * phases - n_steps) >= spp) continue;  // an empty last phase
-        const uint32_t x_row = spp * 128u + 32u;  // + 64 bytes: = 64 mod 256 bytes
-        const size_t buf = (size_t)tokens * x_row * sizeof(half_t), need = buf * (phases > 1 ? 2 : 1);
-        if (need > kLdsBudget) continue;
-        if ((size_t)tokens * spp * 16u > (size_t)ps_input_vectors((int)tg) * kPsWaves * kWave) continue;  // inputs of a range: <= kXV vectors per thread
-        if (spp * 16u < (uint32_t)kWave) return false;  // (the 1 / rms reduction assumes <= 2 tokens per wave sweep)
-        uint32_t ks = 1, lg = 0;
-        while (ks < (uint32_t)kPsWaves && (spp + ks - 1) / ks > (uint32_t)kCM) ks *= 2, ++lg;
-        if ((spp + ks - 1) / ks > (uint32_t)kCM) continue;
-        // more slices per quad = fewer quads per workgroup and round = more, smaller rounds: take the split whose last
-        // round is fullest (gate/up of a 4096-wide model: 5.4 rounds of 1024 quads -> 10.75 of 512), as long as a task
-        // keeps >= 2 loads per lane
-        auto rounds_of = [&](uint32_t k) { return (pl.n_quads + grid * ((uint32_t)kPsWaves / k) - 1) / (grid * ((uint32_t)kPsWaves / k)); };
-        auto eff_of = [&](uint32_t k) { return (double)pl.n_quads / ((double)rounds_of(k) * grid * ((uint32_t)kPsWaves / k)); };
-        static const bool deep = [] { const char* e = getenv("QUEST_PERSIST_DEEP"); return e && e[0] == '1'; }();
-        if (!deep)
-            for (uint32_t k = ks * 2, l = lg + 1; k <= (uint32_t)kPsWaves && (spp + k - 1) / k >= 2; k *= 2, ++l)
-                if (eff_of(k) > eff_of(ks) + 0.04) ks = k, lg = l;
-        const uint32_t rounds = rounds_of(ks);
-        if (phases > 1 && rounds > 1) continue;  // the accumulators live across phases: one round only; try more phases
-        pl.ks = ks, pl.ks_log2 = lg, pl.rounds = rounds, pl.phases = phases, pl.spp = spp, pl.x_row = x_row;
-        pl.x_buf = (uint32_t)(buf / sizeof(half_t));
-        pl.vpp_magic = (uint32_t)(0xffffffffu / (spp * 16u)) + 1u;
-        constexpr size_t kFloor = (kPsPerCu == 1 ? 81 : 54) * 1024;  // LDS floor: exactly kPsPerCu workgroups per CU
-        lds = need > kFloor ? need : (kFloor < kLdsBudget ? kFloor : kLdsBudget);
-        return true;
-    }
-    return false;
+    grid = (uint32_t)persist_cus();
+    const uint32_t x_row = spp * 128u + 32u;  // + 64 bytes: = 64 mod 256 bytes
+    const size_t need = (size_t)tokens * x_row * sizeof(half_t);
+    if (need > budget) return false;  // the inputs do not fit LDS (down_proj at 8 tokens)
+    if ((size_t)tokens * spp * 16u > (size_t)ps_input_vectors((int)tg) * kPsWaves * kWave) return false;  // <= kXV vectors per thread
+    if (spp * 16u < (uint32_t)kWave) return false;  // (the 1 / rms reduction assumes <= 2 tokens per wave sweep)
+    uint32_t ks = 1, lg = 0;
+    while (ks < (uint32_t)kPsWaves && (spp + ks - 1) / ks > (uint32_t)kCM) ks *= 2, ++lg;
+    if ((spp + ks - 1) / ks > (uint32_t)kCM) return false;  // rows longer than 16 slices x 4 steps x 128
+    // more slices per quad = fewer quads per workgroup and round = more, smaller rounds: take the split whose last round
+    // is fullest, as long as a task keeps >= 2 loads per lane
+    auto rounds_of = [&](uint32_t k) { return (pl.n_quads + grid * ((uint32_t)kPsWaves / k) - 1) / (grid * ((uint32_t)kPsWaves / k)); };
+    auto eff_of = [&](uint32_t k) { return (double)pl.n_quads / ((double)rounds_of(k) * grid * ((uint32_t)kPsWaves / k)); };
+    for (uint32_t k = ks * 2, l = lg + 1; k <= (uint32_t)kPsWaves && (spp + k - 1) / k >= 2; k *= 2, ++l)
+        if (eff_of(k) > eff_of(ks) + 0.04) ks = k, lg = l;
+    pl.ks = ks, pl.ks_log2 = lg, pl.rounds = rounds_of(ks), pl.spp = spp, pl.x_row = x_row;
+    pl.vpp_magic = (uint32_t)(0xffffffffu / (spp * 16u)) + 1u;
+    constexpr size_t kFloor = 81 * 1024;  // more than half of the CU's LDS: exactly one workgroup per CU
+    lds = need > kFloor ? need : kFloor;
+    return true;
 }
 
 // QUEST_BATCHED_GEMV=skinny forces the first kernel (tuning / tests).
@@ -905,12 +860,8 @@ static int launch_batched(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_
     PersistPlan pl{};
     uint32_t grid = 0;
     size_t lds = 0;
-    // several input phases (down_proj): measured SLOWER than the first kernel at Llama-2-7B shapes (32.8 vs 23.8 us), kept
-    // for tuning behind QUEST_PERSIST_PHASES=1
-    static const bool allow_phases = [] { const char* e = getenv("QUEST_PERSIST_PHASES"); return e && e[0] == '1'; }();
-    const bool one_phase = !allow_phases || a.g.gamma != nullptr || !(MODE == kGvPlain || MODE == kGvResidual);
     if (MODE == kGvQkvRope && a.g.head_dim > 256) return launch_skinny<MODE>(a, virtual_rows, s);  // (the LDS rotation table)
-    if (!force_skinny && plan_persist(a, virtual_rows, tg, one_phase, MODE == kGvQkvRope, pl, grid, lds)) {
+    if (!force_skinny && plan_persist(a, virtual_rows, tg, MODE == kGvQkvRope, pl, grid, lds)) {
         if (tg == 1) return launch_persist_tg<MODE, 1>(a, pl, grid, lds, s);
         if (tg == 2) return launch_persist_tg<MODE, 2>(a, pl, grid, lds, s);
         return launch_persist_tg<MODE, 4>(a, pl, grid, lds, s);
