@@ -536,11 +536,11 @@ static int launch_skinny(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_t
 //   two LDS buffers, the accumulators living across the ranges, was built and measured: 32.8 us against that kernel's
 //   23.7 at 8 tokens -- removed.)
 //
-//   Order of requests (in-kernel stamps, scripts/ps_timeline.py): a CU's memory pipeline takes about half of the
-//   workgroup's first 16 x 8 KiB of weight requests before the later waves' loads stall at issue for 4 us, and loads
-//   return in order -- inputs requested behind weights arrived after 5-8 us with the whole workgroup waiting at the
-//   staging barrier.  So: every wave requests its share of the inputs, a bare barrier makes that true for all 16 before
-//   any weight request, the inputs are normalised and stored (L2 latency), and only then do the weights start.
+//   Order of requests (in-kernel stamps, scripts/ps_timeline.py): a CU's memory pipeline holds about 64 KiB of requests;
+//   a wave whose loads do not fit stalls at issue (up to 4 us at the start of a launch), and a wave's loads return in
+//   order.  The prologue requests the inputs first (every wave its share, a bare barrier so that all 16 have, before
+//   anybody's weights), normalises and stores them, and then starts the weights; with the first weight set requested
+//   ahead of the inputs the launch takes the same time (37.3 vs 37.1 us).
 constexpr int kPsWaves = 16, kCM = 4;  // kCM: k steps per task = fragments per set (two sets of 8 spill next to the inputs' registers)
 // input vectors (16 bytes) per thread and staged range: 4096 per workgroup, 8192 for 9-16 tokens
 constexpr int ps_input_vectors(int tg) { return (tg <= 2 ? 64 : 128) / kPsWaves; }
@@ -562,8 +562,7 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     __shared__ float s_inv[4 * TG];
     __shared__ float s_part[2][kPsWaves][4][4 * TG];  // [buffer][wave = quad slot x slice][row of the quad][token]
     // kGvQkvRope: (cos, sin) of every (token, frequency), computed once per workgroup while the first weights are on their
-    // way -- sincosf's large-argument path in the epilogue of every round held the epilogue wave, hence the whole
-    // workgroup at the next barrier, for ~0.8 us per round (qkv launch: 27.8 -> 23 us without the epilogues)
+    // way; a round's epilogue reads it (no sincosf, with its large-argument path, per round)
     constexpr int kRopeMaxHalfD = 128;
     __shared__ float2 s_rope[MODE == kGvQkvRope ? 4 * TG * kRopeMaxHalfD : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -584,10 +583,8 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     // whenever global stores are pending -- the epilogue's -- which would drain the prefetched set every round
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // segment = round
-    const uint32_t n_seg = pl.rounds;
+    const uint32_t n_seg = pl.rounds;  // a segment = one round of tasks
     auto seg_quad = [&](uint32_t seg) { return (seg * gridDim.x + blockIdx.x) * qw + qslot; };
-    auto seg_step0 = [&](uint32_t) { return 0u; };  // first k step of a segment's range (one range: the whole row)
     auto row_ptr = [&](uint32_t quad) -> const half_t* {
         uint32_t m, rr;
         const bool live = quad < pl.n_quads && skinny_row<MODE>(p, 4u * quad + j, m, rr);
@@ -602,37 +599,35 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     auto issue = [&](half8 (&w)[CM], uint32_t seg) {
         const bool real = seg < n_seg;  // block-uniform; past the end: CM requests of ONE cached line, nobody waits for them
         const half_t* wrow = real ? row_ptr(seg_quad(seg)) : p.w[0];
-        const uint32_t s0 = seg_step0(seg), s1 = real ? min(s0 + pl.spp, n_steps) : 0u;
+        const uint32_t s1 = real ? n_steps : 0u;
 #pragma unroll
         for (int i = 0; i < CM; ++i) {
-            const uint32_t st = s0 + slice + ks * (uint32_t)i, k0 = st * 128u + blk * 8u;
+            const uint32_t st = slice + ks * (uint32_t)i, k0 = st * 128u + blk * 8u;
             w[i] = ld8_stream(wrow + (st < s1 && k0 < p.in_dim ? k0 : 0u));
         }
     };
 
-    // ---- inputs of the k range of a segment: element e = tid + 1024 i -> (token e / vpp, vector e % vpp), vpp = 16 spp
-    // vectors per token and range (the host guarantees tokens x vpp <= kXV x 1024); always kXV loads (clamped)
+    // ---- the inputs: element e = tid + 1024 i -> (token e / vpp, vector e % vpp), vpp = 16 spp vectors per token (the
+    // host guarantees tokens x vpp <= kXV x 1024); always kXV loads (clamped)
     const uint32_t vpp = pl.spp * 16u, x_tot = a.n_tokens * vpp;
     half8 xr[kXV];
-    auto x_load = [&](uint32_t seg) {
-        const uint32_t k_base = seg < n_seg ? seg_step0(seg) * 128u : p.in_dim;  // past the end: kXV requests of x[0]
+    auto x_load = [&] {
 #pragma unroll
         for (int i = 0; i < kXV; ++i) {
-            const uint32_t e = tid + (uint32_t)i * kPsWaves * kWave, t = __umulhi(e, pl.vpp_magic), k0 = k_base + (e - t * vpp) * kVec;
+            const uint32_t e = tid + (uint32_t)i * kPsWaves * kWave, t = __umulhi(e, pl.vpp_magic), k0 = (e - t * vpp) * kVec;
             const bool in = e < x_tot && k0 < p.in_dim;
             xr[i] = ld8(p.x + (in ? (size_t)t * a.x_stride + k0 : (size_t)0));
         }
     };
-    auto x_store = [&](uint32_t seg, half_t* dst) {  // zero for dead tokens and past the row's end
-        const uint32_t k_base = seg_step0(seg) * 128u;
+    auto x_store = [&](half_t* dst) {  // zero for dead tokens and past the row's end
 #pragma unroll
         for (int i = 0; i < kXV; ++i) {
             const uint32_t e = tid + (uint32_t)i * kPsWaves * kWave, t = __umulhi(e, pl.vpp_magic), v = e - t * vpp;
             if (e >= 4u * TG * vpp) continue;
             half8 o = xr[i];
-            const bool in = e < x_tot && k_base + v * kVec < p.in_dim;
+            const bool in = e < x_tot && v * kVec < p.in_dim;
             if (norm && in) {
-                const float8 xf = to_f32(o), g = to_f32(ld8(p.gamma + k_base + v * kVec));
+                const float8 xf = to_f32(o), g = to_f32(ld8(p.gamma + v * kVec));
                 const float inv = s_inv[t];
                 float8 rr;
 #pragma unroll
@@ -644,7 +639,7 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     };
 
     // ---- prologue: inputs first (see above)
-    x_load(0);
+    x_load();
     __builtin_amdgcn_s_barrier();
     PS_STAMP();
     if (norm) {  // 1 / rms per token: a thread's vector i lies in ONE token; per-token totals through LDS atomics
@@ -654,7 +649,7 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
         for (int i = 0; i < kXV; ++i) {
             const uint32_t e = tid + (uint32_t)i * kPsWaves * kWave, t = __umulhi(e, pl.vpp_magic);
             float ss = 0.f;
-            if (e < x_tot && (e - t * vpp) * kVec < p.in_dim) {  // (one phase: the range starts at k = 0)
+            if (e < x_tot && (e - t * vpp) * kVec < p.in_dim) {
                 const float8 xf = to_f32(xr[i]);
 #pragma unroll
                 for (int c = 0; c < kVec; ++c) ss = __builtin_fmaf(xf[c], xf[c], ss);
@@ -669,7 +664,7 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
         if (tid < 4u * TG) s_inv[tid] = 1.0f / sqrtf(s_inv[tid] / (float)p.in_dim + p.eps);
         __syncthreads();
     }
-    x_store(0, x_s);
+    x_store(x_s);
     PS_STAMP();
     lds_barrier();
     issue(wa, 0);
@@ -691,13 +686,12 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     for (int t = 0; t < TG; ++t) acc[t] = float4_t{0.f, 0.f, 0.f, 0.f};
     auto consume = [&](const half8 (&w)[CM], uint32_t seg) {
         if (seg_quad(seg) >= pl.n_quads) return;  // wave-uniform
-        const uint32_t s0 = seg_step0(seg), s1 = min(s0 + pl.spp, n_steps);
         const half_t* xb = x_s;
 #pragma unroll
         for (int i = 0; i < CM; ++i) {
-            const uint32_t st = s0 + slice + ks * (uint32_t)i;
-            if (st < s1) {  // wave-uniform
-                const uint32_t kl = (st - s0) * 128u + blk * 8u;  // k inside the staged range
+            const uint32_t st = slice + ks * (uint32_t)i;
+            if (st < n_steps) {  // wave-uniform
+                const uint32_t kl = st * 128u + blk * 8u;
                 const half8 w8 = w[i];
                 const half4_t w0 = {w8[0], w8[1], w8[2], w8[3]}, w1 = {w8[4], w8[5], w8[6], w8[7]};
 #pragma unroll
@@ -710,7 +704,7 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
             }
         }
     };
-    // the k slices of the quads meet; epilogue (end of a round / of the last phase)
+    // the k slices of the quads meet; epilogue
     auto finish = [&](uint32_t seg) {
         const uint32_t buf = seg & 1u;
 #pragma unroll
