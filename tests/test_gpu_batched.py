@@ -234,8 +234,9 @@ def test_batched_argument_errors():
         b._decode_handler.set_batch(0)
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_model_batched_generation_matches_single_sequence(fused):
+@pytest.mark.parametrize("fused,lens", [(False, (300, 215, 330)), (True, (300, 215, 330)),
+                                        (True, (300, 215, 330, 180, 257, 199, 310, 222, 176))])  # 9 sequences: 3 token groups
+def test_model_batched_generation_matches_single_sequence(fused, lens):
     """A Llama-architecture model (2 dense layers + sparse layers, GQA) decoding three prompts of different
     lengths together -- one hipGraph replay per token for the whole batch -- against the same model decoding
     each prompt alone (teacher-forced with the single-sequence greedy tokens).  fused: the decoder layers' projections
@@ -246,9 +247,8 @@ def test_model_batched_generation_matches_single_sequence(fused):
     dev = torch.device("cuda:0")
     cfg = LlamaConfig(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
                       num_attention_heads=4, num_key_value_heads=2)
-    lens = (300, 215, 330)
     prompts = [((torch.arange(L, device=dev)[None] * (5 + 2 * i)) + i) % 256 for i, L in enumerate(lens)]
-    n_new = 24
+    n_new = 24 if len(lens) <= 3 else 10
 
     def build():
         torch.manual_seed(11)
