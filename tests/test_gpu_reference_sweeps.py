@@ -143,3 +143,31 @@ def test_chain_at_odd_page_sizes(page_size, L, B, Hq, Hkv, D, layout):
     assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
     assert torch.equal(o, o2)
     ctl.end_forward()
+
+
+@pytest.mark.parametrize("kv_len", [33, 66, 129, 400, 700, 1110])
+def test_prefill_attention_reference_sweep(kv_len):
+    """quest/tests/test_prefill_attention.py:44-88: qo_len x kv_len of the reference's own sweep (H = 32, D = 128, page 16;
+    the last qo_len rows of a kv_len cache, bottom-right causal) against its _ref_self_attention restated in fp32, at its
+    tolerance.  qo_len == kv_len goes through SDPA's flash backend, qo_len < kv_len through the masked memory-efficient one."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    H, D = 32, 128
+    g = torch.Generator(device=dev).manual_seed(kv_len)
+    k = torch.randn(kv_len, H, D, generator=g, device=dev, dtype=torch.float16)
+    v = torch.randn(kv_len, H, D, generator=g, device=dev, dtype=torch.float16)
+    ctl = make_controller(kv_len, H, H, D, 16, 1024, shuffle_seed=kv_len)
+    ctl.prepare_metadata(kv_len)
+    ctl.begin_forward(kv_len)
+    qu.append_kv(k, v, ctl, 0)
+    for qo_len in (13, 24, 51, 77, 244, 311, 502, kv_len):
+        if qo_len > kv_len:
+            continue
+        q = torch.randn(qo_len, H, D, generator=g, device=dev, dtype=torch.float16)
+        o = qu.prefill_forward(q, ctl, 0)
+        s = torch.einsum("qhd,khd->hqk", q.float(), k.float()) / D ** 0.5
+        mask = torch.ones(qo_len, kv_len, dtype=torch.bool, device=dev).tril(diagonal=kv_len - qo_len)
+        ref = torch.einsum("hqk,khd->qhd", s.masked_fill(~mask, float("-inf")).softmax(-1), v.float())
+        torch.testing.assert_close(o.float(), ref, rtol=5e-3, atol=5e-3)
+    ctl.end_forward()
