@@ -382,6 +382,12 @@ int quest_decode_qkv_rope_batched(const void* h, const void* gamma, float eps, c
                                   uint32_t num_kv_heads, uint32_t head_dim, float rope_scale, float rope_theta,
                                   const quest_step_state_t* states, uint32_t n_tokens, quest_stream_t stream);
 
+/* Which kernel an n-token launch of this shape takes (tests / tuning; nothing is launched): 1 and info = {k slices per
+ * quad of rows, rounds, dynamic LDS bytes, workgroups, 128-wide k steps per row, weight fragments per set} for the persistent
+ * kernel (inputs resident in LDS), 0 for the inputs-from-L2 kernel, < 0 for argument errors.  virtual_rows = output rows
+ * of the launch (q + k + v rows; 2 x intermediate for the gate/up launch). */
+int quest_decode_batched_plan(uint32_t in_dim, uint32_t virtual_rows, uint32_t n_tokens, int rope, uint32_t info[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,7 @@ SIGNATURES = {
     "quest_decode_mlp_gate_up_batched": (ctypes.c_int, [c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
     "quest_decode_qkv_rope_batched": (ctypes.c_int, [c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32,
                                                       c_u32, c_u32, c_f32, c_f32, c_vp, c_u32, c_vp]),
+    "quest_decode_batched_plan": (ctypes.c_int, [c_u32, c_u32, c_u32, ctypes.c_int, c_vp]),
     "quest_rms_norm_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp]),
 }
 

@@ -973,3 +973,20 @@ extern "C" int quest_decode_qkv_rope_batched(const void* h, const void* gamma, f
     a.state_stride = 1;
     return launch_batched<kGvQkvRope>(a, p.rows[0] + p.rows[1] + p.rows[2], (hipStream_t)stream);
 }
+
+// Which kernel an n-token launch of this shape takes (tests / tuning; no launch): returns 1 and fills
+// info = {k slices per quad, rounds, dynamic LDS bytes, workgroups, 128-wide k steps per row, fragments per set} for the
+// persistent kernel, 0 for the first (inputs-from-L2) kernel, < 0 for argument errors as the launches return them.
+extern "C" int quest_decode_batched_plan(uint32_t in_dim, uint32_t virtual_rows, uint32_t n_tokens, int rope, uint32_t info[6]) {
+    if (in_dim == 0 || virtual_rows == 0 || n_tokens == 0 || n_tokens > 16 || !info) return QUEST_EINVAL;
+    if (in_dim % 8 != 0) return QUEST_EUNSUPPORTED;
+    SkinnyArgs a{};
+    a.g.in_dim = in_dim, a.n_tokens = n_tokens;
+    const uint32_t tg = n_tokens <= 4 ? 1 : (n_tokens <= 8 ? 2 : 4);
+    PersistPlan pl{};
+    uint32_t grid = 0;
+    size_t lds = 0;
+    if (!plan_persist(a, virtual_rows, tg, rope != 0, pl, grid, lds)) return 0;
+    info[0] = pl.ks, info[1] = pl.rounds, info[2] = (uint32_t)lds, info[3] = grid, info[4] = pl.spp, info[5] = (uint32_t)kCM;
+    return 1;
+}

@@ -410,3 +410,33 @@ def test_kernel_sweep_table_and_side_flags():
     md = sweep.markdown({"rows": [r]})
     assert "63.551 us" in md and md.count("\n") == 2
     assert sweep.LONGBENCH_LEN == (5819, 15370, 11984, 14101, 24723, 8154) and sweep.LONGBENCH_BUDGET[4] == 4096
+
+
+def test_n_token_launch_planner_host_logic():
+    """quest_decode_batched_plan (no GPU needed): Llama-2-7B launches at 8 tokens take the persistent kernel with the
+    inputs in LDS -- except down_proj, whose 8 x 11008 inputs do not fit -- one workgroup per CU (256 when no device is
+    visible), at most 4 weight fragments per task, every quad of rows covered by the rounds."""
+    import ctypes
+
+    from quest_amd._lib import lib
+
+    def plan(in_dim, rows, n, rope=0):
+        info = (ctypes.c_uint32 * 6)()
+        rc = lib.quest_decode_batched_plan(in_dim, rows, n, rope, info)
+        return rc, list(info)
+
+    for name, in_dim, rows, rope in (("qkv", 4096, 3 * 4096, 1), ("o_proj", 4096, 4096, 0), ("gate_up", 4096, 2 * 11008, 0),
+                                     ("lm_head", 4096, 32000, 0)):
+        for n in (1, 4, 8, 16):
+            rc, (ks, rounds, lds, grid, spp, cm) = plan(in_dim, rows, n, rope)
+            assert rc == 1, (name, n)
+            assert grid >= 1 and spp == 32 and cm == 4 and ks in (1, 2, 4, 8, 16) and (spp + ks - 1) // ks <= cm
+            assert rounds * grid * (16 // ks) * 4 >= rows              # every row has a task
+            assert (rounds - 1) * grid * (16 // ks) * 4 < rows         # and no round is empty
+            tokens = 4 if n <= 4 else (8 if n <= 8 else 16)
+            assert lds >= tokens * (in_dim + 32) * 2 and lds > 80 * 1024  # inputs fit; one workgroup per CU
+    assert plan(11008, 4096, 8)[0] == 0          # down_proj at 8 tokens: inputs-from-L2 kernel
+    assert plan(11008, 4096, 4)[0] == 0          # ... and at 4: rows longer than 16 slices x 4 steps x 128
+    assert plan(8192, 4096, 4)[0] == 1
+    assert plan(256, 40, 2)[0] == 0              # rows shorter than a wave sweep
+    assert plan(4096, 4096, 0)[0] == -1 and plan(4096, 4096, 17)[0] == -1 and plan(4100, 4096, 8)[0] == -2
