@@ -640,6 +640,18 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
 
     // ---- prologue: inputs first (see above)
     x_load();
+    if constexpr (MODE == kGvQkvRope) {  // under the inputs' latency; published by the staging barrier
+        const uint32_t half_d = p.head_dim / 2u;
+        for (uint32_t e = tid; e < a.n_tokens * half_d; e += kPsWaves * kWave) {
+            const uint32_t t = e / half_d, d = e % half_d;
+            const float pos = (float)(p.state[(size_t)t * a.state_stride].seq_len - 1);
+            const float freq = p.rcp_scale * exp2f(p.log2_rcp_theta * (float)(2 * d) / (float)p.head_dim);
+            float sn, cs;
+            sincosf(pos * freq, &sn, &cs);
+            s_rope[t * kRopeMaxHalfD + d] = make_float2(cs, sn);
+        }
+    }
+
     __builtin_amdgcn_s_barrier();
     PS_STAMP();
     if (norm) {  // 1 / rms per token: a thread's vector i lies in ONE token; per-token totals through LDS atomics
@@ -669,18 +681,6 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
     lds_barrier();
     issue(wa, 0);
     PS_STAMP();
-    if constexpr (MODE == kGvQkvRope) {  // published by the first round's barrier
-        const uint32_t half_d = p.head_dim / 2u;
-        for (uint32_t e = tid; e < a.n_tokens * half_d; e += kPsWaves * kWave) {
-            const uint32_t t = e / half_d, d = e % half_d;
-            const float pos = (float)(p.state[(size_t)t * a.state_stride].seq_len - 1);
-            const float freq = p.rcp_scale * exp2f(p.log2_rcp_theta * (float)(2 * d) / (float)p.head_dim);
-            float sn, cs;
-            sincosf(pos * freq, &sn, &cs);
-            s_rope[t * kRopeMaxHalfD + d] = make_float2(cs, sn);
-        }
-    }
-
     float4_t acc[TG];
 #pragma unroll
     for (int t = 0; t < TG; ++t) acc[t] = float4_t{0.f, 0.f, 0.f, 0.f};
