@@ -73,6 +73,7 @@ def time_batched(cfg, a, dense, dev):
         c.end_forward()
     del k, v
     model.capture_decode_graph_batched()
+    time_batched.fused_layers = bool(model.fused_layers)
     model.graph_input.copy_(torch.randn(a.seqs, 1, a.hidden, generator=g, device=dev, dtype=torch.float16) * 0.1)
     for _ in range(3):
         model._graph.replay()
@@ -150,7 +151,8 @@ def main():
         d_ms = time_batched(cfg, a, True, dev)
         print(json.dumps({"bench": "e2e batched decode, random-weight Llama", "sequences": a.seqs, "ctx": a.ctx,
                           "token_budget": a.token_budget, "layers": a.layers, "hidden": a.hidden, "heads": a.heads,
-                          "kv_heads": a.kv_heads, "dense_first_layers": 2, "ms_per_step_quest": q_ms,
+                          "kv_heads": a.kv_heads, "intermediate": a.inter, "vocab": a.vocab, "dense_first_layers": 2,
+                          "fused_decoder_layer_launches": getattr(time_batched, "fused_layers", None), "ms_per_step_quest": q_ms,
                           "ms_per_step_full_kv": d_ms, "tokens_per_s_quest": a.seqs / (q_ms * 1e-3),
                           "tokens_per_s_full_kv": a.seqs / (d_ms * 1e-3), "speedup": d_ms / q_ms}))
         return
