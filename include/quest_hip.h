@@ -311,6 +311,13 @@ int quest_decode_set_batch(quest_decode_handler_t* h, uint32_t n_seqs);
 /* Introspection of the current plan (for benches/tests): pages per workgroup, workgroups per head. */
 int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_chunk,
                            uint32_t* chunks_per_head);
+/* Which kernel instantiation the handler's most recent per-head-list launch (quest_decode_forward*, fused or not) took:
+ * info = {keys per thread of the fused top-k front end (0: index-tensor launch), waves per workgroup, front-end variant
+ * (0 / 1 / 3: first generation with scalar / vector-fed staging arrays / keys straight into registers; 2: second
+ * generation; 4 / 5: column-range ownership on the first / second generation's threshold phase), 1 if the one-variant
+ * instantiation was launched (0: the generic kernel), workgroups per head, sequences}.  Tests and benches assert with it
+ * that they run the kernel they mean to. */
+int quest_decode_last_launch_info(const quest_decode_handler_t* h, uint32_t info[6]);
 /* Measurement aid: with skip != 0, quest_decode_forward* launch only the attention kernel and leave the
  * per-workgroup partial states in the handler's workspace (the output tensor is NOT written when the plan has
  * more than one workgroup per head).  Lets a bench time the dominant kernel by itself. */
@@ -321,10 +328,13 @@ int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
  * the plan] (rows of a sequence still shorter than the budget are filled up to its live page count).  NULL
  * pointers turn it off.  Not an entry the reference has: its top-k output lives in topk_filtering's tensors. */
 int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int32_t* idx_out);
-/* Which top-k front end the fused launches use: 0 = chosen by row length (default), 1 = first generation
+/* Which top-k front end the fused launches use: 0 = automatic (default: column-range ownership, csrc/topk_colrange.cuh,
+ * where a head has several 8-wave workgroups and aligned score rows; otherwise by row length), 1 = first generation
  * (csrc/topk_select.cuh; rows up to 4096 pages), 2 = second generation (csrc/topk_bitmap.cuh; needs 8-byte aligned
- * score rows) without its histogram pre-filter, 3 = second generation with the pre-filter (the default beyond 4096
- * pages).  All implement the same selection (bit-identical page lists); tuning / test aid. */
+ * score rows) without its histogram pre-filter, 3 = second generation with the pre-filter, 4 = column-range ownership
+ * also on rows short enough for 4-wave workgroups (tests).  1-3 are the slot-ownership variants.  All implement the same
+ * selection: bit-identical page SETS and (inspection) lists; the column-range variants fold a head's pages in a
+ * different workgroup split, so outputs differ from the others' by fp32 merge order (tests: <= 2e-3).  Tuning / test aid. */
 int quest_decode_set_front_end(quest_decode_handler_t* h, int generation);
 /* Override the planner (0 = automatic).  Used by tuning sweeps. */
 int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);

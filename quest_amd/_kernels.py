@@ -472,12 +472,13 @@ def _batch(state, kv_tables, meta_tables, budgets=None) -> Batch:
             raise RuntimeError("page_budgets must be an int32 tensor")
     for t, name in ((kv_tables, "kv_tables"), (meta_tables, "meta_tables")):
         if t is not None:
-            _check_input(t, name)
-            _check_dim(2, t, name)
+            # rows of `capacity` entries at a stride >= capacity: BatchedInferenceController pads the stride to a multiple
+            # of 4 entries so that every sequence's table is 16-byte aligned (vector loads of page ids)
+            _check_rows(t, name)
             _check_eq(t.size(0), n, f"{name}.size(0), n_seqs")
             if t.dtype != torch.int32:
                 raise RuntimeError(f"{name} must be an int32 tensor")
-    return Batch(n, 0 if kv_tables is None else kv_tables.size(1), 0 if meta_tables is None else meta_tables.size(1), 0,
+    return Batch(n, 0 if kv_tables is None else kv_tables.stride(0), 0 if meta_tables is None else meta_tables.stride(0), 0,
                  None if budgets is None else budgets.data_ptr())
 
 
@@ -805,11 +806,23 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         check(lib.quest_decode_plan_info(self._h, ctypes.byref(a), ctypes.byref(b)), "plan_info")
         return a.value, b.value
 
+    def last_launch_info(self) -> dict:
+        """Which kernel instantiation the handler's most recent per-head-list launch took: keys per thread of the fused
+        front end (0 = index-tensor launch), waves per workgroup, front-end variant (DecodeParams.vec_front: 0 / 1 / 3
+        first generation staged / vector-staged / direct, 2 second generation, 4 / 5 column-range ownership on the
+        first / second generation's threshold phase), whether the one-variant instantiation was launched, workgroups
+        per head, sequences.  So that tests and benches can assert they run the same kernel."""
+        info = (ctypes.c_uint32 * 6)()
+        check(lib.quest_decode_last_launch_info(self._h, info), "last_launch_info")
+        return {"keys_per_thread": info[0], "waves": info[1], "front_end_variant": info[2], "specialised": bool(info[3]),
+                "workgroups_per_head": info[4], "n_seqs": info[5]}
+
     def set_pages_per_chunk(self, ppc: int) -> None:
         check(lib.quest_decode_set_pages_per_chunk(self._h, int(ppc)), "set_pages_per_chunk")
 
     def set_front_end(self, generation: int) -> None:
-        """Tuning / test aid: force the fused launches' top-k front end (0 = by row length, 1, 2)."""
+        """Tuning / test aid: force the fused launches' top-k front end (0 = automatic; 1 / 2 / 3 = the slot-ownership
+        generations; 4 = column-range ownership also on short rows)."""
         check(lib.quest_decode_set_front_end(self._h, int(generation)), "set_front_end")
 
     def set_selection_out(self, val_out, idx_out) -> None:

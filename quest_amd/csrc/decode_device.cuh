@@ -2,7 +2,7 @@
 // per-workgroup partial states (merge_states_kernel's fast path) and the workgroup body of sparse_decode_kernel (sparse_attn.hip, which also holds the reference citations and the design notes).
 #pragma once
 #include "estimate_device.cuh"
-#include "topk_bitmap.cuh"
+#include "topk_colrange.cuh"
 
 // Developer aid (scripts/timeline.py): -DQUEST_TIMELINE makes one workgroup of sparse_decode_kernel write
 // clock stamps of its phases into the `lse` buffer instead of the log-sum-exp.
@@ -10,10 +10,14 @@
 #define QUEST_LSE_ENABLED false
 #define QUEST_STAMP(i) \
     do { __builtin_amdgcn_s_waitcnt(0); tl[i] = clock64(); } while (0)
+#define QUEST_TL_PARAM , long long* tl
+#define QUEST_TL_ARG , tl
 #else
 #define QUEST_LSE_ENABLED true
 #define QUEST_STAMP(i) \
     do { } while (0)
+#define QUEST_TL_PARAM
+#define QUEST_TL_ARG
 #endif
 
 namespace quest {
@@ -50,7 +54,9 @@ struct DecodeParams {
     uint32_t vec_front;     // fused front end: 0 = first generation (topk_select.cuh); 1 = the same, staging arrays fed by
                             // 8/16-byte granule loads; 3 = the same, each thread loads its OWN cpt (4 or 8) columns and
                             // page ids straight into registers (no LDS staging); 2 = second generation
-                            // (topk_bitmap.cuh).  1-3 need aligned score rows
+                            // (topk_bitmap.cuh); 4 = column-range ownership (topk_colrange.cuh) on the ownership of 3
+                            // (sparse_decode_colrange_body); 5 = the same on the granule ownership of 2.  1-5 need
+                            // aligned score rows
     uint32_t cpt;           // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
     // ---- beyond the preloaded block (one scalar load of the argument segment)
     uint32_t idx_stride;
@@ -74,6 +80,9 @@ struct DecodeParams {
     uint32_t xcd_period;  // > 1: grid row y serves query head (y % period) * (Hq / period) + y / period (see sparse_decode_kernel)
     uint32_t fe2_prefilter;  // second-generation front end: histogram only the keys above a per-wave lower bound (topk_bitmap.cuh)
     const int32_t* budgets;  // optional per-sequence page budgets (pages incl. the current one) of a batched launch
+    // column-range ownership (vec_front 4 / 5, topk_colrange.cuh)
+    uint32_t chunks_inv;     // floor(2^32 / n_chunks) + 1: x / n_chunks == mulhi(x, chunks_inv) for the row lengths served
+    uint32_t table_vec;      // page table(s) 16-byte aligned: a lane's 4 page ids are one load
 };
 
 // leading scalar kernel arguments (preloaded into SGPRs at wave launch) and their hand-over to the struct; a_pack =
@@ -218,6 +227,144 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
     }
 }
 
+// Gather of the slots [slot_begin, slot_end) of one head by the NW waves of a workgroup + the workgroup's result: slot s
+// is the listed page page_of(s) for s < n_listed, the sequence's current page (p.last_page_idx, p.last_page_len rows)
+// otherwise.  Writes o (one workgroup per head) or the workgroup's partial state.
+template <int D, int S_T, int NW, typename PageOf>
+__device__ __forceinline__ void attend_slots(const DecodeParams& p, const SeqView& sv, const half8 q_raw, const uint32_t chunk,
+                                             const uint32_t hq, const uint32_t slot_begin, const uint32_t slot_end,
+                                             const uint32_t n_listed, const int wave, const int lane,
+                                             PageOf&& page_of QUEST_TL_PARAM) {
+    constexpr int LPR = D / kVec, R = kWave / LPR;
+    const int row = lane / LPR, col = lane % LPR;
+    RowState<D> st;
+    const uint32_t hk = hq / p.group;
+    const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
+    const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
+    float8 qv = to_f32(q_raw);
+    qv *= p.scale_log2;
+    // physical page of a slot: a listed page, or the sequence's current page for slots at or beyond n_listed
+    auto slot_page = [&](uint32_t slot) -> int32_t {
+        if (slot >= n_listed) return p.last_page_idx;
+        return page_of(slot);
+    };
+
+    if constexpr (S_T > 0) {
+        constexpr int T = (S_T + R - 1) / R;  // load instructions per page per tensor
+        const uint32_t step = R * p.st.entry;
+        for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += 2 * NW) {
+            const uint32_t s1 = s0 + NW;
+            const bool has1 = s1 < slot_end;
+            const int32_t pg0 = __builtin_amdgcn_readfirstlane(slot_page(s0));
+            const int32_t pg1 = __builtin_amdgcn_readfirstlane(has1 ? slot_page(s1) : pg0);
+            const int len0 = s0 < n_listed ? S_T : (int)p.last_page_len;
+            const int len1 = has1 ? (s1 < n_listed ? S_T : (int)p.last_page_len) : 0;
+            const half_t* b0 = head_base + (size_t)pg0 * p.st.page;
+            const half_t* b1 = head_base + (size_t)pg1 * p.st.page;
+            half8 k[2 * T], v[2 * T];
+            int left[2 * T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                left[t] = len0 - t * R;
+                left[T + t] = len1 - t * R;
+                // rows past the page's length exist in the pool (the page is allocated) but hold
+                // stale bytes; they are fetched only for the sequence's last page and masked in fold
+                k[t] = ld8_kv(b0 + lane_off + t * step);
+                v[t] = ld8_kv(b0 + lane_off + t * step + p.st.v_off);
+            }
+            if (has1) {  // wave-uniform (a likely-taken hint here cost 3.5 us per batched launch: measured, r3j)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    k[T + t] = ld8_kv(b1 + lane_off + t * step);
+                    v[T + t] = ld8_kv(b1 + lane_off + t * step + p.st.v_off);
+                }
+                fold_groups<D, 2 * T>(st, qv, k, v, left, row);
+            } else {
+                half8 k0[T], v0[T];
+                int left0[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    k0[t] = k[t];
+                    v0[t] = v[t];
+                    left0[t] = left[t];
+                }
+                fold_groups<D, T>(st, qv, k0, v0, left0, row);
+            }
+        }
+    } else {
+        const uint32_t S = p.page_size;
+        for (uint32_t slot = slot_begin + wave; slot < slot_end; slot += NW) {
+            const bool sel = slot < n_listed;
+            const int32_t pg = __builtin_amdgcn_readfirstlane(slot_page(slot));
+            const int len = sel ? (int)S : (int)p.last_page_len;
+            const half_t* b = head_base + (size_t)pg * p.st.page;
+            for (int t0 = 0; t0 < len; t0 += R) {
+                half8 k1[1], v1[1];
+                const int left[1] = {len - t0};
+                // rows past `len` stay inside the (allocated) page for page sizes that are a multiple of R;
+                // otherwise clamp to the page's first row -- masked in fold either way
+                const uint32_t r_in = (uint32_t)(t0 + row) < S ? (uint32_t)t0 : 0u;
+                const half_t* ptr = b + lane_off + (size_t)r_in * p.st.entry - (r_in == (uint32_t)t0 ? 0 : (size_t)row * p.st.entry);
+                k1[0] = ld8(ptr);
+                v1[0] = ld8(ptr + p.st.v_off);
+                fold_groups<D, 1>(st, qv, k1, v1, left, row);
+            }
+        }
+    }
+
+    QUEST_STAMP(6);
+    // rows of the wave -> one state (xor butterfly across rows; both partners get the same bits)
+    for_each_row_distance<LPR>([&](auto off_c) {
+        constexpr int OFF = decltype(off_c)::value;
+        const float m_o = lane_xor<OFF>(st.m, lane), d_o = lane_xor<OFF>(st.d, lane);
+        const float m_n = __builtin_fmaxf(st.m, m_o);
+        const float a = __builtin_amdgcn_exp2f(st.m - m_n), b = __builtin_amdgcn_exp2f(m_o - m_n);
+        st.d = st.d * a + d_o * b;
+#pragma unroll
+        for (int i = 0; i < kVec; ++i) st.acc[i] = st.acc[i] * a + lane_xor<OFF>(st.acc[i], lane) * b;
+        st.m = m_n;
+    });
+
+    // waves -> workgroup through LDS
+    __shared__ float s_acc[NW][D];
+    __shared__ float s_md[NW][2];
+    if (row == 0) {
+#pragma unroll
+        for (int i = 0; i < kVec; ++i) s_acc[wave][col * kVec + i] = st.acc[i];
+        if (col == 0) {
+            s_md[wave][0] = st.m;
+            s_md[wave][1] = st.d;
+        }
+    }
+    QUEST_STAMP(7);
+    __syncthreads();
+    QUEST_STAMP(8);
+    const int f = threadIdx.x;
+    if (f < D) {
+        float M = s_md[0][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) M = __builtin_fmaxf(M, s_md[w][0]);
+        float acc = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float e = __builtin_amdgcn_exp2f(s_md[w][0] - M);
+            acc += e * s_acc[w][f];
+            den += e * s_md[w][1];
+        }
+        if (p.n_chunks == 1) {
+            sv.o[(size_t)hq * D + f] = (half_t)(acc / den);
+            if (QUEST_LSE_ENABLED && p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
+        } else {
+            float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
+            w[f] = acc;
+            if (f == 0) {
+                w[D] = M;
+                w[D + 1] = den;
+            }
+        }
+    }
+}
+
 // S_T = compile-time page size (16) or 0 for the generic run-time path.
 //
 // Addressing: the (page, kv head) tile base is wave-uniform (page id through readfirstlane -> SGPR
@@ -237,11 +384,11 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
 template <int D, int S_T, int FC, int NW, int VF = -1>
 __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_t chunk, const uint32_t hq, const uint32_t seq,
                                                    const uint32_t num_qo_heads) {
-    constexpr int LPR = D / kVec, R = kWave / LPR;
+    constexpr int LPR = D / kVec;
     const uint32_t vec_front = VF >= 0 ? (uint32_t)VF : p.vec_front;
     // wave index as an SGPR so per-wave control flow below is scalar branching
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int row = lane / LPR, col = lane % LPR;
+    const int col = lane % LPR;
     // Source order matters up to the first loads: everything above them uses only the preloaded arguments (see
     // DecodeParams); values that need the rest of the struct (kv head, slots, pool strides) are derived after them.
 #ifdef QUEST_TIMELINE
@@ -275,8 +422,6 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
 
     // q is requested now but first used after the top-k front end, so its latency hides under the selection
     const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);
-
-    RowState<D> st;
 
     __shared__ int32_t s_sel[FC > 0 ? kFusedMaxPpc : 1];
     if constexpr (FC > 0) {
@@ -471,133 +616,11 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             }
         }  // n > 0
     }
-    const uint32_t hk = hq / p.group;
-    const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
-    const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
     const int32_t* idx_row = sv.indices + (size_t)hq * p.idx_stride;  // uniform
-    float8 qv = to_f32(q_raw);
-    qv *= p.scale_log2;
-    // physical page of a slot: selected list (global index row, or the LDS list of the fused front end)
-    auto slot_page = [&](uint32_t slot) -> int32_t {
-        if (slot >= p.n_sel) return p.last_page_idx;
+    attend_slots<D, S_T, NW>(p, sv, q_raw, chunk, hq, slot_begin, slot_end, p.n_sel, wave, lane, [&](uint32_t slot) -> int32_t {
         if constexpr (FC > 0) return s_sel[slot - slot_begin];
         else return idx_row[slot];
-    };
-
-    if constexpr (S_T > 0) {
-        constexpr int T = (S_T + R - 1) / R;  // load instructions per page per tensor
-        const uint32_t step = R * p.st.entry;
-        for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += 2 * NW) {
-            const uint32_t s1 = s0 + NW;
-            const bool has1 = s1 < slot_end;
-            const int32_t pg0 = __builtin_amdgcn_readfirstlane(slot_page(s0));
-            const int32_t pg1 = __builtin_amdgcn_readfirstlane(has1 ? slot_page(s1) : pg0);
-            const int len0 = s0 < p.n_sel ? S_T : (int)p.last_page_len;
-            const int len1 = has1 ? (s1 < p.n_sel ? S_T : (int)p.last_page_len) : 0;
-            const half_t* b0 = head_base + (size_t)pg0 * p.st.page;
-            const half_t* b1 = head_base + (size_t)pg1 * p.st.page;
-            half8 k[2 * T], v[2 * T];
-            int left[2 * T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                left[t] = len0 - t * R;
-                left[T + t] = len1 - t * R;
-                // rows past the page's length exist in the pool (the page is allocated) but hold
-                // stale bytes; they are fetched only for the sequence's last page and masked in fold
-                k[t] = ld8_kv(b0 + lane_off + t * step);
-                v[t] = ld8_kv(b0 + lane_off + t * step + p.st.v_off);
-            }
-            if (has1) {  // wave-uniform (a likely-taken hint here cost 3.5 us per batched launch: measured, r3j)
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    k[T + t] = ld8_kv(b1 + lane_off + t * step);
-                    v[T + t] = ld8_kv(b1 + lane_off + t * step + p.st.v_off);
-                }
-                fold_groups<D, 2 * T>(st, qv, k, v, left, row);
-            } else {
-                half8 k0[T], v0[T];
-                int left0[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    k0[t] = k[t];
-                    v0[t] = v[t];
-                    left0[t] = left[t];
-                }
-                fold_groups<D, T>(st, qv, k0, v0, left0, row);
-            }
-        }
-    } else {
-        const uint32_t S = p.page_size;
-        for (uint32_t slot = slot_begin + wave; slot < slot_end; slot += NW) {
-            const bool sel = slot < p.n_sel;
-            const int32_t pg = __builtin_amdgcn_readfirstlane(slot_page(slot));
-            const int len = sel ? (int)S : (int)p.last_page_len;
-            const half_t* b = head_base + (size_t)pg * p.st.page;
-            for (int t0 = 0; t0 < len; t0 += R) {
-                half8 k1[1], v1[1];
-                const int left[1] = {len - t0};
-                // rows past `len` stay inside the (allocated) page for page sizes that are a multiple of R;
-                // otherwise clamp to the page's first row -- masked in fold either way
-                const uint32_t r_in = (uint32_t)(t0 + row) < S ? (uint32_t)t0 : 0u;
-                const half_t* ptr = b + lane_off + (size_t)r_in * p.st.entry - (r_in == (uint32_t)t0 ? 0 : (size_t)row * p.st.entry);
-                k1[0] = ld8(ptr);
-                v1[0] = ld8(ptr + p.st.v_off);
-                fold_groups<D, 1>(st, qv, k1, v1, left, row);
-            }
-        }
-    }
-
-    QUEST_STAMP(6);
-    // rows of the wave -> one state (xor butterfly across rows; both partners get the same bits)
-    for_each_row_distance<LPR>([&](auto off_c) {
-        constexpr int OFF = decltype(off_c)::value;
-        const float m_o = lane_xor<OFF>(st.m, lane), d_o = lane_xor<OFF>(st.d, lane);
-        const float m_n = __builtin_fmaxf(st.m, m_o);
-        const float a = __builtin_amdgcn_exp2f(st.m - m_n), b = __builtin_amdgcn_exp2f(m_o - m_n);
-        st.d = st.d * a + d_o * b;
-#pragma unroll
-        for (int i = 0; i < kVec; ++i) st.acc[i] = st.acc[i] * a + lane_xor<OFF>(st.acc[i], lane) * b;
-        st.m = m_n;
-    });
-
-    // waves -> workgroup through LDS
-    __shared__ float s_acc[NW][D];
-    __shared__ float s_md[NW][2];
-    if (row == 0) {
-#pragma unroll
-        for (int i = 0; i < kVec; ++i) s_acc[wave][col * kVec + i] = st.acc[i];
-        if (col == 0) {
-            s_md[wave][0] = st.m;
-            s_md[wave][1] = st.d;
-        }
-    }
-    QUEST_STAMP(7);
-    __syncthreads();
-    QUEST_STAMP(8);
-    const int f = threadIdx.x;
-    if (f < D) {
-        float M = s_md[0][0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) M = __builtin_fmaxf(M, s_md[w][0]);
-        float acc = 0.f, den = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float e = __builtin_amdgcn_exp2f(s_md[w][0] - M);
-            acc += e * s_acc[w][f];
-            den += e * s_md[w][1];
-        }
-        if (p.n_chunks == 1) {
-            sv.o[(size_t)hq * D + f] = (half_t)(acc / den);
-            if (QUEST_LSE_ENABLED && p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
-        } else {
-            float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
-            w[f] = acc;
-            if (f == 0) {
-                w[D] = M;
-                w[D + 1] = den;
-            }
-        }
-    }
+    } QUEST_TL_ARG);
 #ifdef QUEST_TIMELINE
     QUEST_STAMP(9);
     if (p.lse && chunk == p.n_chunks / 2 && hq == num_qo_heads / 2 && seq == 0 && threadIdx.x == 0) {
@@ -605,6 +628,111 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         if constexpr (FC > 0)
             for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
         p.lse[10] = (float)(wall_clock64() - wall0);  // 100 MHz ticks over the same span as tl[9] - tl[0]
+    }
+#endif
+}
+
+// ---- column-range ownership (round 4; topk_colrange.cuh has the design note).  Workgroup `chunk` of a head owns the
+// columns [chunk * rl, chunk * rl + rl) of the head's score row, rl = ceil(n / n_chunks) rounded up to 4 (<= 256), and
+// gathers the selected pages among them (NG granules of 4 columns per lane: rl <= 256 NG); the last workgroup of a head also takes the sequence's current page.  After the
+// barrier that publishes the threshold there is no further exchange: no rank scan, no slot walk, no page-list barrier.
+// GEN 1: threshold-phase ownership of vec_front 3 (thread t loads its own p.cpt = 4 / 8 contiguous columns; rows up to
+// 4096 columns, FC = 8).  GEN 2: granule ownership of topk_bitmap.cuh with its pre-filter (rows up to FC * NT columns).
+template <int D, int FC, int NW, int GEN, int NG>
+__device__ __forceinline__ void sparse_decode_colrange_body(DecodeParams p, const uint32_t chunk, const uint32_t hq,
+                                                            const uint32_t seq, const uint32_t num_qo_heads) {
+    constexpr int LPR = D / kVec, NT = NW * kWave;
+    static_assert(GEN == 1 || GEN == 2, "threshold-phase ownership");
+    static_assert(GEN == 2 || FC == 8, "first-generation ownership: 8 keys per thread");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int col = lane % LPR;
+#ifdef QUEST_TIMELINE
+    long long tl[10] = {};
+    long long sub_out[9] = {};
+    long long* const sub = sub_out;
+    const long long wall0 = wall_clock64();
+    QUEST_STAMP(0);
+#else
+    long long* const sub = nullptr;
+#endif
+    const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
+    const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);  // first used after the selection
+    __shared__ TopkSmem<NT> sm;
+    __shared__ int32_t s_list[kColRangeMax * NG];
+    const uint32_t n_cap = p.n_scores;
+    const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
+    // live lengths of a state-driven launch: one scalar load, issued before the vector loads, consumed after them
+    const int4 live = *(p.state ? reinterpret_cast<const int4*>(sv.state) : reinterpret_cast<const int4*>(p.q));
+
+    // ---- threshold-phase loads: addresses depend on the capacity only
+    uint32_t key[GEN == 1 ? FC : 1];
+    Fe2Raw<false> raw2[GEN == 2 ? FC / 4 : 1];
+    uint4 own_keys = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t c0 = threadIdx.x * p.cpt;
+    if constexpr (GEN == 1) {
+        const uint32_t own_cc = c0 < n_cap ? c0 : 0u;
+        // two unconditional 8-byte loads (the second repeats the first at 4 columns per thread): see sparse_decode_body
+        const uint2 lo = *reinterpret_cast<const uint2*>(srow + own_cc);
+        const uint2 hi = *reinterpret_cast<const uint2*>(srow + own_cc + (p.cpt == 8 ? 4u : 0u));
+        own_keys = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+        fe2_issue<NT, FC / 4, false>(srow, sv.indices, n_cap + 1u, false, n_cap, raw2);
+    }
+    fe2_clear<NT>(sm);
+    const int32_t budget_raw = ld_uniform_i32(p.budgets ? p.budgets + seq : reinterpret_cast<const int32_t*>(p.q));
+    if (p.state) {
+        p.n_scores = (uint32_t)(live.y - 1);
+        p.last_page_len = (uint32_t)live.z;
+        p.last_page_idx = live.w;
+        if (p.budgets) p.n_sel = min(p.n_sel, (uint32_t)max(budget_raw - 1, 0));
+        p.n_sel = min(p.n_sel, p.n_scores);
+    }
+    const uint32_t n = p.n_scores;
+    // ---- the workgroup's column range and the lane's 4 columns of it (scores + page ids): needed only once T is known
+    const uint32_t rl = (__umulhi(n + p.n_chunks - 1u, p.chunks_inv) + 3u) & ~3u;
+    const uint32_t rs = chunk * rl, re = min(rs + rl, n);
+    const uint32_t gc0 = rs + 4u * (uint32_t)lane;
+    ColRangeRaw graw[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        graw[g] = colrange_issue(srow, sv.indices, n_cap + 1u, n_cap, gc0 + (uint32_t)(g * kColRangeMax), p.table_vec != 0);
+    const bool last_chunk = chunk + 1u == p.n_chunks;
+    uint32_t n_listed = 0;
+    if (n > 0) {  // block-uniform; a one-page sequence has only its current page
+        ColRangeSel cs;
+        if constexpr (GEN == 1) {
+            uint32_t mm = kMmNeutral;
+            const uint32_t w[4] = {own_keys.x, own_keys.y, own_keys.z, own_keys.w};
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                key[i] = half_key((uint16_t)((i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu));
+                if ((uint32_t)i < p.cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
+            }
+            QUEST_STAMP(1);
+            topk_publish_range<NT>(sm, mm);
+            QUEST_STAMP(2);
+            __syncthreads();
+            QUEST_STAMP(3);
+            cs = topk_threshold_colrange<NT, FC>(sm, key, n, p.n_sel, p.cpt, rs, sub);
+        } else {
+            QUEST_STAMP(1);
+            cs = fe2_threshold_colrange<NT, FC>(sm, raw2, n_cap, n, p.n_sel, rs, p.fe2_prefilter != 0, sub);
+        }
+        QUEST_STAMP(4);
+        const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
+        n_listed = colrange_collect<NG>(cs, graw, gc0, re, s_list, wave == 0, p.sel_idx_out ? p.sel_idx_out + out_row : nullptr,
+                                    p.sel_val_out ? p.sel_val_out + out_row : nullptr);
+        QUEST_STAMP(5);
+    }
+    attend_slots<D, 16, NW>(p, sv, q_raw, chunk, hq, 0u, n_listed + (last_chunk ? 1u : 0u), n_listed, wave, lane,
+                            [&](uint32_t slot) -> int32_t { return s_list[slot]; } QUEST_TL_ARG);
+#ifdef QUEST_TIMELINE
+    QUEST_STAMP(9);
+    if (p.lse && chunk == p.n_chunks / 2 && hq == num_qo_heads / 2 && seq == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
+        for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
+        p.lse[10] = (float)(wall_clock64() - wall0);
+        p.lse[11] = (float)n_listed;
     }
 #endif
 }

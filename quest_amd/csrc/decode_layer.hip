@@ -250,7 +250,7 @@ template <int MODE>
 static int launch_gemv(const GemvArgs& p, uint32_t virtual_rows, hipStream_t s) {
     constexpr uint32_t kWant = 512;
     static const int forced = [] {
-        const char* e = getenv("QUEST_GEMV_CFG");
+        const char* e = quest_tuning_env("QUEST_GEMV_CFG");
         int rw = 0, u = 0;
         return e && sscanf(e, "%d,%d", &rw, &u) == 2 ? rw * 100 + u : 0;
     }();
@@ -847,7 +847,7 @@ static int launch_batched(const SkinnyArgs& a, uint32_t virtual_rows, hipStream_
     if (a.n_tokens == 0 || a.n_tokens > 16) return QUEST_EINVAL;
     if (a.g.in_dim % 8 != 0) return QUEST_EUNSUPPORTED;
     static const bool force_skinny = [] {
-        const char* e = getenv("QUEST_BATCHED_GEMV");
+        const char* e = quest_tuning_env("QUEST_BATCHED_GEMV");
         return e && e[0] == 's';
     }();
     const uint32_t tg = a.n_tokens <= 4 ? 1 : (a.n_tokens <= 8 ? 2 : 4);
@@ -935,7 +935,7 @@ extern "C" int quest_decode_gemv_residual_batched(const void* x, const void* w, 
     p.w[0] = (const half_t*)w, p.rows[0] = out_dim, p.out[0] = (half_t*)h, p.residual = (const half_t*)h;
     a.n_tokens = n_tokens, a.x_stride = in_dim, a.out_stride[0] = out_dim;
 #ifdef QUEST_PS_TIMELINE
-    if (const char* e = getenv("QUEST_PS_DEBUG_PTR")) p.out[2] = reinterpret_cast<half_t*>(strtoull(e, nullptr, 0));
+    if (const char* e = quest_tuning_env("QUEST_PS_DEBUG_PTR")) p.out[2] = reinterpret_cast<half_t*>(strtoull(e, nullptr, 0));
 #endif
     return launch_batched<kGvResidual>(a, out_dim, (hipStream_t)stream);
 }

@@ -244,6 +244,14 @@ __device__ __forceinline__ uint32_t half_key(uint16_t b) {
 #define QUEST_LIKELY(x) __builtin_expect(!!(x), 1)
 #endif
 
+// Tuning knobs (environment variables read by the launch paths) are honoured only when QUEST_TUNING=1 is set as well:
+// an inherited environment must not silently change which kernel a product launch takes.
+#include <cstdlib>
+static inline const char* quest_tuning_env(const char* name) {
+    static const bool on = [] { const char* e = getenv("QUEST_TUNING"); return e && atoi(e) != 0; }();
+    return on ? getenv(name) : nullptr;
+}
+
 #define QUEST_LAUNCH_CHECK()                  \
     do {                                      \
         hipError_t e__ = hipGetLastError();   \

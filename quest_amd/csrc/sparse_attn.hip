@@ -36,7 +36,9 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(QUEST_
     QUEST_DECODE_HEAD_TAKE(p);
     uint32_t hq = blockIdx.y;
     if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (a_num_qo_heads / p.xcd_period) + hq / p.xcd_period;
-    sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+    if constexpr (VF == 4) sparse_decode_colrange_body<D, FC, NW, 1, 1>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+    else if constexpr (VF == 5) sparse_decode_colrange_body<D, FC, NW, 2, 2>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+    else sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,7 +276,8 @@ struct quest_decode_handler {
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
-    int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation, 3 = 2 + pre-filter
+    int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation, 3 = 2 + pre-filter, 4 = column-range ownership where applicable (= 0 today)
+    uint32_t last_launch[6] = {0, 0, 0, 0, 0, 0};  // quest_decode_last_launch_info
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
 };
@@ -298,7 +301,7 @@ extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_
         h->num_cus = (uint32_t)cus;
     else
         (void)hipGetLastError();  // no device (CPU-only import): keep the MI355X default
-    if (const char* e = getenv("QUEST_DEC_WAVES")) h->dec_waves = atoi(e) == 8 ? 8 : 4;  // tuning knob
+    if (const char* e = quest_tuning_env("QUEST_DEC_WAVES")) h->dec_waves = atoi(e) == 8 ? 8 : 4;  // tuning knob
     *out = h;
     return 0;
 }
@@ -323,7 +326,7 @@ extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) 
 }
 
 extern "C" int quest_decode_set_front_end(quest_decode_handler_t* h, int generation) {
-    if (!h || generation < 0 || generation > 3) return QUEST_EINVAL;
+    if (!h || generation < 0 || generation > 4) return QUEST_EINVAL;
     h->front_end = generation;
     return 0;
 }
@@ -417,11 +420,22 @@ extern "C" int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t*
     return 0;
 }
 
+extern "C" int quest_decode_last_launch_info(const quest_decode_handler_t* h, uint32_t info[6]) {
+    if (!h || !info) return QUEST_EINVAL;
+    for (int i = 0; i < 6; ++i) info[i] = h->last_launch[i];
+    return 0;
+}
+
 template <int D, int FC>
-static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t waves,
+static int launch_decode_fc(quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t waves,
                             hipStream_t s, uint32_t n_seqs) {
     dim3 grid(h->n_chunks, num_qo_heads, n_seqs);
-    const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0) : 0;  // the table has n_scores + 1 entries, staged in granules of 4
+    const bool colrange = FC > 0 && (p.vec_front == 4 || p.vec_front == 5);  // no dynamic LDS: nothing is staged
+    const size_t lds = FC > 0 && !colrange ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0) : 0;  // the table has n_scores + 1 entries, staged in granules of 4
+    // what this launch is (quest_decode_last_launch_info): keys per thread, waves, front-end variant, one-variant
+    // instantiation or the generic kernel, workgroups per head, sequences
+    uint32_t* info = h->last_launch;
+    info[0] = (uint32_t)FC, info[1] = waves, info[2] = FC > 0 ? p.vec_front : 0u, info[3] = 0u, info[4] = h->n_chunks, info[5] = n_seqs;
     // The common (keys per thread, front-end variant) pairs of 8-wave page-16 launches as their own compact
     // instantiations -- the generic kernel carries all four front-end variants (27 KiB of code; the one-variant kernels
     // are 10-14 KiB) and measured 0.57 us per launch slower at the headline shape:
@@ -429,10 +443,18 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
     //   FC 8,  variant 1: the same rows in batched launches, staging arrays fed by vector loads (cfg 3 x 8, cfg 5)
     //   FC 16 / 32, variant 2: second-generation front end of long rows (cfg 4)
     // QUEST_FE_SPECIALIZE=0 launches the generic kernel instead (A/B).
-    static const bool specialize = [] { const char* e = getenv("QUEST_FE_SPECIALIZE"); return !e || atoi(e) != 0; }();
-    if (specialize && p.page_size == 16 && waves == 8) {
-        constexpr int VFA = FC == 8 ? 3 : 2, VFB = FC == 8 ? 1 : 2;
+    static const bool specialize = [] { const char* e = quest_tuning_env("QUEST_FE_SPECIALIZE"); return !e || atoi(e) != 0; }();
+    if (colrange && !(p.page_size == 16 && waves == 8 && (FC == 8 || FC == 16 || FC == 24 || FC == 32)))
+        return QUEST_EUNSUPPORTED;  // plan_decode only picks the column-range variants for these instantiations
+    if ((specialize || colrange) && p.page_size == 16 && waves == 8) {
+        constexpr int VFA = FC == 8 ? 3 : 2, VFB = FC == 8 ? 1 : 2, VFC = FC == 8 ? 4 : 5;
         if constexpr (FC == 8 || FC == 16 || FC == 24 || FC == 32) {
+            info[3] = 1u;
+            if (p.vec_front == (uint32_t)VFC) {
+                hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFC>), grid, dim3(8 * kWave), 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
+                QUEST_LAUNCH_CHECK();
+                goto merge;
+            }
             if (p.vec_front == (uint32_t)VFA) {
                 hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFA>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
                 QUEST_LAUNCH_CHECK();
@@ -443,6 +465,7 @@ static int launch_decode_fc(const quest_decode_handler* h, const DecodeParams& p
                 QUEST_LAUNCH_CHECK();
                 goto merge;
             }
+            info[3] = 0u;
         }
     }
     if (p.page_size == 16 && waves == 8)
@@ -463,7 +486,7 @@ merge:
 
 // fc: fused top-k front end variant (0 = page ids come from an index tensor)
 template <int D>
-static int launch_decode(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, int fc,
+static int launch_decode(quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, int fc,
                          uint32_t waves, hipStream_t s, uint32_t n_seqs) {
     switch (fc) {
         case 0: return launch_decode_fc<D, 0>(h, p, num_qo_heads, waves, s, n_seqs);
@@ -531,6 +554,8 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     p.stage_ids = n_scores <= 4096 ? 1u : 0u;  // keys always staged (2 B each); ids (4 B each) up to 16 KiB
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
     p.vec_front = 0;
+    int forced = 0;
+    bool table_vec = false, rows_aligned = false;
     if (fused) {
         // second-generation front end (topk_bitmap.cuh): 8-byte loads of 4 scores straight from the row -> the rows
         // must be 8-byte aligned and readable up to the next multiple of 4 columns (the row stride covers it)
@@ -539,14 +564,16 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         // generation has fewer barriers but its per-wave scans are redundant work on an issue-bound CU (4 waves per
         // SIMD), which costs more than it saves on short rows -> gen 2 from 4097 columns up (gen 1 spills there).
         // quest_decode_set_front_end / QUEST_FRONT_END=1 / 2 force a generation where it is applicable (tuning, tests).
-        static const int env_forced = [] { const char* e = getenv("QUEST_FRONT_END"); return e ? atoi(e) : 0; }();
-        const int forced = h->front_end ? h->front_end : env_forced;
+        static const int env_forced = [] { const char* e = quest_tuning_env("QUEST_FRONT_END"); return e ? atoi(e) : 0; }();
+        forced = h->front_end ? h->front_end : env_forced;
         const uint32_t stride = p.score_stride;
         const bool aligned = ((uintptr_t)scores & 7u) == 0 && stride % 4u == 0 && stride >= ((n_scores + 3u) & ~3u);
         const bool table_aligned = ((uintptr_t)kv.indices & 15u) == 0 && (batch.n_seqs == 1 || batch.kv_table_stride % 4u == 0);
+        table_vec = table_aligned;
+        rows_aligned = aligned;
         int gen = 1;
         if (aligned) {
-            if (forced == 2 || forced == 3 || (forced == 0 && n_scores > 4096u)) gen = 2;
+            if (forced == 2 || forced == 3 || ((forced == 0 || forced == 4) && n_scores > 4096u)) gen = 2;
         }
         if (gen != 1) {
             p.vec_front = 2;
@@ -556,7 +583,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
             // (gen 2 stages ids only in the instantiations with <= 16 keys per thread: rows <= 4096 columns)
             // pre-filter of the histogram: pays where a thread holds many keys (rows beyond 4096 columns); QUEST_FE2_PREFILTER=0
             // turns it off, =2 turns it on for every second-generation launch (tuning, tests)
-            static const int pre_env = [] { const char* e = getenv("QUEST_FE2_PREFILTER"); return e ? atoi(e) : 1; }();
+            static const int pre_env = [] { const char* e = quest_tuning_env("QUEST_FE2_PREFILTER"); return e ? atoi(e) : 1; }();
             p.fe2_prefilter = forced == 3 || pre_env == 2 || (pre_env == 1 && forced != 2 && n_scores > 4096u) ? 1u : 0u;
         } else if (aligned && table_aligned && p.stage_ids && forced != 1) {
             p.vec_front = 1;  // generation 1 with its staging arrays filled by the granule loads (8 / 16 bytes per lane)
@@ -569,7 +596,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     p.table_stride = batch.kv_table_stride;
     p.budgets = state ? batch.page_budgets : nullptr;
     {   // XCD-aware row order for GQA (see sparse_decode_kernel); QUEST_XCD_GROUP=0 keeps the plain order (tuning)
-        static const bool xcd_group = [] { const char* e = getenv("QUEST_XCD_GROUP"); return !e || atoi(e) != 0; }();
+        static const bool xcd_group = [] { const char* e = quest_tuning_env("QUEST_XCD_GROUP"); return !e || atoi(e) != 0; }();
         uint32_t gcd = 8, c = h->n_chunks % 8u;
         while (c) { const uint32_t t = gcd % c; gcd = c; c = t; }
         const uint32_t period = 8u / gcd;
@@ -584,13 +611,13 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         // the selection is VALU-issue bound (~1000 instructions per wave at 8 keys per thread), so rows
         // beyond 1024 pages get 8 waves (<= 4 keys per thread up to 2048 pages, <= 8 up to 4096); the
         // attention part runs the same with 4 or 8 waves.  Measured at cfg 3: 15.2 vs 15.8 us.
-        if (kv.page_size == 16 && n_scores > 4u * 4u * kWave) waves = 8;
+        if (kv.page_size == 16 && (n_scores > 4u * 4u * kWave || forced == 4)) waves = 8;
         const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
         const uint32_t per_thread = (n_scores + nt - 1) / nt;
         // (24: rows of 8193-12288 columns at 512 threads -- cfg 4's capacity of ~8320 pages needs 17 keys per thread; the
         // 32-key instantiation carries two more dead load / histogram / bitmap rounds in every unrolled phase.
         // QUEST_FC24=0 takes the 32-key instantiation instead: A/B)
-        static const bool fc24 = [] { const char* e = getenv("QUEST_FC24"); return !e || atoi(e) != 0; }();
+        static const bool fc24 = [] { const char* e = quest_tuning_env("QUEST_FC24"); return !e || atoi(e) != 0; }();
         fc = per_thread <= 8 ? 8 : per_thread <= 16 ? 16 : (per_thread <= 24 && fc24) ? 24 : per_thread <= 32 ? 32 : 64;
         // ownership chunk: a multiple of 4 columns when the register capacity allows, so a thread's keys are one
         // 8/16-byte LDS read (topk_load_keys)
@@ -600,12 +627,26 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         // straight into registers (no staging arrays).  Measured (us per launch, staged -> direct): cfg 3 12.79 ->
         // 12.38; 8 sequences batched 48.6 -> 48.85, cfg 5 51.2 -> 51.2 -> single-sequence launches only.
         // QUEST_FE1_DIRECT=0 keeps the staged variant, =2 takes the direct one for batches too (tuning, tests).
-        static const int direct_env = [] { const char* e = getenv("QUEST_FE1_DIRECT"); return e ? atoi(e) : 1; }();
+        static const int direct_env = [] { const char* e = quest_tuning_env("QUEST_FE1_DIRECT"); return e ? atoi(e) : 1; }();
         const bool direct_ok = direct_env == 2 || (direct_env == 1 && batch.n_seqs == 1);
-        if (p.vec_front == 1 && fc == 8 && direct_ok &&
+        const bool direct_possible = rows_aligned && p.vec_front != 2 && forced != 1 && fc == 8 &&
             (p.cpt == 4 || (p.cpt == 8 && ((uintptr_t)scores & 15u) == 0 && p.score_stride % 8u == 0 &&
-                            p.score_stride >= ((n_scores + 7u) & ~7u))))
-            p.vec_front = 3;
+                            p.score_stride >= ((n_scores + 7u) & ~7u)));
+        if (direct_possible && direct_ok && p.vec_front == 1) p.vec_front = 3;
+        // Column-range ownership (round 4, topk_colrange.cuh): a workgroup gathers the selected pages of ITS range of
+        // columns -- no rank scan, no page-list hand-off after the threshold is known.  Needs more than one workgroup per
+        // head (a lone workgroup has nothing to divide: the slot form serves batches planned at one workgroup per head)
+        // and a range a wave covers with 4 (first-generation ownership) or 8 (second) columns per lane.  Front ends
+        // forced to 1 / 2 / 3 keep the slot-ownership variants (tests compare the page lists of all of them);
+        // QUEST_COLRANGE=0 (with QUEST_TUNING=1) turns it off for A/B runs.
+        static const int colrange_env = [] { const char* e = quest_tuning_env("QUEST_COLRANGE"); return e ? atoi(e) : 1; }();
+        if (colrange_env && (forced == 0 || forced == 4) && h->n_chunks >= 2 && kv.page_size == 16 && waves == 8) {
+            const uint32_t rl = ((n_scores + h->n_chunks - 1) / h->n_chunks + 3u) & ~3u;
+            if (direct_possible && rl <= (uint32_t)kColRangeMax) p.vec_front = 4;
+            else if (p.vec_front == 2 && (fc == 16 || fc == 24 || fc == 32) && rl <= 2u * (uint32_t)kColRangeMax) p.vec_front = 5;
+        }
+        p.chunks_inv = (uint32_t)(0x100000000ull / h->n_chunks) + 1u;  // (n_chunks == 1: unused)
+        p.table_vec = table_vec ? 1u : 0u;
     }
     return 0;
 }

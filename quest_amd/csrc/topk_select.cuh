@@ -27,7 +27,7 @@ struct TopkSmem {
     uint32_t wave_tot[2][NT / kWave];  // one row per block scan, so a scan needs a single barrier
     uint32_t wave_mm[NT / kWave];      // per wave: (max key << 16) | (0xffff - min key)
     uint32_t wave_lb[NT / kWave];      // per wave: a key that at least ceil(k / waves) of the wave's keys reach (fe2 pre-filter)
-    uint32_t misc[4];                  // thr_bin, above, T, need_eq
+    uint32_t misc[8];                  // thr_bin, above, T, need_eq (topk_select); + bin word, T, need, lower counts (topk_colrange.cuh)
 };
 
 // Packed (max, 0xffff - min) of 16-bit keys: one v_pk_max_u16 combines both halves.

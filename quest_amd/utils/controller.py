@@ -237,10 +237,15 @@ class BatchedInferenceController:
         self._dense_handler = None
         self.kv_tables = self.meta_tables = self.step_states = None
         self.state_epoch = 0
-        self.page_budgets = None      # optional int32 [n_seqs] device tensor (set_page_budgets)
+        # per-sequence page budgets: ONE persistent int32 [n_seqs] device buffer (a captured graph holds its address),
+        # rewritten in place by set_page_budgets; kNoBudget = "the planned budget" (the kernels clamp to the plan)
+        self._budget_buf = None
+        self.page_budgets = None      # the buffer once set_page_budgets has been called with a list, else None
         self._host_budgets = None
+        self._graph_budget_ptr = 0    # what begin_graph_decode planned with: 0 = no per-sequence budgets
         self.topk_dout_buffer = self.topk_dindices_buffer = None
         self._planned = None
+        self._graph_planned = 0       # budget begin_graph_decode planned for (0: no graph plan)
 
     # ---- per-sequence page budgets + eager (host-planned) batched steps.  The reference keeps one controller and one
     # page budget per request and loops over requests in Python (controller.py:39-41, :80-129: five list -> tensor
@@ -250,13 +255,29 @@ class BatchedInferenceController:
         """Pages each sequence attends per step INCLUDING its current page (None: the constructor's budget for all).
         A sequence with fewer pages than its budget attends all of them."""
         if budgets is None:
+            if self._graph_budget_ptr:
+                # a captured step reads the buffer: "no per-sequence budget" = the sentinel, in place
+                self._budget_buf.fill_(self.kNoBudget)
+                self._host_budgets = None
+                return
             self.page_budgets = self._host_budgets = None
             return
         budgets = [int(x) for x in budgets]
         if len(budgets) != self.n_seqs or min(budgets) < 1:
             raise ValueError("one page budget >= 1 per sequence")
+        if self._graph_planned and not self._graph_budget_ptr:
+            raise RuntimeError("per-sequence budgets set after begin_graph_decode() planned without them: a captured "
+                               "graph would ignore them; call set_page_budgets() before begin_graph_decode()")
+        if self._graph_planned and max(budgets) > self._graph_planned:
+            raise RuntimeError(f"budget {max(budgets)} exceeds the {self._graph_planned} pages the captured plan was "
+                               "made for; call begin_graph_decode() (and re-capture) after raising budgets")
         self._host_budgets = budgets
-        self.page_budgets = torch.tensor(budgets, dtype=torch.int32, device=self.device)
+        if self._budget_buf is None:
+            self._budget_buf = torch.empty(self.n_seqs, dtype=torch.int32, device=self.device)
+        self._budget_buf.copy_(torch.tensor(budgets, dtype=torch.int32))
+        self.page_budgets = self._budget_buf
+
+    kNoBudget = 2 ** 31 - 1
 
     def max_page_budget(self) -> int:
         return max(self._host_budgets) if self._host_budgets is not None else self._page_budget
@@ -273,7 +294,9 @@ class BatchedInferenceController:
             self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
                                                self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
             self._planned = budget
-            k = max(budget - 1, 1)
+        # keyed on the buffers' WIDTH, not on _planned: begin_graph_decode plans without allocating them
+        k = max(budget - 1, 1)
+        if self.topk_dout_buffer is None or self.topk_dout_buffer.size(2) != k:
             self.topk_dout_buffer = torch.zeros(self.n_seqs, self.num_heads, k, dtype=self.dtype, device=self.device)
             self.topk_dindices_buffer = torch.zeros(self.n_seqs, self.num_heads, k, dtype=torch.int32, device=self.device)
         self.inference_page_budget = budget
@@ -293,12 +316,26 @@ class BatchedInferenceController:
             c.prepare_metadata(seq_len)
 
     def enable_device_state(self) -> None:
-        self.kv_tables = torch.stack([c.kv_cache.full_device_table() for c in self.seqs]).contiguous()
-        self.meta_tables = torch.stack([c.metadata_cache.full_device_table() for c in self.seqs]).contiguous()
+        self.kv_tables = self._stack_tables([c.kv_cache.full_device_table() for c in self.seqs])
+        self.meta_tables = self._stack_tables([c.metadata_cache.full_device_table() for c in self.seqs])
         self.max_pages = self.kv_tables.size(1)
         self.step_states = torch.zeros(self.n_seqs, 8, dtype=torch.int32, device=self.device)
         self.state_epoch += 1
         self.sync_device_state()
+
+    @staticmethod
+    def _stack_tables(tables) -> torch.Tensor:
+        """``[n_seqs, capacity]`` view of a buffer whose rows are padded to a multiple of 4 entries: every sequence's
+        table then starts 16-byte aligned, which the fused attention launch needs to fetch 4 page ids with one load
+        (a stride of exactly `capacity` entries -- 2055, 2065, 2179 in the bench -- made every batched launch take the
+        scalar-load front end).  The pad entries repeat the row's last page and are never indexed."""
+        cap = tables[0].numel()
+        stride = (cap + 3) // 4 * 4
+        buf = torch.empty(len(tables), stride, dtype=torch.int32, device=tables[0].device)
+        for row, t in zip(buf, tables):
+            row[:cap] = t
+            row[cap:] = t[-1]
+        return buf[:, :cap]
 
     def sync_device_state(self) -> None:
         rows = []
@@ -316,6 +353,9 @@ class BatchedInferenceController:
         budget = min(self.max_page_budget(), self.max_pages)
         self.inference_page_budget = budget
         self._planned = budget
+        # what a graph captured after this call bakes in: the plan's page count and whether the launches read budgets
+        self._graph_planned = budget
+        self._graph_budget_ptr = self.page_budgets.data_ptr() if self.page_budgets is not None else 0
         self._decode_handler.set_batch(self.n_seqs)
         self._decode_handler.begin_forward(torch.tensor([0, budget - 1], dtype=torch.int32), self.num_heads,
                                            self.num_kv_heads, self.head_dim, self.page_size, self.dtype)
@@ -330,4 +370,5 @@ class BatchedInferenceController:
         for c in self.seqs:
             c.clean_states()
         self.kv_tables = self.meta_tables = self.step_states = None
+        self._graph_planned, self._graph_budget_ptr = 0, 0  # graphs over the dropped state are stale anyway
         self.state_epoch += 1

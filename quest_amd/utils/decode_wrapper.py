@@ -65,6 +65,9 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def plan_info(self):
         return self._wrapper.plan_info()
 
+    def last_launch_info(self) -> dict:
+        return self._wrapper.last_launch_info()
+
     def set_pages_per_chunk(self, ppc: int) -> None:
         self._wrapper.set_pages_per_chunk(ppc)
 

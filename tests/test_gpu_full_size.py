@@ -127,13 +127,18 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     qu.step_advance_dyn(ctl)
     o2 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
     ctl._decode_handler.set_selection_out(None, None)
+    # the launch bench.py --config 4 times: column-range ownership on the long-row (granule) threshold phase
+    info = ctl._decode_handler.last_launch_info()
+    assert (info["front_end_variant"], info["waves"], info["specialised"]) == (5, 8, True), info
     assert ctl.step_state.cpu().tolist()[:3] == [L, n_pages, PAGE]
     assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est))
     assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
     torch.testing.assert_close(o2[0].float(), o_ref, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
-    # the same step (the append is idempotent) without and with the histogram pre-filter of the long-row front end
-    # (csrc/topk_bitmap.cuh; the default above is "with"): same pages, same bits
+    # the same step (the append is idempotent) through the slot-ownership form of the long-row front end, without and
+    # with its histogram pre-filter (csrc/topk_bitmap.cuh): same page lists; the outputs agree with each other bit for
+    # bit and with the column-range launch above within the fp32 merge-order bound (a different workgroup split)
+    o_slot = None
     for gen in (2, 3):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl._decode_handler.set_front_end(gen)
@@ -143,7 +148,10 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
         o3 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, qu.score_scratch(ctl).zero_())
         ctl._decode_handler.set_selection_out(None, None)
         assert torch.equal(sel_i2, sel_i), f"front end {gen}: page lists differ"
-        assert torch.equal(o3, o2), f"front end {gen}"
+        assert ctl._decode_handler.last_launch_info()["front_end_variant"] == 2
+        torch.testing.assert_close(o3.float(), o2.float(), rtol=2e-3, atol=2e-3)
+        o_slot = o3 if o_slot is None else o_slot
+        assert torch.equal(o3, o_slot), f"front end {gen}"
     ctl._decode_handler.set_front_end(0)
     ctl.end_forward()
 
@@ -190,6 +198,10 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
     qu.step_advance_batched(b)
     o = qu.decode_layer_batched(q, k1, v1, b, 0, scores)
     b._decode_handler.set_selection_out(None, None)
+    # the launch bench.py --config 5 times: one workgroup per head, staging arrays fed by vector loads (needs the
+    # stacked page tables' rows 16-byte aligned: BatchedInferenceController pads the stride to a multiple of 4)
+    info = b._decode_handler.last_launch_info()
+    assert (info["keys_per_thread"], info["waves"], info["front_end_variant"], info["specialised"]) == (8, 8, 1, True), info
     # the same step through the other front-end generation (the append is idempotent): same pages, same bits
     states_after = b.step_states.clone()
     b.step_states[:, 0] -= 1   # seq_len
@@ -229,6 +241,143 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
         last = c.kv_cache.indicies[-1]
         slot = (L - 1) % PAGE
         assert torch.equal(b.kv_layer(0)[last, 0, slot], ks[i][-1]) and torch.equal(b.kv_layer(0)[last, 1, slot], vs[i][-1])
+
+
+def _prefill(ctl, k, v):
+    import quest_amd.utils as qu
+
+    L = k.shape[0]
+    ctl.prepare_metadata(L - 1)
+    ctl.begin_forward(L - 1)
+    qu.append_kv(k[:-1], v[:-1], ctl, 0)
+    ctl.end_forward()
+
+
+def test_cfg3_headline_on_the_timed_path():
+    """BASELINE configs[2] (the headline: Hq = Hkv = 32, D = 128, L = 32768, budget 2048 tokens = 128 pages) through the
+    launches bench.py TIMES -- device-resident step state, `step_advance_dyn` + `decode_layer_dyn`, pool capacity of the
+    bench's default run (2179 pages -> 8 keys per thread, 8-wave workgroups, 16 per head) -- against the oracle: pools,
+    page scores, selected pages (ids + values) bit-exact, attention within 5e-3 of fp32 torch over the selected tokens
+    and 2e-3 of the eager fused launch.  Asserts the launch IS sparse_decode_kernel<128,16,8,8,4> (column-range
+    ownership) and that the slot-ownership front end selects the same pages."""
+    import quest_amd.utils as qu
+
+    L, H, B = 32768, 32, 128
+    n_pages = L // PAGE
+    g = torch.Generator(device=DEV).manual_seed(3)
+    k = torch.randn(L, H, D, generator=g, device=DEV, dtype=torch.float16)
+    v = torch.randn(L, H, D, generator=g, device=DEV, dtype=torch.float16)
+    q = torch.randn(1, H, D, generator=g, device=DEV, dtype=torch.float16)
+    ctl = qu.InferenceController(1, H, D, PAGE, B, L + 2084, torch.float16, torch.device(DEV), shuffle_seed=33)
+    _prefill(ctl, k, v)
+    # eager fused launches (host-planned entry points) first: they leave the cache at L tokens
+    ctl.prepare_metadata(1)
+    ctl.begin_forward(1)
+    est = qu.decode_append_estimate(q, k[-1:], v[-1:], ctl, 0)
+    o_eager = qu.decode_topk_sparse_attn(q, est, ctl, 0, write_topk=True)
+    assert ctl._decode_handler.last_launch_info()["front_end_variant"] == 4
+    ctl.end_forward()
+    kp = k.view(n_pages, PAGE, H, D)
+    meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]
+    assert torch.equal(meta[:, 0].reshape(-1, H, D)[:n_pages], kp.amax(1))
+    assert torch.equal(meta[:, 1].reshape(-1, H, D)[:n_pages], kp.amin(1))
+    kv_table = list(ctl.kv_cache.indicies)
+    e_est, ev, ei = _expected(q.cpu().numpy(), ctl.metadata_cache.buf_layer(0).cpu().numpy(), ctl.metadata_cache.indicies,
+                              ctl.metadata_cache.last_page_len, kv_table, B)
+    assert np.array_equal(U16(est.cpu().numpy()), U16(e_est))
+    assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
+    assert np.array_equal(U16(ctl.topk_dout_buffer.cpu().numpy()), U16(ev))
+    o_ref = _torch_attention(q[0], k, v, _logical(kv_table, ei), L)
+    torch.testing.assert_close(o_eager[0].float(), o_ref, rtol=5e-3, atol=5e-3)
+
+    # ---- the timed path: rewind one token on the device state and decode it again (the append is idempotent)
+    ctl.enable_device_state()
+    assert ctl.max_pages == 2179
+    st = ctl.step_state.cpu().tolist()
+    assert st[:3] == [L, n_pages, PAGE]
+    st[0] -= 1
+    st[2] -= 1
+    ctl.begin_graph_decode()
+    outs = {}
+    for gen in (0, 1):
+        ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
+        ctl._decode_handler.set_front_end(gen)
+        sel_v = torch.zeros(1, H, B - 1, dtype=torch.float16, device=DEV)
+        sel_i = torch.full((1, H, B - 1), -1, dtype=torch.int32, device=DEV)
+        ctl._decode_handler.set_selection_out(sel_v, sel_i)
+        scores = qu.score_scratch(ctl).zero_()
+        qu.step_advance_dyn(ctl)
+        o = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
+        ctl._decode_handler.set_selection_out(None, None)
+        info = ctl._decode_handler.last_launch_info()
+        # forced generation 1 = the slot-ownership front end with scalar-load staging, in the generic kernel
+        assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": 4 if gen == 0 else 0,
+                        "specialised": gen == 0, "workgroups_per_head": 16, "n_seqs": 1}, info
+        assert ctl.step_state.cpu().tolist()[:4] == [L, n_pages, PAGE, kv_table[-1]]
+        assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est)), "page scores"
+        assert np.array_equal(sel_i[0].cpu().numpy(), ei), f"front end {gen}: selected pages"
+        assert np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev)), f"front end {gen}: selected values"
+        torch.testing.assert_close(o[0].float(), o_ref, rtol=5e-3, atol=5e-3)
+        torch.testing.assert_close(o.float(), o_eager.float(), rtol=2e-3, atol=2e-3)
+        outs[gen] = o
+    ctl._decode_handler.set_front_end(0)
+    assert torch.equal(outs[0], o_eager)  # eager and state-driven column-range launches: same ranges, same bits
+    meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]
+    assert torch.equal(meta[:, 0].reshape(-1, H, D)[:n_pages], kp.amax(1))
+    assert torch.equal(meta[:, 1].reshape(-1, H, D)[:n_pages], kp.amin(1))
+    last, slot = kv_table[-1], (L - 1) % PAGE
+    assert torch.equal(ctl.kv_cache.buf_layer(0)[last, 0, slot], k[-1]) and torch.equal(ctl.kv_cache.buf_layer(0)[last, 1, slot], v[-1])
+
+
+@pytest.mark.parametrize("extra_tokens,stride", [(280, 2068), (264, 2068), (328, 2072)])
+def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride):
+    """The `batched_8seq` side measurement of bench.py (8 x cfg-3 MHA sequences, one launch per op) through its timed
+    entry points at the bench's own pool capacities -- 2066 / 2065 / 2069 pages per sequence, none a multiple of 4, which
+    used to push every batched launch onto the scalar-load front end: the stacked tables' stride is padded, the
+    launch is the vector-fed one-variant kernel, and results match the oracle per sequence."""
+    import quest_amd.utils as qu
+
+    n, H, B, L = 8, 32, 128, 32768
+    dev = torch.device(DEV)
+    b = qu.BatchedInferenceController(n, 1, H, D, PAGE, B, L + extra_tokens, torch.float16, dev, shuffle_seed=77)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    lens = [L, L - 1, L, L - 13, L, L, L - 8, L]
+    ks, vs = [], []
+    for c, Li in zip(b.seqs, lens):
+        k = torch.randn(Li, H, D, generator=g, device=DEV, dtype=torch.float16)
+        v = torch.randn(Li, H, D, generator=g, device=DEV, dtype=torch.float16)
+        _prefill(c, k, v)
+        ks.append(k)
+        vs.append(v)
+    q = torch.randn(n, H, D, generator=g, device=DEV, dtype=torch.float16)
+    k1 = torch.stack([k[-1] for k in ks])
+    v1 = torch.stack([v[-1] for v in vs])
+    b.enable_device_state()
+    assert b.kv_tables.stride(0) == stride and b.kv_tables.size(1) % 4 != 0
+    b.begin_graph_decode()
+    sel_v = torch.zeros(n, H, B - 1, dtype=torch.float16, device=DEV)
+    sel_i = torch.full((n, H, B - 1), -1, dtype=torch.int32, device=DEV)
+    b._decode_handler.set_selection_out(sel_v, sel_i)
+    scores = qu.score_scratch(b).zero_()
+    qu.step_advance_batched(b)
+    o = qu.decode_layer_batched(q, k1, v1, b, 0, scores)
+    b._decode_handler.set_selection_out(None, None)
+    info = b._decode_handler.last_launch_info()
+    assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": 1, "specialised": True,
+                    "workgroups_per_head": 1, "n_seqs": 8}, info
+    b.prepare_metadata(1)
+    meta_np = b.metadata_layer(0).cpu().numpy()
+    for i, (c, Li) in enumerate(zip(b.seqs, lens)):
+        n_pages = (Li + PAGE - 1) // PAGE
+        kv_table = list(c.kv_cache.indicies)
+        e_est, ev, ei = _expected(q[i:i + 1].cpu().numpy(), meta_np, c.metadata_cache.indicies,
+                                  c.metadata_cache.last_page_len, kv_table, B)
+        assert np.array_equal(U16(scores[i, :, : n_pages - 1].cpu().numpy()), U16(e_est)), f"sequence {i}: scores"
+        assert np.array_equal(sel_i[i].cpu().numpy(), ei), f"sequence {i}: selected pages"
+        assert np.array_equal(U16(sel_v[i].cpu().numpy()), U16(ev))
+        if extra_tokens == 280 or i < 2:  # the fp32 reference of every sequence once; two per further capacity
+            o_ref = _torch_attention(q[i], ks[i], vs[i], _logical(kv_table, ei), Li)
+            torch.testing.assert_close(o[i].float(), o_ref, rtol=5e-3, atol=5e-3)
 
 
 def test_cfg2_longchat_4096_tokens_budget_512_pages_full_kv():

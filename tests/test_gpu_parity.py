@@ -391,7 +391,8 @@ def test_cfg3_full_size_properties():
                                                        (8, 8, 128, 16, 200, 9000, 0), (4, 2, 128, 16, 300, 40000, 0)])
 def test_fused_equals_unfused(Hq, Hkv, D, page, B, L, layout):
     """append+estimate in one launch and top-k+attention in one launch must reproduce the separate
-    ops bit for bit (pools, scores, selected pages) and the attention output exactly as well."""
+    ops bit for bit (pools, scores, selected pages) and the attention output exactly as well -- except where the fused
+    launch runs the column-range front end (rows beyond 1024 pages), whose work split differs: <= 2e-3 there."""
     qu = _qu()
     q, k, v = inputs(900 + Hq + D + page + B, L, Hq, Hkv, D)
     outs = []
@@ -408,6 +409,7 @@ def test_fused_equals_unfused(Hq, Hkv, D, page, B, L, layout):
         if fused:
             est = qu.decode_append_estimate(qc, kc[-1:], vc[-1:], ctl, 0)
             o = qu.decode_topk_sparse_attn(qc, est, ctl, 0)
+            variant = ctl._decode_handler.last_launch_info()["front_end_variant"]
         else:
             qu.append_kv(kc[-1:], vc[-1:], ctl, 0)
             est = qu.decode_estimate(qc, ctl, 0)
@@ -423,7 +425,12 @@ def test_fused_equals_unfused(Hq, Hkv, D, page, B, L, layout):
     assert np.array_equal(U16(a[0]), U16(b[0])), "scores"
     assert np.array_equal(a[1], b[1]), "selected pages"
     assert np.array_equal(U16(a[2]), U16(b[2])), "selected values"
-    assert np.array_equal(U16(a[3]), U16(b[3])), "attention output"
+    if variant in (4, 5):
+        # column-range ownership (rows beyond 1024 pages): the same page SET per head, folded in a different workgroup
+        # split than the index-list launch's slot chunks -> fp32 merge order differs (csrc/topk_colrange.cuh)
+        np.testing.assert_allclose(a[3].astype(np.float32), b[3].astype(np.float32), rtol=2e-3, atol=2e-3)
+    else:
+        assert np.array_equal(U16(a[3]), U16(b[3])), "attention output"
     # pools: compare only valid entries (the tail of the last page / last metadata page is uninitialised)
     from _harness import gather_entries
     for x, y, n in ((a[4], b[4], L), (a[5], b[5], a[6])):

@@ -135,6 +135,10 @@ def test_shared_pool_reservation_and_batched_controller_host_logic():
         c.prepare_metadata(100 + 16 * i)
     bc.enable_device_state()
     assert bc.kv_tables.shape == (3, 13) and bc.meta_tables.shape == (3, 1) and bc.max_pages == 13
+    # rows padded to a multiple of 4 entries: every sequence's table starts 16-byte aligned (vector loads of page ids in
+    # the fused attention launch); the views keep the true capacity as their width
+    assert bc.kv_tables.stride(0) == 16 and bc.meta_tables.stride(0) == 4 and bc.kv_tables.stride(1) == 1
+    assert all((bc.kv_tables.data_ptr() + 4 * 16 * i) % 16 == 0 for i in range(3))
     rows = bc.kv_tables.tolist()
     assert len({p for r in rows for p in r}) == 39  # disjoint reservations cover the pool
     st = bc.step_states.tolist()
@@ -144,6 +148,52 @@ def test_shared_pool_reservation_and_batched_controller_host_logic():
     assert [c.kv_cache.seqlen for c in bc.seqs] == [101, 117, 133]
     with pytest.raises(ValueError):
         BatchedInferenceController(0, 1, 4, 128, 16, 5, 200, torch.float16, "cpu")
+
+
+def test_batched_controller_budgets_and_graph_plan(monkeypatch):
+    """(1) per-sequence budgets live in ONE persistent device buffer (a captured graph holds its address), new
+    budgets are copied in place, and budgets a captured plan cannot honour are refused instead of silently ignored;
+    (2) an eager begin_forward() after begin_graph_decode() with the same budget still allocates the top-k buffers."""
+    import quest_amd.utils.controller as ctl_mod
+
+    class _Stub:
+        def __init__(self, kv_layout="NHD"):
+            self.planned = []
+
+        def set_batch(self, n):
+            pass
+
+        def begin_forward(self, indptr, hq, hkv, d, s, dt):
+            self.planned.append(indptr.tolist()[1])
+
+    monkeypatch.setattr(ctl_mod, "BatchDecodeWithPagedKVCacheWrapper", _Stub)
+    bc = ctl_mod.BatchedInferenceController(3, 1, 4, 128, 16, 5, 400, torch.float16, "cpu")
+    for c in bc.seqs:
+        c.prepare_metadata(300)
+    bc.enable_device_state()
+    bc.set_page_budgets([3, 5, 4])
+    buf = bc.page_budgets
+    assert buf.tolist() == [3, 5, 4] and bc.max_page_budget() == 5
+    bc.begin_graph_decode()
+    assert bc._decode_handler.planned == [4]
+    bc.set_page_budgets([2, 2, 5])
+    assert bc.page_budgets is buf and buf.tolist() == [2, 2, 5]  # same storage: a captured graph sees the new values
+    with pytest.raises(RuntimeError, match="exceeds"):
+        bc.set_page_budgets([2, 2, 6])  # beyond the captured plan
+    bc.set_page_budgets(None)  # "no per-sequence budget" for a graph that reads the buffer = the sentinel, in place
+    assert bc.page_budgets is buf and buf.tolist() == [bc.kNoBudget] * 3 and bc.max_page_budget() == 5
+    # eager step after a graph plan with the same budget: the top-k buffers must exist (they used to stay None)
+    bc.begin_forward()
+    assert bc.topk_dout_buffer.shape == (3, 4, 4) and bc.topk_dindices_buffer.dtype == torch.int32
+    assert bc._decode_handler.planned == [4]  # same budget: not re-planned
+
+    bc2 = ctl_mod.BatchedInferenceController(2, 1, 4, 128, 16, 5, 400, torch.float16, "cpu")
+    for c in bc2.seqs:
+        c.prepare_metadata(300)
+    bc2.enable_device_state()
+    bc2.begin_graph_decode()  # planned WITHOUT per-sequence budgets: the captured launches pass no budget pointer
+    with pytest.raises(RuntimeError, match="before begin_graph_decode"):
+        bc2.set_page_budgets([3, 3])
 
 
 def test_controller_budget_logic(monkeypatch):
@@ -348,7 +398,10 @@ def test_round3_entry_points_validate_arguments_without_gpu():
     assert lib.quest_decode_handler_create(ctypes.byref(h), 0) == 0
     assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, one, 10, 4, None, None, None, None) == -1
     assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, None, 10, 16, None, None, None, None) == -1
-    assert lib.quest_decode_set_front_end(h, 3) == 0 and lib.quest_decode_set_front_end(h, 4) == -1
+    assert lib.quest_decode_set_front_end(h, 4) == 0 and lib.quest_decode_set_front_end(h, 5) == -1
+    info = (ctypes.c_uint32 * 6)()
+    assert lib.quest_decode_last_launch_info(h, info) == 0 and list(info) == [0] * 6  # nothing launched yet
+    assert lib.quest_decode_last_launch_info(None, info) == -1
     lib.quest_decode_handler_destroy(h)
     # fused decoder-layer launches
     assert lib.quest_decode_norm_gemv(None, None, 0.0, one, one, 64, 8, None) == -1
