@@ -48,5 +48,55 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def kernel_metadata(lib_path: str = LIB):
+    """Code-object metadata of every kernel in the built library: {mangled name: {vgpr, vgpr_spill, scratch, lds, sgpr,
+    code_bytes}} (clang-offload-bundler + llvm-readelf from the ROCm LLVM; no GPU needed).  Used by
+    scripts/kernel_meta.py and by the CPU test that guards the headline kernels' resources."""
+    import re
+    import tempfile
+
+    llvm = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    notes, syms = "", ""
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")  # one offload bundle per source file, concatenated in .hip_fatbin
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat])
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), blob)]
+        for i, st in enumerate(starts):
+            part, co = os.path.join(d, f"b{i}.bin"), os.path.join(d, f"k{i}.co")
+            open(part, "wb").write(blob[st:(starts[i + 1] if i + 1 < len(starts) else len(blob))])
+            subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+            notes += subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", co], text=True)
+            syms += subprocess.check_output([f"{llvm}/llvm-readelf", "-sW", co], text=True)
+    size = {}
+    for line in syms.splitlines():
+        f = line.split()
+        if len(f) >= 8 and f[3] == "FUNC":
+            size[f[7]] = int(f[2])
+    keys = {"group_segment_fixed_size": "lds", "private_segment_fixed_size": "scratch", "sgpr_count": "sgpr",
+            "vgpr_count": "vgpr", "vgpr_spill_count": "vgpr_spill"}
+    rows, cur = [], None
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2).strip()
+        if k == "agpr_count":  # first key of a kernel's record
+            cur = {}
+        elif cur is not None and k in keys:
+            cur[keys[k]] = int(v)
+        elif cur is not None and k == "symbol":
+            cur["symbol"] = v.strip("'").replace(".kd", "")
+        elif cur is not None and k == "wavefront_size":  # last key
+            rows.append(cur)
+            cur = None
+    out = {}
+    for r in rows:  # keyed by the MANGLED name (GNU c++filt does not know _Float16; template arguments read ILi<n>E...)
+        r["code_bytes"] = size.get(r["symbol"], 0)
+        out[r["symbol"]] = r
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -230,11 +230,33 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
 // Gather of the slots [slot_begin, slot_end) of one head by the NW waves of a workgroup + the workgroup's result: slot s
 // is the listed page page_of(s) for s < n_listed, the sequence's current page (p.last_page_idx, p.last_page_len rows)
 // otherwise.  Writes o (one workgroup per head) or the workgroup's partial state.
+// (The kernel parameters it needs travel BY VALUE in AttendArgs, built field by field by the caller: handing the
+// callers' modified copy of DecodeParams over by reference left a 32-byte slice of it in memory, which the compiler then
+// "promoted" to LDS -- 16 KiB per workgroup, one workgroup per CU instead of two, 24 us instead of 12 at cfg 3.)
+struct AttendArgs {
+    const half_t* kv;
+    PoolStrides st;
+    uint32_t group, last_page_len;
+    int32_t last_page_idx;
+    uint32_t page_size, n_chunks, ws_stride;
+    float scale_log2;
+    float* lse;
+};
+__device__ __forceinline__ AttendArgs attend_args(const DecodeParams& p) {
+    AttendArgs a;
+    a.kv = p.kv;
+    a.st.page = p.st.page, a.st.v_off = p.st.v_off, a.st.head = p.st.head, a.st.entry = p.st.entry;
+    a.group = p.group, a.last_page_len = p.last_page_len, a.last_page_idx = p.last_page_idx;
+    a.page_size = p.page_size, a.n_chunks = p.n_chunks, a.ws_stride = p.ws_stride;
+    a.scale_log2 = p.scale_log2;
+    a.lse = p.lse;
+    return a;
+}
 template <int D, int S_T, int NW, typename PageOf>
-__device__ __forceinline__ void attend_slots(const DecodeParams& p, const SeqView& sv, const half8 q_raw, const uint32_t chunk,
+__device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView sv, const half8 q_raw, const uint32_t chunk,
                                              const uint32_t hq, const uint32_t slot_begin, const uint32_t slot_end,
                                              const uint32_t n_listed, const int wave, const int lane,
-                                             PageOf&& page_of QUEST_TL_PARAM) {
+                                             PageOf page_of QUEST_TL_PARAM) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
     const int row = lane / LPR, col = lane % LPR;
     RowState<D> st;
@@ -617,7 +639,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         }  // n > 0
     }
     const int32_t* idx_row = sv.indices + (size_t)hq * p.idx_stride;  // uniform
-    attend_slots<D, S_T, NW>(p, sv, q_raw, chunk, hq, slot_begin, slot_end, p.n_sel, wave, lane, [&](uint32_t slot) -> int32_t {
+    attend_slots<D, S_T, NW>(attend_args(p), sv, q_raw, chunk, hq, slot_begin, slot_end, p.n_sel, wave, lane, [&](uint32_t slot) -> int32_t {
         if constexpr (FC > 0) return s_sel[slot - slot_begin];
         else return idx_row[slot];
     } QUEST_TL_ARG);
@@ -694,8 +716,12 @@ __device__ __forceinline__ void sparse_decode_colrange_body(DecodeParams p, cons
     const uint32_t gc0 = rs + 4u * (uint32_t)lane;
     ColRangeRaw graw[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-        graw[g] = colrange_issue(srow, sv.indices, n_cap + 1u, n_cap, gc0 + (uint32_t)(g * kColRangeMax), p.table_vec != 0);
+    for (int g = 0; g < NG; ++g) {
+        graw[g].k = make_uint2(0u, 0u);
+        graw[g].ids = make_uint4(0u, 0u, 0u, 0u);
+        if (g == 0 || (uint32_t)(g * kColRangeMax) < rl)  // block-uniform: NG covers the longest row of the instantiation
+            graw[g] = colrange_issue(srow, sv.indices, n_cap + 1u, n_cap, gc0 + (uint32_t)(g * kColRangeMax), p.table_vec != 0);
+    }
     const bool last_chunk = chunk + 1u == p.n_chunks;
     uint32_t n_listed = 0;
     if (n > 0) {  // block-uniform; a one-page sequence has only its current page
@@ -720,11 +746,11 @@ __device__ __forceinline__ void sparse_decode_colrange_body(DecodeParams p, cons
         }
         QUEST_STAMP(4);
         const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
-        n_listed = colrange_collect<NG>(cs, graw, gc0, re, s_list, wave == 0, p.sel_idx_out ? p.sel_idx_out + out_row : nullptr,
+        n_listed = colrange_collect<NG>(cs, graw, gc0, rl, re, s_list, wave == 0, p.sel_idx_out ? p.sel_idx_out + out_row : nullptr,
                                     p.sel_val_out ? p.sel_val_out + out_row : nullptr);
         QUEST_STAMP(5);
     }
-    attend_slots<D, 16, NW>(p, sv, q_raw, chunk, hq, 0u, n_listed + (last_chunk ? 1u : 0u), n_listed, wave, lane,
+    attend_slots<D, 16, NW>(attend_args(p), sv, q_raw, chunk, hq, 0u, n_listed + (last_chunk ? 1u : 0u), n_listed, wave, lane,
                             [&](uint32_t slot) -> int32_t { return s_list[slot]; } QUEST_TL_ARG);
 #ifdef QUEST_TIMELINE
     QUEST_STAMP(9);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(QUEST_
     uint32_t hq = blockIdx.y;
     if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (a_num_qo_heads / p.xcd_period) + hq / p.xcd_period;
     if constexpr (VF == 4) sparse_decode_colrange_body<D, FC, NW, 1, 1>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
-    else if constexpr (VF == 5) sparse_decode_colrange_body<D, FC, NW, 2, 2>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+    else if constexpr (VF == 5) sparse_decode_colrange_body<D, FC, NW, 2, FC / 8>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
 }
 
@@ -643,7 +643,9 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         if (colrange_env && (forced == 0 || forced == 4) && h->n_chunks >= 2 && kv.page_size == 16 && waves == 8) {
             const uint32_t rl = ((n_scores + h->n_chunks - 1) / h->n_chunks + 3u) & ~3u;
             if (direct_possible && rl <= (uint32_t)kColRangeMax) p.vec_front = 4;
-            else if (p.vec_front == 2 && (fc == 16 || fc == 24 || fc == 32) && rl <= 2u * (uint32_t)kColRangeMax) p.vec_front = 5;
+            // (second-generation ownership: fc / 8 granules of 4 columns per lane, i.e. rl <= 32 fc -- what 16 workgroups
+            // per head need at the instantiation's longest row)
+            else if (p.vec_front == 2 && (fc == 16 || fc == 24 || fc == 32) && rl <= (uint32_t)(fc / 8) * (uint32_t)kColRangeMax) p.vec_front = 5;
         }
         p.chunks_inv = (uint32_t)(0x100000000ull / h->n_chunks) + 1u;  // (n_chunks == 1: unused)
         p.table_vec = table_vec ? 1u : 0u;

@@ -303,13 +303,13 @@ __device__ __forceinline__ ColRangeRaw colrange_issue(const uint16_t* srow, cons
 }
 
 // Every wave for itself: which of the range's columns are selected -- a lane holds NG granules of 4 columns, granule g
-// at gc0 + 256 g, bounded by col_end; the selected columns' page ids go to list[0 .. count) in column order (all waves
+// at gc0 + 256 g, rounds below range_len, columns bounded by col_end; the selected columns' page ids go to list[0 .. count) in column order (all waves
 // write the same values to the same words: a wave's reads follow its own writes in program order, so no barrier is
 // needed).  Returns the count (wave-uniform).  sel_idx_row / sel_val_row: optional global rows of the head's selection
 // (inspection aid), written by the wave(s) with write_out.
 template <int NG>
 __device__ __forceinline__ uint32_t colrange_collect(const ColRangeSel& cs, const ColRangeRaw (&raw)[NG], uint32_t gc0,
-                                                     uint32_t col_end, int32_t* list, bool write_out,
+                                                     uint32_t range_len, uint32_t col_end, int32_t* list, bool write_out,
                                                      int32_t* sel_idx_row, uint16_t* sel_val_row) {
     // ties still to be taken when this granule round's columns begin (signed: lower columns may have used them up)
     int allowed0 = (int)cs.need - (int)cs.eq_lower;
@@ -318,6 +318,7 @@ __device__ __forceinline__ uint32_t colrange_collect(const ColRangeSel& cs, cons
     uint32_t base = 0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+        if (g > 0 && (uint32_t)(g * kColRangeMax) >= range_len) break;  // block-uniform: rounds beyond the live range
         const uint32_t k01 = half_key2(raw[g].k.x), k23 = half_key2(raw[g].k.y);
         const uint32_t kk[4] = {k01 & 0xffffu, k01 >> 16, k23 & 0xffffu, k23 >> 16};
         const uint32_t id[4] = {raw[g].ids.x, raw[g].ids.y, raw[g].ids.z, raw[g].ids.w};
