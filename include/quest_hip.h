@@ -318,6 +318,10 @@ int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_
  * instantiation was launched (0: the generic kernel), workgroups per head, sequences}.  Tests and benches assert with it
  * that they run the kernel they mean to. */
 int quest_decode_last_launch_info(const quest_decode_handler_t* h, uint32_t info[6]);
+/* Developer aid: the handler's partial-state workspace ([sequences][heads][workgroups per head][record_floats] fp32:
+ * acc[head_dim], m, d, spare).  Builds with -DQUEST_WALLSTAMPS leave per-workgroup wall-clock stamps in the spare words
+ * (scripts/wallstamps.py). */
+int quest_decode_debug_workspace(const quest_decode_handler_t* h, void** ptr, uint64_t* bytes, uint32_t* record_floats);
 /* Measurement aid: with skip != 0, quest_decode_forward* launch only the attention kernel and leave the
  * per-workgroup partial states in the handler's workspace (the output tensor is NOT written when the plan has
  * more than one workgroup per head).  Lets a bench time the dominant kernel by itself. */
@@ -328,11 +332,12 @@ int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
  * the plan] (rows of a sequence still shorter than the budget are filled up to its live page count).  NULL
  * pointers turn it off.  Not an entry the reference has: its top-k output lives in topk_filtering's tensors. */
 int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int32_t* idx_out);
-/* Which top-k front end the fused launches use: 0 = automatic (default: column-range ownership, csrc/topk_colrange.cuh,
- * where a head has several 8-wave workgroups and aligned score rows; otherwise by row length), 1 = first generation
+/* Which top-k front end the fused launches use: 0 = automatic (by row length and alignment), 1 = first generation
  * (csrc/topk_select.cuh; rows up to 4096 pages), 2 = second generation (csrc/topk_bitmap.cuh; needs 8-byte aligned
  * score rows) without its histogram pre-filter, 3 = second generation with the pre-filter, 4 = column-range ownership
- * also on rows short enough for 4-wave workgroups (tests).  1-3 are the slot-ownership variants.  All implement the same
+ * (csrc/topk_colrange.cuh; where a head has several workgroups and aligned score rows -- 8-wave workgroups also on
+ * short rows; built in round 4, measured slower than slot ownership, kept for A/B runs and tests), 5 = as 0 (A/B runs
+ * under QUEST_COLRANGE=1).  0-3 and 5 are slot ownership.  All implement the same
  * selection: bit-identical page SETS and (inspection) lists; the column-range variants fold a head's pages in a
  * different workgroup split, so outputs differ from the others' by fp32 merge order (tests: <= 2e-3).  Tuning / test aid. */
 int quest_decode_set_front_end(quest_decode_handler_t* h, int generation);

@@ -82,6 +82,8 @@ SIGNATURES = {
     "quest_decode_forward_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_vp, Batch, c_vp, c_vp]),
     "quest_decode_set_batch": (ctypes.c_int, [c_vp, c_u32]),
     "quest_decode_plan_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32), ctypes.POINTER(c_u32)]),
+    "quest_decode_debug_workspace": (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(ctypes.c_uint64),
+                                                    ctypes.POINTER(c_u32)]),
     "quest_decode_last_launch_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_u32)]),
     "quest_decode_set_pages_per_chunk": (ctypes.c_int, [c_vp, c_u32]),
     "quest_decode_set_skip_merge": (ctypes.c_int, [c_vp, ctypes.c_int]),

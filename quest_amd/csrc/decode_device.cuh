@@ -20,6 +20,20 @@
 #define QUEST_TL_ARG
 #endif
 
+// Developer aid (scripts/wallstamps.py): -DQUEST_WALLSTAMPS makes EVERY workgroup of the fused launches leave four
+// wall-clock stamps (100 MHz, chip-wide: kernel entry, page list known, wave 0's pages folded, partial written) and its
+// page count in the spare floats of its partial-state record -- the distribution over the 512 workgroups of a launch in
+// the cold regime the bench measures, which the one-workgroup cycle timeline above cannot show.
+#ifdef QUEST_WALLSTAMPS
+#define QUEST_WS_PARAM , const unsigned ws_entry, const unsigned ws_fe
+#define QUEST_WS_ARG , ws_entry, (unsigned)wall_clock64()
+#define QUEST_WS_ENTRY const unsigned ws_entry = (unsigned)wall_clock64();
+#else
+#define QUEST_WS_PARAM
+#define QUEST_WS_ARG
+#define QUEST_WS_ENTRY
+#endif
+
 namespace quest {
 
 // K/V tile loads of the per-head-list kernel: streaming (`nt`) by default; -DQUEST_KV_CACHED keeps them in the L2's normal
@@ -256,7 +270,7 @@ template <int D, int S_T, int NW, typename PageOf>
 __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView sv, const half8 q_raw, const uint32_t chunk,
                                              const uint32_t hq, const uint32_t slot_begin, const uint32_t slot_end,
                                              const uint32_t n_listed, const int wave, const int lane,
-                                             PageOf page_of QUEST_TL_PARAM) {
+                                             PageOf page_of QUEST_TL_PARAM QUEST_WS_PARAM) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
     const int row = lane / LPR, col = lane % LPR;
     RowState<D> st;
@@ -335,6 +349,9 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
     }
 
     QUEST_STAMP(6);
+#ifdef QUEST_WALLSTAMPS
+    const unsigned ws_gather = (unsigned)wall_clock64();
+#endif
     // rows of the wave -> one state (xor butterfly across rows; both partners get the same bits)
     for_each_row_distance<LPR>([&](auto off_c) {
         constexpr int OFF = decltype(off_c)::value;
@@ -382,6 +399,13 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
             if (f == 0) {
                 w[D] = M;
                 w[D + 1] = den;
+#ifdef QUEST_WALLSTAMPS
+                if (p.ws_stride >= (uint32_t)D + 8u) {
+                    unsigned* u = reinterpret_cast<unsigned*>(w + D + 2);
+                    u[0] = ws_entry, u[1] = ws_fe, u[2] = ws_gather, u[3] = (unsigned)wall_clock64();
+                    u[4] = slot_end > slot_begin ? slot_end - slot_begin : 0u;
+                }
+#endif
             }
         }
     }
@@ -419,6 +443,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
     const long long wall0 = wall_clock64();
     QUEST_STAMP(0);
 #endif
+    QUEST_WS_ENTRY
     const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
     // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
     // row length comes from the state
@@ -642,7 +667,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
     attend_slots<D, S_T, NW>(attend_args(p), sv, q_raw, chunk, hq, slot_begin, slot_end, p.n_sel, wave, lane, [&](uint32_t slot) -> int32_t {
         if constexpr (FC > 0) return s_sel[slot - slot_begin];
         else return idx_row[slot];
-    } QUEST_TL_ARG);
+    } QUEST_TL_ARG QUEST_WS_ARG);
 #ifdef QUEST_TIMELINE
     QUEST_STAMP(9);
     if (p.lse && chunk == p.n_chunks / 2 && hq == num_qo_heads / 2 && seq == 0 && threadIdx.x == 0) {
@@ -677,6 +702,7 @@ __device__ __forceinline__ void sparse_decode_colrange_body(DecodeParams p, cons
 #else
     long long* const sub = nullptr;
 #endif
+    QUEST_WS_ENTRY
     const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
     const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);  // first used after the selection
     __shared__ TopkSmem<NT> sm;
@@ -751,7 +777,7 @@ __device__ __forceinline__ void sparse_decode_colrange_body(DecodeParams p, cons
         QUEST_STAMP(5);
     }
     attend_slots<D, 16, NW>(attend_args(p), sv, q_raw, chunk, hq, 0u, n_listed + (last_chunk ? 1u : 0u), n_listed, wave, lane,
-                            [&](uint32_t slot) -> int32_t { return s_list[slot]; } QUEST_TL_ARG);
+                            [&](uint32_t slot) -> int32_t { return s_list[slot]; } QUEST_TL_ARG QUEST_WS_ARG);
 #ifdef QUEST_TIMELINE
     QUEST_STAMP(9);
     if (p.lse && chunk == p.n_chunks / 2 && hq == num_qo_heads / 2 && seq == 0 && threadIdx.x == 0) {

@@ -326,7 +326,7 @@ extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) 
 }
 
 extern "C" int quest_decode_set_front_end(quest_decode_handler_t* h, int generation) {
-    if (!h || generation < 0 || generation > 4) return QUEST_EINVAL;
+    if (!h || generation < 0 || generation > 5) return QUEST_EINVAL;
     h->front_end = generation;
     return 0;
 }
@@ -417,6 +417,14 @@ extern "C" int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t*
     if (!h || !h->started) return QUEST_ESTATE;
     if (pages_per_chunk) *pages_per_chunk = h->pages_per_chunk;
     if (chunks_per_head) *chunks_per_head = h->n_chunks;
+    return 0;
+}
+
+extern "C" int quest_decode_debug_workspace(const quest_decode_handler_t* h, void** ptr, uint64_t* bytes, uint32_t* record_floats) {
+    if (!h || !ptr || !bytes) return QUEST_EINVAL;
+    *ptr = h->ws;
+    *bytes = h->ws_bytes;
+    if (record_floats) *record_floats = h->ws_stride;
     return 0;
 }
 
@@ -555,7 +563,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
     p.vec_front = 0;
     int forced = 0;
-    bool table_vec = false, rows_aligned = false;
+    bool table_vec = false, rows_aligned = false, no_colrange = false;
     if (fused) {
         // second-generation front end (topk_bitmap.cuh): 8-byte loads of 4 scores straight from the row -> the rows
         // must be 8-byte aligned and readable up to the next multiple of 4 columns (the row stride covers it)
@@ -566,6 +574,8 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         // quest_decode_set_front_end / QUEST_FRONT_END=1 / 2 force a generation where it is applicable (tuning, tests).
         static const int env_forced = [] { const char* e = quest_tuning_env("QUEST_FRONT_END"); return e ? atoi(e) : 0; }();
         forced = h->front_end ? h->front_end : env_forced;
+        no_colrange = forced == 5;  // 5 = automatic choice among the slot-ownership variants
+        if (no_colrange) forced = 0;
         const uint32_t stride = p.score_stride;
         const bool aligned = ((uintptr_t)scores & 7u) == 0 && stride % 4u == 0 && stride >= ((n_scores + 3u) & ~3u);
         const bool table_aligned = ((uintptr_t)kv.indices & 15u) == 0 && (batch.n_seqs == 1 || batch.kv_table_stride % 4u == 0);
@@ -634,13 +644,17 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
                             p.score_stride >= ((n_scores + 7u) & ~7u)));
         if (direct_possible && direct_ok && p.vec_front == 1) p.vec_front = 3;
         // Column-range ownership (round 4, topk_colrange.cuh): a workgroup gathers the selected pages of ITS range of
-        // columns -- no rank scan, no page-list hand-off after the threshold is known.  Needs more than one workgroup per
-        // head (a lone workgroup has nothing to divide: the slot form serves batches planned at one workgroup per head)
-        // and a range a wave covers with 4 (first-generation ownership) or 8 (second) columns per lane.  Front ends
-        // forced to 1 / 2 / 3 keep the slot-ownership variants (tests compare the page lists of all of them);
-        // QUEST_COLRANGE=0 (with QUEST_TUNING=1) turns it off for A/B runs.
-        static const int colrange_env = [] { const char* e = quest_tuning_env("QUEST_COLRANGE"); return e ? atoi(e) : 1; }();
-        if (colrange_env && (forced == 0 || forced == 4) && h->n_chunks >= 2 && kv.page_size == 16 && waves == 8) {
+        // columns -- no rank scan, no page-list hand-off after the threshold is known.  Built, parity-green, and measured
+        // SLOWER than slot ownership (us per launch, same box: cfg 3 13.27 vs 12.07; cfg 4 20.34 vs 19.54; with 16-wave
+        // workgroups 15.1 vs 13.3): the page list is known 0.7 us earlier (3.06 vs 3.78 us after kernel entry) but a
+        // range of 128 columns holds 8 +- 2.7 selected pages, a CU's two workgroups 16 +- 3.9, and the gather is bound by
+        // what ONE CU can have in flight: waves with two pages finish 2.4 us after waves with one, the last data of the
+        // launch arrives 7.2 us after the first request instead of 5.7 (profiles/r04_wallstamps_cfg3_*.log).  Exact slot
+        // ownership puts the same 8 pages on every workgroup.  So: OFF by default; quest_decode_set_front_end(h, 4)
+        // (or QUEST_TUNING=1 QUEST_COLRANGE=1) selects it where it is applicable -- more than one workgroup per head
+        // and a range a wave covers with 4 (first-generation threshold phase) or fc / 2 (second) columns per lane.
+        static const int colrange_env = [] { const char* e = quest_tuning_env("QUEST_COLRANGE"); return e ? atoi(e) : 0; }();
+        if ((forced == 4 || (colrange_env && forced == 0 && !no_colrange)) && h->n_chunks >= 2 && kv.page_size == 16 && waves == 8) {
             const uint32_t rl = ((n_scores + h->n_chunks - 1) / h->n_chunks + 3u) & ~3u;
             if (direct_possible && rl <= (uint32_t)kColRangeMax) p.vec_front = 4;
             // (second-generation ownership: fc / 8 granules of 4 columns per lane, i.e. rl <= 32 fc -- what 16 workgroups

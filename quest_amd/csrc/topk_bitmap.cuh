@@ -68,10 +68,14 @@ __device__ __forceinline__ void fe2_issue(const uint16_t* srow, const int32_t* t
 // Zero the histograms (overlaps the loads; the first barrier of fe2_select publishes it).
 template <int NT>
 __device__ __forceinline__ void fe2_clear(TopkSmem<NT>& sm) {
-    static_assert(kBins1 % (4 * NT) == 0, "one or more 16-byte stores per thread");
+    if constexpr (4 * NT > kBins1) {  // 1024 threads: the first half clears
+        if (threadIdx.x < kBins1 / 4) reinterpret_cast<uint4*>(sm.hist1)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        static_assert(kBins1 % (4 * NT) == 0, "one or more 16-byte stores per thread");
 #pragma unroll
-    for (int v = 0; v < kBins1 / (4 * NT); ++v)
-        reinterpret_cast<uint4*>(sm.hist1)[threadIdx.x + v * NT] = make_uint4(0u, 0u, 0u, 0u);
+        for (int v = 0; v < kBins1 / (4 * NT); ++v)
+            reinterpret_cast<uint4*>(sm.hist1)[threadIdx.x + v * NT] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (threadIdx.x < kBins2) sm.hist2[threadIdx.x] = 0;
 }
 

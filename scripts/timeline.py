@@ -37,7 +37,7 @@ ctl.begin_forward(1)
 est = [qu.decode_estimate(w.q[l], ctl, l) for l in range(a.layers)]
 names = ["entry", "loads issued+hist cleared", "scores arrived, keys in LDS", "barrier", "topk_select done",
          "page list in LDS (barrier)", "all K/V folded", "row butterfly + LDS write", "barrier", "partial written"]
-h = ctl._decode_handler._wrapper
+h = ctl._decode_handler
 # state-driven twin of the same sequence (8-wave workgroups, lengths from the device state)
 a2 = bench.parse(cfg_args)
 a2.mode, a2.layers = "graph", a.layers
@@ -49,24 +49,26 @@ for l in range(a.layers):
     _kernels.append_estimate_dyn(w2.k1[l], w2.v1[l], c2.kv_cache.buf_layer(l), c2.kv_table_full, w2.q[l], sc2[l],
                                  c2.metadata_cache.buf_layer(l), c2.meta_table_full, c2.step_state, c2.max_pages - 1,
                                  c2.layout)
-h2 = c2._decode_handler._wrapper
-for fused in (("dyn",) if a.seqlen > 65536 else ("dyn", True, False)):
+h2 = c2._decode_handler
+variants = ("dyn",) if a.seqlen > 65536 else ("dyn", "dyn-slots", True, False)
+for fused in variants:
     acc = torch.zeros(a.layers * 4, 32, device=dev)
     for rep in range(4):
         for l in range(a.layers):
             lse = acc[rep * a.layers + l]
             q = w.q[l]
             o = torch.empty_like(q)
-            if fused == "dyn":
+            if fused in ("dyn", "dyn-slots"):
+                h2.set_front_end(0 if fused == "dyn" else 5)
                 kv = _kernels._paged(c2.kv_cache.buf_layer(l), c2.kv_table_full, None, 1, 0, c2.layout)
-                check(lib.quest_decode_forward_fused_topk_dyn(h2._h, w2.q[l].data_ptr(), o.data_ptr(), kv, q.size(1),
+                check(lib.quest_decode_forward_fused_topk_dyn(h2._wrapper._h, w2.q[l].data_ptr(), o.data_ptr(), kv, q.size(1),
                                                               sc2[l].data_ptr(), sc2[l].size(1), c2.max_pages - 1,
                                                               c2.step_state.data_ptr(), lse.data_ptr(),
                                                               torch.cuda.current_stream().cuda_stream), "dyn")
             elif fused:
                 kv = _kernels._paged(ctl.kv_cache.buf_layer(l), ctl.kv_indices_with_last, None, ctl.kv_cache.last_page_len,
                                      ctl.kv_last_page_idx, ctl.layout)
-                check(lib.quest_decode_forward_fused_topk(h._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), est[l].data_ptr(),
+                check(lib.quest_decode_forward_fused_topk(h._wrapper._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), est[l].data_ptr(),
                                                           est[l].size(1), None, None, lse.data_ptr(),
                                                           torch.cuda.current_stream().cuda_stream), "fused")
             else:
@@ -74,16 +76,31 @@ for fused in (("dyn",) if a.seqlen > 65536 else ("dyn", True, False)):
                 idx = ctl.topk_dindices_buffer
                 kv = _kernels._paged(ctl.kv_cache.buf_layer(l), idx, None, ctl.kv_cache.last_page_len,
                                      ctl.kv_last_page_idx, ctl.layout, page_budget=idx.size(1))
-                check(lib.quest_decode_forward(h._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), lse.data_ptr(),
+                check(lib.quest_decode_forward(h._wrapper._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), lse.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream), "plain")
     torch.cuda.synchronize()
     t = acc[a.layers:].cpu().median(dim=0).values  # skip the first (cold) round
     cyc_per_us = float(t[9] / (t[10] / 100.0)) if t[10] > 0 else float("nan")
-    print(f"== {'state-driven fused front end' if fused == 'dyn' else 'fused top-k front end' if fused else 'index list from memory (FC = 0)'}: "
+    label = {"dyn": "state-driven, default front end", "dyn-slots": "state-driven, slot-ownership front end (forced)",
+             True: "host-planned fused launch", False: "index list from memory (FC = 0)"}[fused]
+    info = (h2 if fused in ("dyn", "dyn-slots") else h).last_launch_info()
+    print(f"== {label}: variant {info['front_end_variant']}, {info['workgroups_per_head']} workgroups per head; "
           f"{cyc_per_us:.0f} cycles/us, workgroup lifetime {float(t[9]) / cyc_per_us:.2f} us")
+    if info["front_end_variant"] in (4, 5):
+        cn = ["entry", "own keys arrived + converted", "range published", "barrier", "threshold known",
+              "page list built (per wave)", "all K/V folded", "row butterfly + LDS write", "barrier", "partial written"]
+        for i, nme in enumerate(cn):
+            print(f"  {float(t[i]) / cyc_per_us:6.2f} us  {nme}")
+        print(f"      pages of this workgroup: {float(t[11]):.0f}")
+        sn = (["hist atomics issued", "barrier", "bins read + summed", "block scan", "threshold bin published (barrier)",
+               "hist2 + barrier", "exact T + barrier"] if info["front_end_variant"] == 4 else
+              ["keys + range published", "barrier A", "hist atomics issued", "barrier B", "threshold (per wave)"])
+        for i, nme in enumerate(sn):
+            print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  {nme}")
+        continue
     for i, nme in enumerate(names):
         print(f"  {float(t[i]) / cyc_per_us:6.2f} us  {nme}")
-    if fused == "dyn":
+    if fused == "dyn" and False:
         subn = ["keys + range published", "barrier A", "hist atomics issued", "barrier B", "threshold (per wave)",
                 "bitmaps written", "barrier D", "ranks scanned", "-"]
         for i, nme in enumerate(subn[:8]):

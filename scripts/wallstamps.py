@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Per-workgroup wall-clock stamps of the fused top-k + attention launch in the regime the bench measures (a hipGraph of
+one launch per layer, each on its own pool: cold caches).  Builds a -DQUEST_WALLSTAMPS variant of the library, loads it
+via QUEST_HIP_LIB, replays the graph and reads the stamps every workgroup of the LAST layer's launch left in its
+partial-state record.
+
+    python scripts/wallstamps.py --build            (here, cross-compiles)
+    python scripts/wallstamps.py [--front-end N]    (on the GPU box; N = quest_decode_set_front_end value, default 0)
+"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VARIANT = os.path.join(ROOT, "quest_amd", "libquest_hip_wallstamps.so")
+
+if "--build" in sys.argv:
+    from quest_amd.build import build_variant
+    print(build_variant(VARIANT, ["-DQUEST_WALLSTAMPS"]))
+    sys.exit(0)
+
+os.environ["QUEST_HIP_LIB"] = VARIANT
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from quest_amd._lib import check, lib  # noqa: E402
+
+fe = int(sys.argv[sys.argv.index("--front-end") + 1]) if "--front-end" in sys.argv else 0
+cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "3"
+ppc = int(sys.argv[sys.argv.index("--ppc") + 1]) if "--ppc" in sys.argv else 0
+a = bench.parse(["--config", cfg, "--steps", "300"] + (["--pages-per-chunk", str(ppc)] if ppc else []))
+dev = torch.device("cuda", 0)
+w = bench.Workload(a, dev)
+ctl = w.ctl
+from quest_amd import _kernels  # noqa: E402
+
+h = ctl._decode_handler
+h.set_front_end(fe)
+max_n = ctl.max_pages - 1
+bench_q = w.q
+o = [w.q[l].clone() for l in range(a.layers)]
+w.qu.step_advance_dyn(ctl)
+for l in range(a.layers):  # fill the score scratch of... (one scratch: the last layer's scores stay)
+    _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
+                                 ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n, ctl.layout)
+
+
+def layer(l):  # the step's pair of launches (the scores must be this layer's)
+    _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
+                                 ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n, ctl.layout)
+    h.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores, ctl.step_state, max_n)
+
+
+h.set_skip_merge(True)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for l in range(a.layers):
+        layer(l)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    for l in range(a.layers):
+        layer(l)
+info = h.last_launch_info()
+ptr, nbytes, rec = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32()
+check(lib.quest_decode_debug_workspace(h._wrapper._h, ctypes.byref(ptr), ctypes.byref(nbytes), ctypes.byref(rec)), "ws")
+hip = ctypes.CDLL("libamdhip64.so")
+H, C, R, D = a.heads, info["workgroups_per_head"], rec.value, a.head_dim
+host = np.empty(H * C * R, np.float32)
+rows = []
+for rep in range(12):
+    g.replay()
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), ptr, ctypes.c_size_t(host.nbytes), 2) == 0
+    u = host.view(np.uint32).reshape(H, C, R)[:, :, D + 2:D + 7].astype(np.int64)
+    if rep >= 2:
+        rows.append(u.copy())
+print(f"== cfg {cfg}, front end {fe}: variant {info['front_end_variant']}, {info['waves']} waves, {C} workgroups per head "
+      f"(last layer's launch, {len(rows)} replays; 10 ns ticks -> us)")
+for name, fn in (("kernel span (last end - first entry)", lambda u, t0: (u[..., 3].max() - t0)),
+                 ("entry of the last workgroup to start", lambda u, t0: (u[..., 0].max() - t0)),
+                 ("median page list known", lambda u, t0: np.median(u[..., 1] - t0)),
+                 ("  latest page list known", lambda u, t0: (u[..., 1].max() - t0)),
+                 ("median wave-0 pages folded", lambda u, t0: np.median(u[..., 2] - t0)),
+                 ("  latest wave-0 pages folded", lambda u, t0: (u[..., 2].max() - t0)),
+                 ("median partial written", lambda u, t0: np.median(u[..., 3] - t0))):
+    vals = [fn(u, u[..., 0].min()) * 0.01 for u in rows]
+    print(f"  {name:42s} {np.median(vals):6.2f} us  (min {min(vals):.2f}, max {max(vals):.2f})")
+u = rows[-1]
+t0 = u[..., 0].min()
+end = (u[..., 3] - t0) * 0.01
+pages = u[..., 4]
+fe_t = (u[..., 1] - u[..., 0]) * 0.01
+ga_t = (u[..., 2] - u[..., 1]) * 0.01
+print("  by pages of the workgroup: count, mean front end, mean gather (wave 0), mean end")
+for p in sorted(set(pages.ravel().tolist())):
+    m = pages == p
+    print(f"    {p:3d} pages: {int(m.sum()):4d} workgroups  fe {fe_t[m].mean():5.2f}  gather {ga_t[m].mean():5.2f}  end {end[m].mean():5.2f}  max end {end[m].max():5.2f}")
+order = np.argsort(end.ravel())[::-1][:8]
+print("  last workgroups to finish (head, chunk, pages, entry, page list, folded, end):")
+for i in order:
+    hq, c = divmod(int(i), C)
+    r = u[hq, c]
+    print(f"    ({hq:2d},{c:2d}) {int(r[4]):3d}  {(r[0]-t0)*0.01:5.2f} {(r[1]-t0)*0.01:5.2f} {(r[2]-t0)*0.01:5.2f} {(r[3]-t0)*0.01:5.2f}")

@@ -127,19 +127,20 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     qu.step_advance_dyn(ctl)
     o2 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
     ctl._decode_handler.set_selection_out(None, None)
-    # the launch bench.py --config 4 times: column-range ownership on the long-row (granule) threshold phase
+    # the launch bench.py --config 4 times: second-generation front end (granule ownership + histogram pre-filter), 24
+    # keys per thread, slot ownership
     info = ctl._decode_handler.last_launch_info()
-    assert (info["front_end_variant"], info["waves"], info["specialised"]) == (5, 8, True), info
+    assert (info["keys_per_thread"], info["front_end_variant"], info["waves"], info["specialised"]) == (24, 2, 8, True), info
     assert ctl.step_state.cpu().tolist()[:3] == [L, n_pages, PAGE]
     assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est))
     assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
     torch.testing.assert_close(o2[0].float(), o_ref, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
-    # the same step (the append is idempotent) through the slot-ownership form of the long-row front end, without and
-    # with its histogram pre-filter (csrc/topk_bitmap.cuh): same page lists; the outputs agree with each other bit for
-    # bit and with the column-range launch above within the fp32 merge-order bound (a different workgroup split)
-    o_slot = None
-    for gen in (2, 3):
+    # the same step (the append is idempotent) without and with the histogram pre-filter of the long-row front end
+    # (csrc/topk_bitmap.cuh; the default above is "with"): same pages, same bits; and through the column-range form
+    # (csrc/topk_colrange.cuh, measured slower and therefore not the default): same page lists, outputs within the fp32
+    # merge-order bound (a different workgroup split)
+    for gen in (2, 3, 4):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl._decode_handler.set_front_end(gen)
         sel_i2 = torch.full_like(sel_i, -1)
@@ -148,10 +149,12 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
         o3 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, qu.score_scratch(ctl).zero_())
         ctl._decode_handler.set_selection_out(None, None)
         assert torch.equal(sel_i2, sel_i), f"front end {gen}: page lists differ"
-        assert ctl._decode_handler.last_launch_info()["front_end_variant"] == 2
-        torch.testing.assert_close(o3.float(), o2.float(), rtol=2e-3, atol=2e-3)
-        o_slot = o3 if o_slot is None else o_slot
-        assert torch.equal(o3, o_slot), f"front end {gen}"
+        assert ctl._decode_handler.last_launch_info()["front_end_variant"] == (5 if gen == 4 else 2)
+        if gen == 4:
+            torch.testing.assert_close(o3.float(), o2.float(), rtol=2e-3, atol=2e-3)
+            torch.testing.assert_close(o3[0].float(), o_ref, rtol=5e-3, atol=5e-3)
+        else:
+            assert torch.equal(o3, o2), f"front end {gen}"
     ctl._decode_handler.set_front_end(0)
     ctl.end_forward()
 
@@ -258,8 +261,8 @@ def test_cfg3_headline_on_the_timed_path():
     launches bench.py TIMES -- device-resident step state, `step_advance_dyn` + `decode_layer_dyn`, pool capacity of the
     bench's default run (2179 pages -> 8 keys per thread, 8-wave workgroups, 16 per head) -- against the oracle: pools,
     page scores, selected pages (ids + values) bit-exact, attention within 5e-3 of fp32 torch over the selected tokens
-    and 2e-3 of the eager fused launch.  Asserts the launch IS sparse_decode_kernel<128,16,8,8,4> (column-range
-    ownership) and that the slot-ownership front end selects the same pages."""
+    and 2e-3 of the eager fused launch.  Asserts the launch IS sparse_decode_kernel<128,16,8,8,3> and that the other
+    front ends (column-range ownership, scalar-load staging) select the same pages."""
     import quest_amd.utils as qu
 
     L, H, B = 32768, 32, 128
@@ -275,7 +278,7 @@ def test_cfg3_headline_on_the_timed_path():
     ctl.begin_forward(1)
     est = qu.decode_append_estimate(q, k[-1:], v[-1:], ctl, 0)
     o_eager = qu.decode_topk_sparse_attn(q, est, ctl, 0, write_topk=True)
-    assert ctl._decode_handler.last_launch_info()["front_end_variant"] == 4
+    assert ctl._decode_handler.last_launch_info()["front_end_variant"] == 3
     ctl.end_forward()
     kp = k.view(n_pages, PAGE, H, D)
     meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]
@@ -299,7 +302,7 @@ def test_cfg3_headline_on_the_timed_path():
     st[2] -= 1
     ctl.begin_graph_decode()
     outs = {}
-    for gen in (0, 1):
+    for gen in (0, 4, 1):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl._decode_handler.set_front_end(gen)
         sel_v = torch.zeros(1, H, B - 1, dtype=torch.float16, device=DEV)
@@ -310,9 +313,10 @@ def test_cfg3_headline_on_the_timed_path():
         o = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
         ctl._decode_handler.set_selection_out(None, None)
         info = ctl._decode_handler.last_launch_info()
-        # forced generation 1 = the slot-ownership front end with scalar-load staging, in the generic kernel
-        assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": 4 if gen == 0 else 0,
-                        "specialised": gen == 0, "workgroups_per_head": 16, "n_seqs": 1}, info
+        # 0 = the timed kernel: keys straight into registers, slot ownership; 4 = its column-range twin (measured slower,
+        # not the default); forced generation 1 = scalar-load staging in the generic kernel
+        assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": {0: 3, 4: 4, 1: 0}[gen],
+                        "specialised": gen != 1, "workgroups_per_head": 16, "n_seqs": 1}, info
         assert ctl.step_state.cpu().tolist()[:4] == [L, n_pages, PAGE, kv_table[-1]]
         assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est)), "page scores"
         assert np.array_equal(sel_i[0].cpu().numpy(), ei), f"front end {gen}: selected pages"
@@ -321,7 +325,8 @@ def test_cfg3_headline_on_the_timed_path():
         torch.testing.assert_close(o.float(), o_eager.float(), rtol=2e-3, atol=2e-3)
         outs[gen] = o
     ctl._decode_handler.set_front_end(0)
-    assert torch.equal(outs[0], o_eager)  # eager and state-driven column-range launches: same ranges, same bits
+    assert torch.equal(outs[0], o_eager) and torch.equal(outs[1], o_eager)  # same slot split: same bits
+    assert not torch.equal(outs[4], o_eager)  # column ranges: another split (within 2e-3, asserted above)
     meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]
     assert torch.equal(meta[:, 0].reshape(-1, H, D)[:n_pages], kp.amax(1))
     assert torch.equal(meta[:, 1].reshape(-1, H, D)[:n_pages], kp.amin(1))

@@ -391,8 +391,8 @@ def test_cfg3_full_size_properties():
                                                        (8, 8, 128, 16, 200, 9000, 0), (4, 2, 128, 16, 300, 40000, 0)])
 def test_fused_equals_unfused(Hq, Hkv, D, page, B, L, layout):
     """append+estimate in one launch and top-k+attention in one launch must reproduce the separate
-    ops bit for bit (pools, scores, selected pages) and the attention output exactly as well -- except where the fused
-    launch runs the column-range front end (rows beyond 1024 pages), whose work split differs: <= 2e-3 there."""
+    ops bit for bit (pools, scores, selected pages) and the attention output exactly as well (a launch forced onto the
+    column-range front end, whose work split differs, would be held to <= 2e-3)."""
     qu = _qu()
     q, k, v = inputs(900 + Hq + D + page + B, L, Hq, Hkv, D)
     outs = []
