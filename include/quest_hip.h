@@ -227,6 +227,18 @@ int quest_decode_forward_shared_dyn(quest_decode_handler_t* h, const void* q, vo
                                     uint32_t num_qo_heads, const quest_step_state_t* state, float* lse,
                                     quest_stream_t stream);
 
+/* quest_append_kv_cache_decode_dyn + quest_decode_forward_shared_dyn in ONE launch (round 4: a full-KV layer of a captured
+ * step = attention + merge instead of append + attention + merge; the reference's pair of calls is QuestAttention.py:106
+ * and :125-132 / page.cu:6-99).  k, v: the new token [1][kv heads][head_dim], not yet in the pool: the one workgroup per
+ * kv head that attends the current page takes the row from k / v, writes it to the pool and folds k into the page's
+ * (max, min) metadata entry -- same pool bytes as the separate append.  metadata: the layer's metadata pool (same
+ * geometry as the KV pool; lengths from `state`).  QUEST_EUNSUPPORTED for shapes outside the group-shared kernel
+ * (page_size 16, head_dim 64 / 128): issue the two launches then. */
+int quest_decode_append_forward_shared_dyn(quest_decode_handler_t* h, const void* k, const void* v,
+                                           quest_paged_kv_t metadata, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                           uint32_t num_qo_heads, const quest_step_state_t* state, float* lse,
+                                           quest_stream_t stream);
+
 /* quest_apply_rope_in_place for one decode token with past_kv_len = state->seq_len - 1. */
 int quest_apply_rope_in_place_dyn(void* q, void* k, uint32_t num_qo_heads, uint32_t num_kv_heads, uint32_t head_dim,
                                   float rope_scale, float rope_theta, const quest_step_state_t* state,
@@ -278,6 +290,12 @@ int quest_append_kv_cache_decode_batched(const void* k, const void* v, quest_pag
 int quest_decode_forward_shared_batched(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
                                         uint32_t num_qo_heads, const quest_step_state_t* state, quest_batch_t batch,
                                         float* lse, quest_stream_t stream);
+/* quest_decode_append_forward_shared_dyn for every sequence of the batch (k, v: [n_seqs][kv heads][head_dim]). */
+int quest_decode_append_forward_shared_batched(quest_decode_handler_t* h, const void* k, const void* v,
+                                               quest_paged_kv_t metadata, const void* q, void* o,
+                                               quest_paged_kv_t paged_kv, uint32_t num_qo_heads,
+                                               const quest_step_state_t* state, quest_batch_t batch, float* lse,
+                                               quest_stream_t stream);
 /*
  * The four operators of a decode step one by one for a whole batch (the state-driven counterparts of
  * append_kv_cache_decode / estimate_attn_score / topk_filtering / BatchDecodeWithPagedKVCache.forward, bsk_ops.h:38-116,

@@ -732,6 +732,48 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         check(lib.quest_decode_forward_shared_dyn(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1), state.data_ptr(),
                                                   None, _stream(q)), "BatchDecodeWithPagedKVCache")
 
+    def append_forward_shared_dyn(self, k, v, metadata_data, meta_table, q, o, paged_kv_data, page_table, state) -> bool:
+        """``append_kv_cache_decode_dyn`` + ``forward_shared_dyn`` in ONE launch (the new token's row is taken from k / v
+        by the workgroup that attends the current page, written to the pool and folded into the metadata there).  False
+        when the shape is outside the group-shared kernel: the caller issues the two launches."""
+        for t, n in ((k, "k"), (v, "v"), (metadata_data, "metadata_data"), (meta_table, "meta_table"), (q, "q"), (o, "o"),
+                     (paged_kv_data, "paged_kv_data"), (page_table, "page_table"), (state, "state")):
+            _check_input(t, n)
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        _check_half(k, "BatchDecodeWithPagedKVCache")
+        _check_eq(tuple(k.shape), tuple(v.shape), "k.shape, v.shape")
+        kv = _paged(paged_kv_data, page_table, None, 1, 0, self._layout)
+        _check_eq(tuple(k.shape[-2:]), (kv.num_heads, kv.head_dim), "k.shape[-2:], (kv heads, head_dim)")
+        meta = _paged(metadata_data, meta_table, None, 1, 0, self._layout)
+        code = lib.quest_decode_append_forward_shared_dyn(self._h, k.data_ptr(), v.data_ptr(), meta, q.data_ptr(), o.data_ptr(),
+                                                          kv, q.size(1), state.data_ptr(), None, _stream(q))
+        if code == -2:
+            return False
+        check(code, "BatchDecodeWithPagedKVCache")
+        return True
+
+    def append_forward_shared_batched(self, k, v, metadata_data, meta_tables, q, o, paged_kv_data, kv_tables, state) -> bool:
+        """``append_forward_shared_dyn`` for every sequence of a batch (k, v ``[n, Hkv, D]``)."""
+        for t, n in ((k, "k"), (v, "v"), (metadata_data, "metadata_data"), (q, "q"), (o, "o"),
+                     (paged_kv_data, "paged_kv_data"), (state, "state")):
+            _check_input(t, n)
+        b = _batch(state, kv_tables, meta_tables)
+        _check_dim(3, q, "q")
+        _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+        _check_eq(k.size(0), b.n_seqs, "k.size(0), n_seqs")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        _check_half(k, "BatchDecodeWithPagedKVCache")
+        _check_eq(tuple(k.shape), tuple(v.shape), "k.shape, v.shape")
+        kv = _paged(paged_kv_data, kv_tables, None, 1, 0, self._layout)
+        _check_eq(tuple(k.shape[-2:]), (kv.num_heads, kv.head_dim), "k.shape[-2:], (kv heads, head_dim)")
+        meta = _paged(metadata_data, meta_tables, None, 1, 0, self._layout)
+        code = lib.quest_decode_append_forward_shared_batched(self._h, k.data_ptr(), v.data_ptr(), meta, q.data_ptr(),
+                                                              o.data_ptr(), kv, q.size(1), state.data_ptr(), b, None, _stream(q))
+        if code == -2:
+            return False
+        check(code, "BatchDecodeWithPagedKVCache")
+        return True
+
     def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
         """forward_fused_topk whose row length and current page come from ``state`` (graph replay)."""
         for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (page_table, "page_table"),

@@ -65,6 +65,10 @@ SIGNATURES = {
     "quest_decode_forward_fused_topk_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32, c_vp,
                                                             c_vp, c_vp]),
     "quest_append_kv_cache_decode_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp, c_vp]),
+    "quest_decode_append_forward_shared_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp,
+                                                              c_vp]),
+    "quest_decode_append_forward_shared_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_vp, c_vp, PagedKV, c_u32, c_vp,
+                                                                  Batch, c_vp, c_vp]),
     "quest_decode_forward_shared_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp, c_vp]),
     "quest_apply_rope_in_place_dyn": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, c_vp]),
     "quest_step_state_advance_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, Batch, c_vp]),
@@ -105,11 +109,27 @@ SIGNATURES = {
 }
 
 
+def verify_build(lib_path: str, src_root: str = None) -> None:
+    """Refuse a library that was not built from the sources beside it: the .so is git-ignored and travels prebuilt, so
+    nothing else ties the loaded binary to the code the tests claim to validate.  The library carries build.py's hash of
+    csrc/*, include/quest_hip.h and the compiler flags; recompute and compare.  `QUEST_HIP_LIB=<path>` (tuning builds
+    with extra -D flags) skips the check -- the override is explicit."""
+    from .build import library_hash, source_hash
+
+    have, want = library_hash(lib_path), source_hash(src_root)
+    if have != want:
+        raise ImportError(
+            f"{lib_path} is stale: it was built from sources with hash {have}, the tree has {want}. "
+            "Run `python -m quest_amd.build` (or __graft_entry__.build()).")
+
+
 def _load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m quest_amd.build` "
             "(there is no CPU fallback for the quest_amd operators).")
+    if not os.environ.get("QUEST_HIP_LIB"):
+        verify_build(LIB_PATH, os.environ.get("QUEST_SRC_ROOT") or None)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -22,18 +22,53 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno
          "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
+HASH_TAG = b"quest_hip gfx950 src="  # quest_build_info() = this tag + 16 hex digits (+ " r4")
+
+
+def source_hash(src_root: str = None, extra_flags=()) -> str:
+    """16 hex digits over everything the library is built from: every file under csrc/, include/quest_hip.h, and the
+    compiler flags.  Compiled into the library (-DQUEST_SRC_HASH, returned by quest_build_info()); quest_amd._lib
+    recomputes it at import and refuses a library built from other sources.  `src_root` = a directory holding
+    quest_amd/csrc and include/ (default: this tree)."""
+    import hashlib
+
+    root = src_root or os.path.dirname(HERE)
+    csrc = os.path.join(root, "quest_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cuh", ".h")))
+    files.append(os.path.join(root, "include", "quest_hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+        h.update(b"\0")
+    h.update(" ".join(list(FLAGS) + list(extra_flags)).encode())
+    return h.hexdigest()[:16]
+
+
+def library_hash(lib_path: str = LIB):
+    """The source hash a built library carries (read from the file, nothing is loaded); None if it has none."""
+    try:
+        blob = open(lib_path, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(HASH_TAG)
+    if i < 0:
+        return None
+    h = blob[i + len(HASH_TAG): i + len(HASH_TAG) + 16]
+    return h.decode() if len(h) == 16 and all(c in b"0123456789abcdef" for c in h) else None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    """True when there is no library or it was built from other sources / flags (content hash, not mtimes: the .so is
+    git-ignored and travels prebuilt, so file times say nothing about what it was built from)."""
+    return library_hash(LIB) != source_hash()
 
 
 def build_variant(out_path: str, extra_flags) -> str:
     """Tuning aid: build a second .so with extra -D flags (loaded with QUEST_HIP_LIB=<path>)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out_path])
+    tag = f'-DQUEST_SRC_HASH="{source_hash(extra_flags=extra_flags)}"'
+    subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + [tag] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out_path])
     return out_path
 
 
@@ -41,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + [f'-DQUEST_SRC_HASH="{source_hash()}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -97,6 +97,12 @@ struct DecodeParams {
     // column-range ownership (vec_front 4 / 5, topk_colrange.cuh)
     uint32_t chunks_inv;     // floor(2^32 / n_chunks) + 1: x / n_chunks == mulhi(x, chunks_inv) for the row lengths served
     uint32_t table_vec;      // page table(s) 16-byte aligned: a lane's 4 page ids are one load
+    // decode append folded into the group-shared (full-KV) launch: shared_decode_kernel<.., APPEND = true>
+    const half_t* app_k;     // [n_seqs][kv heads][D]: the new token's key / value, not yet in the pool
+    const half_t* app_v;
+    half_t* app_meta;        // metadata pool of this layer (same layout / page size as the KV pool)
+    uint32_t meta_last_page_len;  // host-planned launches; state-driven ones read both from the step state
+    int32_t meta_last_page_idx;
 };
 
 // leading scalar kernel arguments (preloaded into SGPRs at wave launch) and their hand-over to the struct; a_pack =

@@ -23,6 +23,7 @@
 #include <new>
 #include <vector>
 
+#include "append_device.cuh"
 #include "decode_device.cuh"
 
 namespace quest {
@@ -47,7 +48,14 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(QUEST_
 // fetches each K/V tile once and folds it into GS online-softmax states, instead of once per query head
 // as the per-head-list kernel above would (4x the traffic at Llama-3 GQA).  Same work split, same partial
 // records, same merge kernel.
-template <int D, int GS, int NW>
+//
+// APPEND (round 4): the decode append rides in the same launch.  The reference issues append_kv_cache_decode and the
+// attention as two calls (QuestAttention.py:106 then :125-132, page.cu:6-99); here a dense layer of a captured step was
+// three launches (append, attention, merge).  The new token's row of the current page is touched by exactly ONE
+// workgroup per kv head -- the one whose chunk holds the last slot -- so that workgroup takes the row from the inputs
+// instead of from the pool, writes it to the pool and folds the key into the page's (max, min) metadata entry
+// (append_decode_body's arithmetic, same bits); nobody else reads or writes those bytes during the launch.
+template <int D, int GS, int NW, bool APPEND = false>
 __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
     QUEST_DECODE_HEAD_TAKE(p);
     constexpr int LPR = D / kVec, R = kWave / LPR, S_T = 16, T = (S_T + R - 1) / R;
@@ -61,6 +69,10 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
         p.n_sel = (uint32_t)(st.n_pages - 1);
         p.last_page_len = (uint32_t)st.kv_last_page_len;
         p.last_page_idx = st.kv_last_page_idx;
+        if constexpr (APPEND) {
+            p.meta_last_page_len = (uint32_t)st.meta_last_page_len;
+            p.meta_last_page_idx = st.meta_last_page_idx;
+        }
     }
     const uint32_t n_slots = p.n_sel + 1;
     const uint32_t slot_begin = min(n_slots, chunk * p.pages_per_chunk);
@@ -77,6 +89,32 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
     const uint32_t step = R * p.st.entry;
     RowState<D> st[GS];
 
+    [[maybe_unused]] const size_t app_in_off = ((size_t)blockIdx.z * gridDim.y + hk) * D + col * kVec;
+    if constexpr (APPEND) {
+        // prologue of the ONE wave (per kv head) that will attend the current page: the lanes that hold the new token's
+        // row write it to the pool and fold the key into the page's metadata entry (entry meta_last_page_len - 1 of the
+        // last metadata page; same pool geometry as the KV pool; a token that opens a page starts from the sentinels)
+        const uint32_t e = p.last_page_len - 1u;
+        if (slot_begin <= p.n_sel && p.n_sel < slot_end && (uint32_t)wave == (p.n_sel - slot_begin) % NW &&
+            (uint32_t)row == e % R) {
+            const half8 kn = ld8(p.app_k + app_in_off), vn = ld8(p.app_v + app_in_off);
+            half_t* dst = const_cast<half_t*>(head_base) + (size_t)p.last_page_idx * p.st.page + lane_off + (e / R) * step;
+            st8(dst, kn);
+            st8(dst + p.st.v_off, vn);
+            uint16_t* mmax = reinterpret_cast<uint16_t*>(p.app_meta) + (size_t)p.meta_last_page_idx * p.st.page +
+                             (size_t)hk * p.st.head + (size_t)(p.meta_last_page_len - 1u) * p.st.entry + col * kVec;
+            uint16_t* mmin = mmax + p.st.v_off;
+            ushort8 mx = (ushort8)(kHalfNegMax), mn = (ushort8)(kHalfMax);
+            if (e > 0) {
+                mx = *reinterpret_cast<const ushort8*>(mmax);
+                mn = *reinterpret_cast<const ushort8*>(mmin);
+            }
+            const ushort8 k8 = __builtin_bit_cast(ushort8, kn);
+            *reinterpret_cast<ushort8*>(mmax) = fold_max(mx, k8);
+            *reinterpret_cast<ushort8*>(mmin) = fold_min(mn, k8);
+        }
+    }
+
     for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += NW) {
         const int32_t pg = __builtin_amdgcn_readfirstlane(s0 < p.n_sel ? sv.indices[s0] : p.last_page_idx);
         const int len = s0 < p.n_sel ? S_T : (int)p.last_page_len;
@@ -86,6 +124,20 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
         for (int t = 0; t < T; ++t) {
             k[t] = ld8_stream(b0 + lane_off + t * step);
             v[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
+        }
+        if constexpr (APPEND) {
+            if (s0 >= p.n_sel) {  // wave-uniform: the current page -- its newest row is the token being decoded, which
+                                  // the prologue above wrote to the pool; here it comes from the inputs again (L2-hot)
+                                  // rather than through a same-wave store -> load of the pool bytes
+                const uint32_t e = (uint32_t)len - 1u;
+                const half8 kn = ld8(p.app_k + app_in_off), vn = ld8(p.app_v + app_in_off);
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if ((uint32_t)(t * R + row) == e) {
+                        k[t] = kn;
+                        v[t] = vn;
+                    }
+            }
         }
         float8 kf[T], vf[T];
         bool valid[T];
@@ -694,13 +746,21 @@ template <int D>
 static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t gs,
                          hipStream_t s, uint32_t n_seqs) {
     dim3 grid(p.n_chunks, num_qo_heads / gs, n_seqs), block(4 * kWave);
+#define QUEST_SHARED_CASE(GS)                                                                                                  \
+    case GS:                                                                                                                   \
+        if (p.app_k)                                                                                                           \
+            hipLaunchKernelGGL((shared_decode_kernel<D, GS, 4, true>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((shared_decode_kernel<D, GS, 4, false>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); \
+        break;
     switch (gs) {
-        case 1: hipLaunchKernelGGL((shared_decode_kernel<D, 1, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
-        case 2: hipLaunchKernelGGL((shared_decode_kernel<D, 2, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
-        case 4: hipLaunchKernelGGL((shared_decode_kernel<D, 4, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
-        case 8: hipLaunchKernelGGL((shared_decode_kernel<D, 8, 4>), grid, block, 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p); break;
+        QUEST_SHARED_CASE(1)
+        QUEST_SHARED_CASE(2)
+        QUEST_SHARED_CASE(4)
+        QUEST_SHARED_CASE(8)
         default: return QUEST_EUNSUPPORTED;
     }
+#undef QUEST_SHARED_CASE
     QUEST_LAUNCH_CHECK();
     if (p.n_chunks > 1) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
@@ -710,9 +770,15 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, u
     return 0;
 }
 
+struct SharedAppend {  // optional decode append riding in the group-shared launch
+    const void* k = nullptr;
+    const void* v = nullptr;
+    const quest_paged_kv_t* metadata = nullptr;
+};
+
 static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv, uint32_t num_qo_heads,
                         float* lse, const quest_step_state_t* state, quest_stream_t stream,
-                        quest_batch_t batch = {1, 0, 0, 0}) {
+                        quest_batch_t batch = {1, 0, 0, 0}, SharedAppend app = {}) {
     if (!h || batch.n_seqs == 0) return QUEST_EINVAL;
     if (state) kv.last_page_len = 1;  // placeholder; read from `state` in the kernel
     if (!h->started) return QUEST_ESTATE;
@@ -726,7 +792,7 @@ static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest
         // outside the group-shared kernel's set.  Eager callers get EUNSUPPORTED and pass the per-head index
         // tensor to quest_decode_forward; a state-driven launch has no such tensor, so it runs the per-head-list
         // kernel with every head reading the ONE page table (row stride 0) and the live length from `state`.
-        if (!state) return QUEST_EUNSUPPORTED;
+        if (!state || app.k) return QUEST_EUNSUPPORTED;  // (with an append: the caller issues it as its own launch)
         kv.page_budget = 0;
         return decode_entry(h, q, o, kv, num_qo_heads, nullptr, 0, nullptr, nullptr, lse, (hipStream_t)stream, 0,
                             state, batch);
@@ -750,6 +816,20 @@ static int shared_entry(quest_decode_handler_t* h, const void* q, void* o, quest
     p.ws_stride = h->ws_stride;
     p.state = state;
     p.table_stride = batch.kv_table_stride;
+    if (app.k) {
+        const quest_paged_kv_t& m = *app.metadata;
+        if (!app.v || !m.data) return QUEST_EINVAL;
+        // the append addresses the metadata pool with the KV pool's strides: same geometry required (it is: the
+        // controller builds both from one KvCache class with the same page size, heads, dim and layout)
+        if (m.layout != kv.layout || m.head_dim != kv.head_dim || m.page_size != kv.page_size || m.num_heads != kv.num_heads)
+            return QUEST_EINVAL;
+        if (!state && (m.last_page_len == 0 || m.last_page_len > m.page_size)) return QUEST_EINVAL;
+        p.app_k = (const half_t*)app.k;
+        p.app_v = (const half_t*)app.v;
+        p.app_meta = (half_t*)m.data;
+        p.meta_last_page_len = m.last_page_len;
+        p.meta_last_page_idx = m.last_page_idx;
+    }
     hipStream_t s = (hipStream_t)stream;
     return kv.head_dim == 64 ? launch_shared<64>(h, p, num_qo_heads, p.group, s, batch.n_seqs)
                              : launch_shared<128>(h, p, num_qo_heads, p.group, s, batch.n_seqs);
@@ -765,6 +845,28 @@ extern "C" int quest_decode_forward_shared_dyn(quest_decode_handler_t* h, const 
                                                quest_stream_t stream) {
     if (!state) return QUEST_EINVAL;
     return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream);
+}
+
+extern "C" int quest_decode_append_forward_shared_dyn(quest_decode_handler_t* h, const void* k, const void* v,
+                                                      quest_paged_kv_t metadata, const void* q, void* o, quest_paged_kv_t kv,
+                                                      uint32_t num_qo_heads, const quest_step_state_t* state, float* lse,
+                                                      quest_stream_t stream) {
+    if (!state || !k || !v) return QUEST_EINVAL;
+    SharedAppend app;
+    app.k = k, app.v = v, app.metadata = &metadata;
+    return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream, {1, 0, 0, 0}, app);
+}
+
+extern "C" int quest_decode_append_forward_shared_batched(quest_decode_handler_t* h, const void* k, const void* v,
+                                                          quest_paged_kv_t metadata, const void* q, void* o,
+                                                          quest_paged_kv_t kv, uint32_t num_qo_heads,
+                                                          const quest_step_state_t* state, quest_batch_t batch, float* lse,
+                                                          quest_stream_t stream) {
+    if (!state || !k || !v) return QUEST_EINVAL;
+    if (h && batch.n_seqs > 1 && batch.kv_table_stride < h->n_sel + 1) return QUEST_EINVAL;
+    SharedAppend app;
+    app.k = k, app.v = v, app.metadata = &metadata;
+    return shared_entry(h, q, o, kv, num_qo_heads, lse, state, stream, batch, app);
 }
 
 extern "C" int quest_decode_forward_fused_topk_strided(quest_decode_handler_t* h, const void* q, void* o,
@@ -837,4 +939,9 @@ extern "C" const char* quest_error_string(int code) {
     }
 }
 
-extern "C" const char* quest_build_info(void) { return "quest_hip gfx950 r3"; }
+// "quest_hip gfx950 src=<16 hex digits> r4": the digits are build.py's hash of csrc/*, include/quest_hip.h and the compiler
+// flags; quest_amd/_lib.py recomputes it from the sources at import and refuses a library built from anything else.
+#ifndef QUEST_SRC_HASH
+#define QUEST_SRC_HASH "unhashed-build!!"
+#endif
+extern "C" const char* quest_build_info(void) { return "quest_hip gfx950 src=" QUEST_SRC_HASH " r4"; }

@@ -228,20 +228,22 @@ def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iControl
 
 def decode_layer_dense_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
                            layer_idx: int, rope_scale: Optional[float] = None, rope_theta: Optional[float] = None,
-                           apply_rope: bool = False) -> torch.Tensor:
+                           apply_rope: bool = False, fuse_append: bool = True) -> torch.Tensor:
     """One FULL-KV layer of a decode token, every length read from the device-resident state:
-    [RoPE] -> append -> attention over all pages (group-shared kernel) (+merge).  Needs
-    ``begin_graph_decode(dense_layers=True)``."""
+    [RoPE] -> append + attention over all pages in ONE launch (group-shared kernel; the workgroup that attends the
+    current page takes the new token from k / v, writes it to the pool and folds it into the metadata) (+merge).  Shapes
+    outside the group-shared kernel take the separate append launch.  Needs ``begin_graph_decode(dense_layers=True)``."""
     ctl = iController
     _need_state(ctl)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
-    _kernels.append_kv_cache_decode_dyn(k, v, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full,
-                                        ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, ctl.step_state,
-                                        ctl.layout)
     o = torch.empty_like(q)
-    ctl._dense_handler.forward_shared_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, ctl.step_state)
+    kvb, mb = ctl.kv_cache.buf_layer(layer_idx), ctl.metadata_cache.buf_layer(layer_idx)
+    if not (fuse_append and ctl._dense_handler.append_forward_shared_dyn(k, v, mb, ctl.meta_table_full, q, o, kvb,
+                                                                         ctl.kv_table_full, ctl.step_state)):
+        _kernels.append_kv_cache_decode_dyn(k, v, kvb, ctl.kv_table_full, mb, ctl.meta_table_full, ctl.step_state, ctl.layout)
+        ctl._dense_handler.forward_shared_dyn(q, o, kvb, ctl.kv_table_full, ctl.step_state)
     return o
 
 
@@ -320,15 +322,18 @@ def decode_sparse_attn_batched(q: torch.Tensor, bController: BatchedInferenceCon
 def decode_layer_dense_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                                bController: BatchedInferenceController, layer_idx: int,
                                rope_scale: Optional[float] = None, rope_theta: Optional[float] = None,
-                               apply_rope: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                               apply_rope: bool = False, out: Optional[torch.Tensor] = None,
+                               fuse_append: bool = True) -> torch.Tensor:
     """``decode_layer_dense_dyn`` for every sequence at once (needs ``begin_graph_decode(dense_layers=True)``)."""
     b = bController
     _need_state(b)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_batched(q, k, scale, theta, b.step_states)
-    _kernels.append_kv_cache_decode_batched(k, v, b.kv_layer(layer_idx), b.kv_tables, b.metadata_layer(layer_idx),
-                                            b.meta_tables, b.step_states, b.layout)
     o = torch.empty_like(q) if out is None else out
-    b._dense_handler.forward_shared_batched(q, o, b.kv_layer(layer_idx), b.kv_tables, b.step_states)
+    kvb, mb = b.kv_layer(layer_idx), b.metadata_layer(layer_idx)
+    if not (fuse_append and b._dense_handler.append_forward_shared_batched(k, v, mb, b.meta_tables, q, o, kvb, b.kv_tables,
+                                                                           b.step_states)):
+        _kernels.append_kv_cache_decode_batched(k, v, kvb, b.kv_tables, mb, b.meta_tables, b.step_states, b.layout)
+        b._dense_handler.forward_shared_batched(q, o, kvb, b.kv_tables, b.step_states)
     return o

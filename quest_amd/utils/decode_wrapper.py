@@ -46,6 +46,13 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def forward_shared_dyn(self, q, o, paged_kv_data, page_table, state) -> None:
         self._wrapper.forward_shared_dyn(q, o, paged_kv_data, page_table, state)
 
+    def append_forward_shared_dyn(self, k, v, metadata_data, meta_table, q, o, paged_kv_data, page_table, state) -> bool:
+        return self._wrapper.append_forward_shared_dyn(k, v, metadata_data, meta_table, q, o, paged_kv_data, page_table, state)
+
+    def append_forward_shared_batched(self, k, v, metadata_data, meta_tables, q, o, paged_kv_data, kv_tables, state) -> bool:
+        return self._wrapper.append_forward_shared_batched(k, v, metadata_data, meta_tables, q, o, paged_kv_data, kv_tables,
+                                                           state)
+
     def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
         self._wrapper.forward_fused_topk_dyn(q, o, paged_kv_data, page_table, scores, state, max_n_scores)
 

@@ -49,3 +49,36 @@ def test_streaming_kernels_have_no_scratch(meta):
         assert hits, frag
         for v in hits:
             assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (frag, v)
+
+
+def test_import_refuses_a_library_built_from_other_sources(tmp_path):
+    """the loaded binary is tied to the sources.  A copy of the tree's sources with ONE byte appended
+    to a kernel file must make both `verify_build` and a fresh `import quest_amd._lib` refuse the prebuilt library; the
+    untouched tree loads, and `needs_build()` follows the same hash (not file times)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    from quest_amd import build
+    from quest_amd._lib import verify_build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert build.library_hash(LIB) == build.source_hash() and not build.needs_build()
+    assert build.library_hash(LIB).encode() in __import__("quest_amd._lib", fromlist=["lib"]).lib.quest_build_info()
+    verify_build(LIB)  # the tree as it stands
+    shutil.copytree(os.path.join(root, "quest_amd", "csrc"), tmp_path / "quest_amd" / "csrc")
+    os.makedirs(tmp_path / "include")
+    shutil.copy(os.path.join(root, "include", "quest_hip.h"), tmp_path / "include" / "quest_hip.h")
+    assert build.source_hash(str(tmp_path)) == build.source_hash()
+    with open(tmp_path / "quest_amd" / "csrc" / "decode_device.cuh", "ab") as f:
+        f.write(b" ")
+    assert build.source_hash(str(tmp_path)) != build.source_hash()
+    with pytest.raises(ImportError, match="stale"):
+        verify_build(LIB, str(tmp_path))
+    env = dict(os.environ, QUEST_SRC_ROOT=str(tmp_path), PYTHONPATH=root)
+    env.pop("QUEST_HIP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", "import quest_amd._lib"], env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode != 0 and "stale" in r.stderr, r.stderr[-400:]
+    os.utime(os.path.join(root, "quest_amd", "csrc", "quest_common.cuh"))  # a newer file time alone is not a change
+    assert not build.needs_build()

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _harness import cuda, inputs, make_controller
+from _harness import cuda, inputs, make_controller, oracle_pools, pools_match
 
 pytestmark = pytest.mark.gpu
 PAGE = 16
@@ -405,3 +405,52 @@ def test_stale_decode_graph_is_refused_after_quest_clear():
     second = generate(20)  # same prompt, same weights: same tokens, same physical pages in the same order
     assert second == first
     assert list(m.model.iController.kv_cache.indicies) == order_1
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,layout,L0", [(8, 8, 128, 0, 70), (8, 2, 128, 1, 33), (4, 1, 64, 0, 16 * 17), (16, 2, 128, 0, 300),
+                                                 (32, 32, 128, 0, 4096 - 5)])
+def test_dense_layer_with_the_append_folded_into_the_attention_launch(Hq, Hkv, D, layout, L0):
+    """A full-KV layer of a captured step is TWO launches (attention with the decode append folded in + merge) instead of
+    three: same KV pool bytes, same metadata bytes and the same output bits as the separate append launch followed by the
+    attention launch, token after token across page boundaries (tokens that open a KV page start its metadata entry from
+    the sentinels) and metadata-page boundaries; MHA and GQA, both layouts; and both match the oracle's pools."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    page, steps = 16, 2 * 16 + 5
+    _, k0, v0 = inputs(31 + Hq + L0, L0, Hq, Hkv, D)
+    g = torch.Generator(device=dev).manual_seed(7)
+    new_q = torch.randn(steps, 1, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    def prefilled():
+        ctl = make_controller(L0 + steps + 2 * page, Hq, Hkv, D, page, 1 << 20, layout=layout, shuffle_seed=3,
+                              max_seq_len=L0 + steps + 2 * page)
+        ctl.prepare_metadata(L0)
+        ctl.begin_forward(L0)
+        qu.append_kv(cuda(k0), cuda(v0), ctl, 0)
+        ctl.end_forward()
+        ctl.enable_device_state()
+        ctl.begin_graph_decode(dense_layers=True)
+        return ctl
+
+    two, three = prefilled(), prefilled()
+    for t in range(steps):
+        outs = []
+        for ctl, fuse in ((two, True), (three, False)):
+            qu.step_advance_dyn(ctl)
+            outs.append(qu.decode_layer_dense_dyn(new_q[t], new_k[t], new_v[t], ctl, 0, fuse_append=fuse))
+            ctl.prepare_metadata(1)
+        assert torch.equal(outs[0], outs[1]), f"token {t}: output bits"
+    assert torch.equal(two.step_state, three.step_state)
+    L = L0 + steps
+    k_all = np.concatenate([k0, new_k[:, 0].cpu().numpy()])
+    v_all = np.concatenate([v0, new_v[:, 0].cpu().numpy()])
+    kv_o, meta_o = oracle_pools(two, k_all, v_all)
+    assert pools_match(two, kv_o, meta_o, L) and pools_match(three, kv_o, meta_o, L)
+    # the fused launch really took the group-shared kernel (one launch + merge): its handler never saw a per-head list
+    kvp = two.kv_cache.buf_layer(0)[torch.as_tensor(two.kv_cache.indicies, device=dev).long()]
+    kvq = three.kv_cache.buf_layer(0)[torch.as_tensor(three.kv_cache.indicies, device=dev).long()]
+    n_full = (L // page) if L % page == 0 else (L // page)
+    assert torch.equal(kvp[:n_full], kvq[:n_full])
