@@ -18,6 +18,7 @@
 // launch carries a RMSNorm prologue -- every workgroup recomputes the 8 KiB reduction rather than pay a launch for it),
 // the weight loads of the first round are issued BEFORE the prologue so its latency hides under them.  HBM-bound
 // (weights read exactly once): 4.9-5.7 TB/s at Llama-2-7B shapes; no MFMA: M = 1.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -787,30 +788,43 @@ __global__ __launch_bounds__(kPsWaves* kWave, 4) void persist_kernel(SkinnyArgs 
 
 // dynamic LDS a workgroup may ask for: the CU's 160 KiB less the kernel's static arrays (s_part 2 TG KiB, the rotation table
 // 4 TG KiB) and some slack
+constexpr int kMaxDevices = 64;
+static int current_device() {  // index into the per-device caches below; -1: unknown (no caching)
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+    return dev;
+}
 static size_t persist_lds_budget(uint32_t tg, bool rope) { return (size_t)(158 - tg * (2 + (rope ? 4 : 0))) * 1024; }
 
 template <int MODE, int TG>
 static int launch_persist_tg(const SkinnyArgs& a, const PersistPlan& pl, uint32_t grid, size_t lds, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {  // more than 64 KiB of dynamic LDS needs the opt-in
+    // more than 64 KiB of dynamic LDS needs the opt-in, once per DEVICE (a process may drive several GPUs) -- kept in a
+    // per-device table of atomics so that two threads launching on different devices do not race on one flag
+    static std::atomic<bool> attr[kMaxDevices];
+    const int dev = current_device();
+    if (dev < 0 || !attr[dev].load(std::memory_order_acquire)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_kernel<MODE, TG, kCM>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)persist_lds_budget(TG, MODE == kGvQkvRope));
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        if (dev >= 0) attr[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((persist_kernel<MODE, TG, kCM>), dim3(grid), dim3(kPsWaves * kWave), lds, s, a, pl);
     QUEST_LAUNCH_CHECK();
     return 0;
 }
 
-static int persist_cus() {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n > 0 ? n : 256;
-    }();
-    return cus;
+static int persist_cus() {  // compute units of the CURRENT device (cached per device)
+    static std::atomic<int> cus[kMaxDevices];
+    const int dev = current_device();
+    int n = dev >= 0 ? cus[dev].load(std::memory_order_relaxed) : 0;
+    if (n <= 0) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0;
+        n = n > 0 ? n : 256;
+        if (dev >= 0) cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 // Plan of the persistent kernel, or false when the shape does not fit it (then: launch_skinny).

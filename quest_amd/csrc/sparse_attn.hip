@@ -32,8 +32,10 @@ namespace quest {
 // heads of a kv-head group select overlapping page sets (measured: 21 % of their pages are shared, scripts/gqa_overlap.py),
 // so their workgroups should sit on the SAME XCD, at the same time: the host picks `xcd_period` such that grid rows
 // y, y + period, y + 2 period, ... (same XCD for every chunk index) serve a run of consecutive query heads.
+// (head_dim 256 keeps twice the K/V registers in flight per lane: its 8-wave instantiations are built for 2 waves per SIMD
+// -- up to 256 VGPRs, one workgroup per CU -- instead of spilling 41-46 registers to scratch at the 128 of 4 waves per SIMD)
 template <int D, int S_T, int FC, int NW, int VF = -1>
-__global__ __launch_bounds__(NW* kWave, NW / 2) void sparse_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
+__global__ __launch_bounds__(NW* kWave, (D >= 256 && NW >= 8) ? NW / 4 : NW / 2) void sparse_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
     QUEST_DECODE_HEAD_TAKE(p);
     uint32_t hq = blockIdx.y;
     if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (a_num_qo_heads / p.xcd_period) + hq / p.xcd_period;

@@ -158,6 +158,23 @@ class LlamaDecoderLayer(nn.Module):
         return h
 
 
+def fused_layer_launches_supported(config, n_tokens: int) -> bool:
+    """Shapes the fused decoder-layer launches (csrc/decode_layer.hip) serve -- checked BEFORE a decode graph is captured,
+    so that a model outside them falls back to the module path (nn.Linear + separate norm / RoPE / activation launches)
+    instead of failing inside the capture with QUEST_EUNSUPPORTED: input dimensions a multiple of 8 halves (16-byte
+    vectors); the batch-1 kernels stage an input vector of at most 30720 halves in LDS (24576 with the RMSNorm prologue
+    of the n-token fallback kernel); RoPE pairs need head_dim % 4 == 0 (batch 1) / % 16 == 0 (n tokens)."""
+    hidden, inter = config.hidden_size, config.intermediate_size
+    head_dim = getattr(config, "head_dim", None) or hidden // config.num_attention_heads
+    if hidden % 8 or inter % 8 or head_dim % 4:
+        return False
+    if max(hidden, inter) > 30720:
+        return False
+    if n_tokens > 1 and (head_dim % 16 or hidden > 24576):
+        return False
+    return True
+
+
 class DecodeWorkspace:
     """Scratch of the fused decode layer (one set for the whole model: layers run one after the other); ``n`` tokens
     (sequences of a batch) per step."""
@@ -392,7 +409,8 @@ class LlamaForCausalLM(nn.Module):
             import os
 
             fused_layers = os.environ.get("QUEST_FUSED_LAYER", "1") != "0"
-        fused_layers = fused_layers and self.lm_head.weight.dtype == torch.float16
+        fused_layers = (fused_layers and self.lm_head.weight.dtype == torch.float16
+                        and fused_layer_launches_supported(self.config, 1))
         self.fused_layers = fused_layers
         if fused_layers:
             from .. import _kernels
@@ -483,7 +501,8 @@ class LlamaForCausalLM(nn.Module):
             fused_layers = os.environ.get("QUEST_FUSED_LAYER", "1") != "0"
         from .. import _kernels
 
-        fused_layers = fused_layers and self.lm_head.weight.dtype == torch.float16 and n <= _kernels.MAX_BATCHED_TOKENS
+        fused_layers = (fused_layers and self.lm_head.weight.dtype == torch.float16 and n <= _kernels.MAX_BATCHED_TOKENS
+                        and fused_layer_launches_supported(self.config, n))
         self.fused_layers = fused_layers
         if fused_layers:
             ws = self._graph_ws = DecodeWorkspace(self.config, torch.float16, dev, n)  # (kept: the graph holds its addresses)

@@ -421,7 +421,7 @@ def test_round3_entry_points_validate_arguments_without_gpu():
                                              None) == -1
     assert lib.quest_decode_qkv_rope_batched(one, one, 1e-5, one, one, one, one, one, one, 512, 4, 4, 72, 1.0, 1e4, one, 8,
                                              None) == -2   # head_dim % 16
-    assert b"r3" in lib.quest_build_info()
+    assert lib.quest_build_info().startswith(b"quest_hip gfx950 src=")
 
 
 def test_batched_controller_page_budgets_host_logic():
@@ -493,3 +493,19 @@ def test_n_token_launch_planner_host_logic():
     assert plan(8192, 4096, 4)[0] == 1
     assert plan(256, 40, 2)[0] == 0              # rows shorter than a wave sweep
     assert plan(4096, 4096, 0)[0] == -1 and plan(4096, 4096, 17)[0] == -1 and plan(4100, 4096, 8)[0] == -2
+
+
+def test_fused_decoder_layer_shape_gate():
+    """models outside the fused decoder-layer launches' shapes must fall back to the module path BEFORE a graph
+    capture (the launches would return QUEST_EUNSUPPORTED inside it)."""
+    from types import SimpleNamespace as NS
+
+    from quest_amd.models.llama import fused_layer_launches_supported as ok
+
+    llama7b = NS(hidden_size=4096, intermediate_size=11008, num_attention_heads=32)
+    assert ok(llama7b, 1) and ok(llama7b, 8) and ok(NS(hidden_size=4096, intermediate_size=14336, num_attention_heads=32), 16)
+    assert not ok(NS(hidden_size=4096, intermediate_size=11004, num_attention_heads=32), 1)   # not a multiple of 8 halves
+    assert not ok(NS(hidden_size=4100, intermediate_size=11008, num_attention_heads=41), 1)
+    assert not ok(NS(hidden_size=8192, intermediate_size=32768, num_attention_heads=64), 1)   # input vector beyond the LDS stage
+    assert ok(NS(hidden_size=1536, intermediate_size=4096, num_attention_heads=16, head_dim=72), 1)
+    assert not ok(NS(hidden_size=1536, intermediate_size=4096, num_attention_heads=16, head_dim=72), 4)  # n-token RoPE blocks
