@@ -434,17 +434,19 @@ def step_op_times(w, a, bpl, reps=10):
     handler.set_skip_merge(False)
     alg = n * (bpl["attn"] + bpl["topk"])
     achieved = alg / (t_ts_kernel * 1e-6) / 1e9
-    waves = 8 if (a.page_size == 16 and max_n > 1024) or os.environ.get("QUEST_DEC_WAVES") == "8" else 4
-    per_thread = max(1, -(-max_n // (waves * 64)))
-    fc = 8 if per_thread <= 8 else 16 if per_thread <= 16 else 24 if per_thread <= 24 else 32 if per_thread <= 32 else 64
+    li = handler.last_launch_info()  # what the timed launches ARE (keys per thread, waves, front-end variant)
+    fc, waves = li["keys_per_thread"], li["waves"]
+    kname = (f"sparse_decode_kernel<{a.head_dim},{a.page_size if a.page_size == 16 else 0},{fc},{waves},"
+             f"{li['front_end_variant'] if li['specialised'] else -1}>")
     ops = {"append_estimate_us": t_ae, "topk_sparse_attn_plus_merge_us": t_ts, "topk_sparse_attn_kernel_only_us": t_ts_kernel,
            "append_estimate_gbs": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9,
            "append_estimate_frac_of_hbm_peak": n * (bpl["append"] + bpl["estimate"]) / (t_ae * 1e-6) / 1e9 / HBM_PEAK_GBS,
            "note": "per launch inside a hipGraph of one launch per layer (each on its own pool), dependent-launch "
                    "boundary included; state-driven entry points = the launches of the timed step"}
     roof = {"bound": "hbm",
-            "kernel": f"sparse_decode_kernel<{a.head_dim},{a.page_size if a.page_size == 16 else 0},{fc},{waves}> (top-k front "
-                      "end + gather of the selected K/V pages; the dominant kernel of the timed step, merge launch excluded)",
+            "kernel": f"{kname} (top-k front end + gather of the selected K/V pages; the dominant kernel of the timed "
+                      "step, merge launch excluded)",
+            "kernel_name": kname, "launch": li,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": alg, "launch_us": t_ts_kernel, "sequences_per_launch": n,
             "op_us_with_merge": t_ts, "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}}
@@ -540,18 +542,23 @@ def cpu_baseline(a, w, budget_s):
                       f"{per_layer * 1e3:.0f} ms per layer-step, scaled to {a.layers} layers, one sequence"}
 
 
-def pmc_traffic(a, n_local):
+def pmc_traffic(a, n_local, kernel_name=None):
     """HBM bytes (read + write) per launch of the dominant kernel of this configuration, from the COMMITTED rocprofv3
     --pmc passes of this very command (profiles/traffic_latest.json, gfx950 FETCH_SIZE correction applied) -- a lookup,
-    not a measurement of the run that prints it.  Returns (bytes or None, source description)."""
+    not a measurement of the run that prints it.  Keyed by configuration AND by the kernel instantiation that was
+    launched (`roofline.kernel_name`): a profile of another instantiation is not reported as this run's traffic.
+    Returns (bytes or None, source description)."""
     tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if "custom" in a.workload_label and not (a.config == 3 and n_local == 8):
         return None, None
     try:
         t = json.load(open(tp))
-        val = t["sparse_decode_kernel_bytes_per_launch"].get(f"cfg{a.config}_seqs{n_local}")
-        return val, ("committed profile profiles/traffic_latest.json (" + t.get("source", "rocprofv3 --pmc") + "); "
-                     "not re-measured by this run")
+        rec = t["bytes_per_launch"].get(f"cfg{a.config}_seqs{n_local}")
+        if rec is None or (kernel_name is not None and rec.get("kernel") not in (None, kernel_name)):
+            return None, (f"profiles/traffic_latest.json holds no entry for {kernel_name} at cfg{a.config}_seqs{n_local}"
+                          if rec is not None else None)
+        return rec["bytes"], ("committed profile profiles/traffic_latest.json (" + t.get("source", "rocprofv3 --pmc") +
+                              f", kernel {rec.get('kernel')}); not re-measured by this run")
     except Exception:
         return None, None
 
@@ -559,7 +566,7 @@ def pmc_traffic(a, n_local):
 def add_traffic(roof, a, n_local):
     """roofline.traffic + its source + the fraction of the HBM peak the PMC bytes amount to (next to `frac`, which is
     algorithmic bytes / time)."""
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(a, n_local)
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(a, n_local, roof.get("kernel_name"))
     roof["frac_hbm_pmc"] = (roof["traffic"] / (roof["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
                             if roof["traffic"] and roof.get("launch_us") else None)
     if roof["traffic"] and roof["traffic"] < 0.95 * roof.get("algorithmic_bytes_per_launch", 0):
@@ -706,11 +713,31 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
             if not side:
                 ref_ops, dense_us = reference_op_times(w, a, bpl)
                 out["reference_op_sequence_us"] = ref_ops
-            if w.dense and dense_us is not None:  # full-KV config: the dense kernel IS the dominant kernel
-                ach = bpl["dense"] / (dense_us * 1e-6) / 1e9
-                out["roofline"] = {"bound": "hbm", "kernel": "shared_decode_kernel (full-KV decode, K/V read once per kv head)",
-                                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                   "traffic": None, "algorithmic_bytes_per_launch": bpl["dense"], "launch_us": dense_us}
+            if w.dense and w.dyn and not batched:  # full-KV config: the dense kernel IS the dominant kernel of the timed step
+                ctl0.begin_graph_decode(dense_layers=True)  # (reference_op_times re-planned the handlers)
+                hd = ctl0._dense_handler
+                od = [w.q[l].clone() for l in range(a.layers)]
+
+                def dense_launch(l):  # the timed step's launch: decode append folded into the group-shared attention
+                    if not hd.append_forward_shared_dyn(w.k1[l], w.v1[l], ctl0.metadata_cache.buf_layer(l), ctl0.meta_table_full,
+                                                        w.q[l], od[l], ctl0.kv_cache.buf_layer(l), ctl0.kv_table_full,
+                                                        ctl0.step_state):
+                        hd.forward_shared_dyn(w.q[l], od[l], ctl0.kv_cache.buf_layer(l), ctl0.kv_table_full, ctl0.step_state)
+
+                t_op = time_kernel_loop(dense_launch, a.layers, 10)
+                hd.set_skip_merge(True)
+                t_k = time_kernel_loop(dense_launch, a.layers, 10)
+                hd.set_skip_merge(False)
+                bpl_now = bytes_per_layer(argparse.Namespace(**{**vars(a), "seqlen": ctl0.kv_cache.seqlen}))
+                alg = bpl_now["dense"] + bpl_now["append"]
+                ach = alg / (t_k * 1e-6) / 1e9
+                kname = f"shared_decode_kernel<{a.head_dim},{a.heads // a.kv_heads},4,true>"
+                out["roofline"] = {"bound": "hbm", "kernel": f"{kname} (full-KV decode with the decode append folded in, K/V read "
+                                   "once per kv head; the dominant kernel of the timed step, merge launch excluded)",
+                                   "kernel_name": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                   "launch_us": t_k, "op_us_with_merge": t_op,
+                                   "sequence_length_at_measurement": ctl0.kv_cache.seqlen}
                 add_traffic(out["roofline"], a, n_local)
             if dense_us is not None:
                 out["dense_full_kv_us"] = dense_us
@@ -777,48 +804,69 @@ def main():
         torch.cuda.set_device(dev)
     out = measure(a, dev, dist, world_seen, rank, stub)
 
-    # ---- side configurations: where the fixed costs of a launch are shared by 8 sequences per GPU --
-    # the per-GPU load of BASELINE configs[4] -- measured AFTER the headline, outside `value`: the headline shapes x 8
-    # sequences (MHA) and configs[4] itself (GQA).  Only in the driver's default single-GPU headline run.
-    if (out is not None and not stub and world_seen == 1 and dist is None and a.config == 3 and not a.no_side
-            and "custom" not in a.workload_label and a.mode == "graph"):
-        import gc
+    # ---- side configurations, measured AFTER the headline and outside `value` (the headline stays cfg 3 x 1 sequence per
+    # GPU so that N = 1 equals BENCH): where the fixed costs of a launch are shared by 8 sequences per GPU -- the per-GPU
+    # load of BASELINE configs[4].  N = 1: the headline shapes x 8 sequences (MHA) and configs[4]'s per-GPU load (GQA).
+    # N > 1: EVERY rank runs configs[4]'s per-GPU load with the per-step all_gather of its 8 token
+    # ids, so that a SCALE record shows the configuration BASELINE names -- 8 GQA sequences per GPU x N GPUs -- as
+    # aggregate tokens/s and per-GPU chain fraction.  A failure here must not cost the headline line: it is printed in
+    # any case.
+    try:
+        if (a.config == 3 and not a.no_side and "custom" not in a.workload_label and a.mode == "graph"):
+            import gc
 
-        for name, overrides in (("batched_8seq", dict(config=3, seqs_per_gpu=8)),
-                                ("cfg5_8seq_gqa", dict(config=5))):
-            gc.collect()
-            torch.cuda.empty_cache()
-            a2 = parse(["--config", str(overrides["config"]), "--steps", str(a.side_steps), "--warmup", str(a.warmup),
-                        "--seed", str(a.seed), "--no-cpu-baseline"]
-                       + (["--seqs-per-gpu", str(overrides["seqs_per_gpu"])] if "seqs_per_gpu" in overrides else []))
-            try:
-                full = measure(a2, dev, None, 1, 0, False, side=True)
-            except Exception as exc:  # the headline line must survive a side measurement that fails (e.g. memory)
-                out[name] = {"error": f"{type(exc).__name__}: {exc}"}
-                continue
-            roof, ops = full.get("roofline") or {}, full.get("ops_us") or {}
-            out[name] = {
-                "workload": full["config"]["workload"], "sequences_per_gpu": full["config"]["sequences_per_gpu"],
-                "steps": full["steps"], "tokens_per_s": full["value"], "ms_per_step": full["ms_per_step"],
-                "us_per_sequence_layer": full["selfattn_us_per_layer"],
-                "chain_frac_of_hbm_peak": full["chain_frac_of_hbm_peak"],
-                "dominant_kernel": roof.get("kernel"), "dominant_kernel_launch_us": roof.get("launch_us"),
-                "dominant_kernel_frac_algorithmic": roof.get("frac"), "dominant_kernel_frac_hbm_pmc": roof.get("frac_hbm_pmc"),
-                "dominant_kernel_traffic_bytes": roof.get("traffic"), "traffic_source": roof.get("traffic_source"),
-                "append_estimate_us": ops.get("append_estimate_us"),
-                "append_estimate_frac_of_hbm_peak": ops.get("append_estimate_frac_of_hbm_peak"),
-                "batched_dense_full_kv_us_per_sequence": ops.get("batched_dense_full_kv_us_per_sequence"),
-                "speedup_vs_batched_dense": full.get("speedup_vs_batched_dense"),
-                "speedup_vs_single_sequence_dense": (out["dense_full_kv_us"] / full["selfattn_us_per_layer"]
-                                                     if overrides["config"] == 3 and out.get("dense_full_kv_us") else None),
-                "note": "measured after the headline timing in the same process; not part of `value`",
-            }
-
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if out is not None:
-        print(json.dumps(out), flush=True)
+            sides = [("batched_8seq", dict(config=3, seqs_per_gpu=8)), ("cfg5_8seq_gqa", dict(config=5))]
+            if dist is not None:
+                sides = sides[1:]
+            for name, overrides in sides:
+                gc.collect()
+                if not stub:
+                    torch.cuda.empty_cache()
+                a2 = parse(["--config", str(overrides["config"]), "--steps", str(a.side_steps), "--warmup", str(a.warmup),
+                            "--seed", str(a.seed), "--no-cpu-baseline", "--gpus", str(a.gpus)]
+                           + (["--seqs-per-gpu", str(overrides["seqs_per_gpu"])] if "seqs_per_gpu" in overrides else []))
+                try:
+                    full = measure(a2, dev, dist, world_seen, rank, stub, side=True)
+                except Exception as exc:  # the headline line must survive a side measurement that fails (e.g. memory)
+                    if dist is not None:
+                        raise  # the peers are inside collectives: leave through the outer handler
+                    out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    continue
+                if out is None:
+                    continue  # ranks > 0 took part in the measurement; rank 0 reports it
+                roof, ops = full.get("roofline") or {}, full.get("ops_us") or {}
+                out[name] = {
+                    "workload": full["config"]["workload"], "sequences_per_gpu": full["config"]["sequences_per_gpu"],
+                    "n_gpus": full["n_gpus"], "steps": full["steps"], "tokens_per_s": full["value"],
+                    "ms_per_step": full["ms_per_step"],
+                    "ms_per_step_without_token_gather": full.get("ms_per_step_without_token_gather"),
+                    "us_per_sequence_layer": full["selfattn_us_per_layer"],
+                    "chain_frac_of_hbm_peak": full["chain_frac_of_hbm_peak"],
+                    "dominant_kernel": roof.get("kernel"), "dominant_kernel_launch_us": roof.get("launch_us"),
+                    "dominant_kernel_frac_algorithmic": roof.get("frac"), "dominant_kernel_frac_hbm_pmc": roof.get("frac_hbm_pmc"),
+                    "dominant_kernel_traffic_bytes": roof.get("traffic"), "traffic_source": roof.get("traffic_source"),
+                    "append_estimate_us": ops.get("append_estimate_us"),
+                    "append_estimate_frac_of_hbm_peak": ops.get("append_estimate_frac_of_hbm_peak"),
+                    "batched_dense_full_kv_us_per_sequence": ops.get("batched_dense_full_kv_us_per_sequence"),
+                    "speedup_vs_batched_dense": full.get("speedup_vs_batched_dense"),
+                    "speedup_vs_single_sequence_dense": (out["dense_full_kv_us"] / full["selfattn_us_per_layer"]
+                                                         if overrides["config"] == 3 and out.get("dense_full_kv_us") else None),
+                    "note": ("measured after the headline timing in the same process(es); not part of `value`"
+                             + ("; every rank decodes 8 sequences, each step ends with the all_gather of the token ids; "
+                                "tokens_per_s is the aggregate over all ranks, the fractions are per GPU (rank 0's)"
+                                if dist is not None else "")),
+                }
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception as exc:
+        if out is not None:
+            out["side_error"] = f"{type(exc).__name__}: {exc}"
+        else:
+            raise
+    finally:
+        if out is not None:
+            print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -119,6 +119,12 @@ int quest_topk_filtering(const void* estimated_value, const int32_t* estimated_i
                          int32_t* indices_out, void* buf, uint32_t num_heads, uint32_t num_pages,
                          uint32_t page_budget, quest_stream_t stream);
 
+/* The same with a row stride for `estimated_value` (elements between consecutive heads' rows; 0 = num_pages): serves the
+ * padded score rows quest_append_estimate_strided writes without a compacting copy. */
+int quest_topk_filtering_strided(const void* estimated_value, uint32_t value_stride, const int32_t* estimated_indices,
+                                 void* d_out, int32_t* indices_out, void* buf, uint32_t num_heads, uint32_t num_pages,
+                                 uint32_t page_budget, quest_stream_t stream);
+
 /*
  * BatchDecodeWithPagedKVCachePyTorchWrapper (bsk_ops.h:84-116, approx_attn.cu:27-150 ->
  * BatchDecodeHandler, decode_handler.cuh:39-244).

@@ -129,8 +129,9 @@ def rms_norm_forward(input, weight, output, epsilon: float) -> None:
 
 
 def topk_filtering(estimated_value, estimated_indices, d_out, indices_out, buf, page_budget: int) -> None:
-    """topk.cu:7-46.  Rows = heads; selects ``page_budget`` largest of each row."""
-    _check_input(estimated_value, "estimated_value")
+    """topk.cu:7-46.  Rows = heads; selects ``page_budget`` largest of each row.  ``estimated_value`` may be a
+    ``[:, :n]`` view of a buffer with padded rows (``decode_append_estimate``'s output): the row stride is passed on."""
+    _check_rows(estimated_value, "estimated_value")
     _check_input(estimated_indices, "estimated_indices")
     _check_input(d_out, "d_out")
     _check_input(indices_out, "indices_out")
@@ -145,9 +146,10 @@ def topk_filtering(estimated_value, estimated_indices, d_out, indices_out, buf, 
     _check_eq(page_budget, d_out.size(1), "page_budget, d_out.size(1)")
     _check_eq(page_budget, indices_out.size(1), "page_budget, indices_out.size(1)")
     _check_half(estimated_value, "Top-k filtering")
-    check(lib.quest_topk_filtering(estimated_value.data_ptr(), estimated_indices.data_ptr(), d_out.data_ptr(),
-                                   indices_out.data_ptr(), buf.data_ptr() if buf is not None else None,
-                                   num_heads, num_pages, int(page_budget), _stream(estimated_value)),
+    check(lib.quest_topk_filtering_strided(estimated_value.data_ptr(), estimated_value.stride(0), estimated_indices.data_ptr(),
+                                           d_out.data_ptr(), indices_out.data_ptr(),
+                                           buf.data_ptr() if buf is not None else None, num_heads, num_pages,
+                                           int(page_budget), _stream(estimated_value)),
           "Top-k filtering")
 
 

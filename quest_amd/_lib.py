@@ -49,6 +49,7 @@ SIGNATURES = {
     "quest_append_estimate": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp]),
     "quest_append_estimate_strided": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, c_u32, PagedKV, c_vp]),
     "quest_topk_filtering": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
+    "quest_topk_filtering_strided": (ctypes.c_int, [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
     "quest_decode_handler_create": (ctypes.c_int, [ctypes.POINTER(c_vp), c_u32]),
     "quest_decode_handler_destroy": (None, [c_vp]),
     "quest_decode_begin_forward": (ctypes.c_int, [c_vp, c_u32, c_u32, c_u32, c_u32, c_u32, c_vp]),

@@ -764,7 +764,7 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, u
     }
 #undef QUEST_SHARED_CASE
     QUEST_LAUNCH_CHECK();
-    if (p.n_chunks > 1) {
+    if (p.n_chunks > 1 && !h->skip_merge) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
                            (const float*)p.ws, p.o, p.lse, p.n_chunks, p.ws_stride);
         QUEST_LAUNCH_CHECK();

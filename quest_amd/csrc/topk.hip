@@ -88,11 +88,12 @@ template <int C>
 __global__ __launch_bounds__(kTkThreads) void topk_kernel(const uint16_t* __restrict__ vals,
                                                           const int32_t* __restrict__ in_idx,
                                                           uint16_t* __restrict__ out_val,
-                                                          int32_t* __restrict__ out_idx, uint32_t n, uint32_t k) {
+                                                          int32_t* __restrict__ out_idx, uint32_t n, uint32_t k,
+                                                          uint32_t val_stride) {
     __shared__ TopkSmem<kTkThreads> sm;
     extern __shared__ __attribute__((aligned(16))) unsigned char tk_dyn[];
     const size_t row = blockIdx.x;
-    topk_row<C>(sm, tk_dyn, vals + row * n, in_idx + row * n, out_val + row * k, out_idx + row * k, n, k, n <= kTkStageIdsMax);
+    topk_row<C>(sm, tk_dyn, vals + row * val_stride, in_idx + row * n, out_val + row * k, out_idx + row * k, n, k, n <= kTkStageIdsMax);
 }
 
 // Batched, state-driven form (EXTENSION; replaces the per-request Python loop around topk_filtering of a batch of
@@ -124,12 +125,15 @@ __global__ __launch_bounds__(kTkThreads) void topk_batched_kernel(const uint16_t
 
 using namespace quest;
 
-extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* estimated_indices, void* d_out,
-                                    int32_t* indices_out, void* buf, uint32_t num_heads, uint32_t num_pages,
-                                    uint32_t page_budget, quest_stream_t stream) {
+extern "C" int quest_topk_filtering_strided(const void* estimated_value, uint32_t value_stride,
+                                            const int32_t* estimated_indices, void* d_out, int32_t* indices_out, void* buf,
+                                            uint32_t num_heads, uint32_t num_pages, uint32_t page_budget,
+                                            quest_stream_t stream) {
     (void)buf;
     if (!estimated_value || !estimated_indices) return QUEST_EINVAL;
     if (num_heads == 0 || num_pages == 0) return QUEST_EINVAL;
+    if (value_stride == 0) value_stride = num_pages;
+    if (value_stride < num_pages) return QUEST_EINVAL;
     if (page_budget > num_pages) return QUEST_EINVAL;  // CHECK_GE(num_pages, page_budget), topk.cu:26
     if (page_budget == 0) return 0;
     if (!d_out || !indices_out) return QUEST_EINVAL;
@@ -141,7 +145,7 @@ extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* 
                           (size_t)page_budget * 4;  // keys, staged ids, compacted selected ids
 #define QUEST_TOPK_LAUNCH(CC)                                                                                   \
     hipLaunchKernelGGL((topk_kernel<CC>), dim3(num_heads), dim3(kTkThreads), tk_lds, s, ev, estimated_indices, dv, \
-                       indices_out, num_pages, page_budget)
+                       indices_out, num_pages, page_budget, value_stride)
     // (a single-wave selection variant was built and measured 2x slower on MI355X: one wave issues ~1
     // instruction per 4-5 cycles, so its ~3.5k instructions cost > 8 us; removed)
     if (num_pages <= 1 * kTkThreads) QUEST_TOPK_LAUNCH(1);
@@ -152,6 +156,13 @@ extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* 
 #undef QUEST_TOPK_LAUNCH
     QUEST_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int quest_topk_filtering(const void* estimated_value, const int32_t* estimated_indices, void* d_out,
+                                    int32_t* indices_out, void* buf, uint32_t num_heads, uint32_t num_pages,
+                                    uint32_t page_budget, quest_stream_t stream) {
+    return quest_topk_filtering_strided(estimated_value, 0, estimated_indices, d_out, indices_out, buf, num_heads, num_pages,
+                                        page_budget, stream);
 }
 
 extern "C" int quest_topk_filtering_batched(const void* scores, uint32_t score_stride, uint32_t max_num_pages,

@@ -102,8 +102,7 @@ def decode_estimate(q: torch.Tensor, iController: InferenceController, layer_idx
 
 def decode_topk(estimated_attn_score: torch.Tensor, iController: InferenceController) -> None:
     """Pick the ``budget - 1`` best pages per head into ``iController.topk_dindices_buffer``."""
-    if not estimated_attn_score.is_contiguous():  # decode_append_estimate's padded rows
-        estimated_attn_score = estimated_attn_score.contiguous()
+    # (decode_append_estimate's padded rows are served in place: the op takes the row stride)
     _kernels.topk_filtering(estimated_attn_score, iController.kv_indices_without_last, iController.topk_dout_buffer,
                             iController.topk_dindices_buffer, iController.topk_buf,
                             iController.inference_page_budget - 1)

@@ -692,3 +692,30 @@ def test_prefill_attention_whole_and_chunked(Hq, Hkv, layout):
         outs.append(qu.prefill_forward(q[a:b], ctl, 0))
         ctl.end_forward()
     torch.testing.assert_close(torch.cat(outs).float(), ref, rtol=5e-3, atol=5e-3)
+
+
+def test_topk_on_padded_score_rows_without_a_copy():
+    """`decode_append_estimate` returns a `[:, :n]` view of rows padded to 8 columns; `decode_topk` takes it as
+    is (the op passes the row stride on) and selects what it selects from the contiguous copy."""
+    qu = _qu()
+    L, H, B = 16 * 301 + 5, 8, 40  # 302 pages -> 301 columns: not a multiple of 8
+    q, k, v = inputs(77, L, H)
+    ctl = make_controller(L, H, H, 128, PAGE, B, shuffle_seed=2)
+    kc, vc, qc = cuda(k), cuda(v), cuda(q)
+    ctl.prepare_metadata(L - 1)
+    ctl.begin_forward(L - 1)
+    qu.append_kv(kc[:-1], vc[:-1], ctl, 0)
+    ctl.end_forward()
+    ctl.prepare_metadata(1)
+    ctl.begin_forward(1)
+    est = qu.decode_append_estimate(qc, kc[-1:], vc[-1:], ctl, 0)
+    assert not est.is_contiguous() and est.stride(0) == 304
+    qu.decode_topk(est, ctl)
+    idx, val = ctl.topk_dindices_buffer.clone(), ctl.topk_dout_buffer.clone()
+    ctl.topk_dindices_buffer.fill_(-1)
+    qu.decode_topk(est.contiguous(), ctl)
+    assert torch.equal(idx, ctl.topk_dindices_buffer) and torch.equal(val, ctl.topk_dout_buffer)
+    table = np.array(ctl.kv_cache.indicies, np.int32)
+    ev, ei = oracle.topk(est.contiguous().cpu().numpy(), np.tile(table[:-1], (H, 1)), B - 1)
+    assert np.array_equal(idx.cpu().numpy(), ei) and np.array_equal(U16(val.cpu().numpy()), U16(ev))
+    ctl.end_forward()

@@ -90,6 +90,32 @@ def test_bench_launcher_starts_n_ranks_and_reports_world_size():
     assert abs(out["value"] - 2 * 8 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-6
 
 
+def test_bench_default_headline_reports_configs4_side_measurement_under_n_ranks():
+    """under N > 1 the default (cfg 3) headline run must ALSO measure BASELINE configs[4]'s shape -- 8 GQA
+    sequences per GPU on every rank, each step ending with the all_gather of the token ids -- and report it as a side
+    object (aggregate tokens/s over all ranks); the headline itself stays one cfg-3 sequence per GPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["QUEST_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--side-steps", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["survey_cfg"] == 3 and out["config"]["sequences_per_gpu"] == 1
+    assert "batched_8seq" not in out and "side_error" not in out
+    side = out["cfg5_8seq_gqa"]
+    assert side["n_gpus"] == 2 and side["sequences_per_gpu"] == 8 and side["steps"] == 3 and "configs[4]" in side["workload"]
+    assert side["ms_per_step_without_token_gather"] is not None
+    assert abs(side["tokens_per_s"] - 2 * 8 * 3 / (side["ms_per_step"] * 3e-3)) / side["tokens_per_s"] < 1e-6
+    assert "aggregate over all ranks" in side["note"]
+
+
 def test_bench_launcher_returns_promptly_when_a_peer_dies_before_rendezvous():
     """Rank 1 exits (code 3) before init_process_group: the launcher must notice, terminate rank 0 (which would
     otherwise sit in the rendezvous until the process-group timeout), print one JSON error line and return non-zero
