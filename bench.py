@@ -81,6 +81,9 @@ def parse(argv=None):
                          "shared pool (grid.z = sequence) unless --multi-seq-mode streams")
     ap.add_argument("--multi-seq-mode", choices=["batched", "streams"], default="batched")
     ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
+    ap.add_argument("--separate-dense-append", action="store_true",
+                    help="full-KV layers: issue the decode append as its own launch (three launches per layer, as before "
+                         "round 4) instead of folded into the attention launch (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--kernel-sweep", action="store_true",
@@ -227,7 +230,8 @@ class Workload:
         qu.step_advance_dyn(ctl)
         for layer in range(a.layers):
             if self.dense:
-                self.outs[layer] = qu.decode_layer_dense_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer)
+                self.outs[layer] = qu.decode_layer_dense_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer,
+                                                             fuse_append=not a.separate_dense_append)
             else:
                 self.outs[layer] = qu.decode_layer_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer,
                                                        self.scores)

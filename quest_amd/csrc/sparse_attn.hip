@@ -92,28 +92,26 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
     RowState<D> st[GS];
 
     [[maybe_unused]] const size_t app_in_off = ((size_t)blockIdx.z * gridDim.y + hk) * D + col * kVec;
+    // APPEND: the lanes (of the ONE wave per kv head that attends the current page) that hold the new token's row.  Their
+    // metadata loads are issued here and consumed after the page loop; the stores come after the loop as well -- issued in
+    // front of it they sat in the wave's vmcnt queue ahead of its K/V loads, whose first wait then also waited for the
+    // write acknowledgements (measured: the fused launch lost its gain whenever the last chunk was long).
+    [[maybe_unused]] bool app_mine = false;
+    [[maybe_unused]] uint16_t* app_mmax = nullptr;
+    [[maybe_unused]] ushort8 app_mx = (ushort8)(kHalfNegMax), app_mn = (ushort8)(kHalfMax);
     if constexpr (APPEND) {
-        // prologue of the ONE wave (per kv head) that will attend the current page: the lanes that hold the new token's
-        // row write it to the pool and fold the key into the page's metadata entry (entry meta_last_page_len - 1 of the
-        // last metadata page; same pool geometry as the KV pool; a token that opens a page starts from the sentinels)
         const uint32_t e = p.last_page_len - 1u;
-        if (slot_begin <= p.n_sel && p.n_sel < slot_end && (uint32_t)wave == (p.n_sel - slot_begin) % NW &&
-            (uint32_t)row == e % R) {
-            const half8 kn = ld8(p.app_k + app_in_off), vn = ld8(p.app_v + app_in_off);
-            half_t* dst = const_cast<half_t*>(head_base) + (size_t)p.last_page_idx * p.st.page + lane_off + (e / R) * step;
-            st8(dst, kn);
-            st8(dst + p.st.v_off, vn);
-            uint16_t* mmax = reinterpret_cast<uint16_t*>(p.app_meta) + (size_t)p.meta_last_page_idx * p.st.page +
-                             (size_t)hk * p.st.head + (size_t)(p.meta_last_page_len - 1u) * p.st.entry + col * kVec;
-            uint16_t* mmin = mmax + p.st.v_off;
-            ushort8 mx = (ushort8)(kHalfNegMax), mn = (ushort8)(kHalfMax);
+        app_mine = slot_begin <= p.n_sel && p.n_sel < slot_end && (uint32_t)wave == (p.n_sel - slot_begin) % NW &&
+                   (uint32_t)row == e % R;
+        if (app_mine) {
+            // metadata entry of the page: entry meta_last_page_len - 1 of the last metadata page (same pool geometry as
+            // the KV pool); a token that opens a page starts from the sentinels, not from stale pool bytes
+            app_mmax = reinterpret_cast<uint16_t*>(p.app_meta) + (size_t)p.meta_last_page_idx * p.st.page +
+                       (size_t)hk * p.st.head + (size_t)(p.meta_last_page_len - 1u) * p.st.entry + col * kVec;
             if (e > 0) {
-                mx = *reinterpret_cast<const ushort8*>(mmax);
-                mn = *reinterpret_cast<const ushort8*>(mmin);
+                app_mx = *reinterpret_cast<const ushort8*>(app_mmax);
+                app_mn = *reinterpret_cast<const ushort8*>(app_mmax + p.st.v_off);
             }
-            const ushort8 k8 = __builtin_bit_cast(ushort8, kn);
-            *reinterpret_cast<ushort8*>(mmax) = fold_max(mx, k8);
-            *reinterpret_cast<ushort8*>(mmin) = fold_min(mn, k8);
         }
     }
 
@@ -128,9 +126,8 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
             v[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
         }
         if constexpr (APPEND) {
-            if (s0 >= p.n_sel) {  // wave-uniform: the current page -- its newest row is the token being decoded, which
-                                  // the prologue above wrote to the pool; here it comes from the inputs again (L2-hot)
-                                  // rather than through a same-wave store -> load of the pool bytes
+            if (s0 >= p.n_sel) {  // wave-uniform: the current page -- its newest row is the token being decoded, which is
+                                  // not in the pool yet (written after this loop): it comes from the inputs
                 const uint32_t e = (uint32_t)len - 1u;
                 const half8 kn = ld8(p.app_k + app_in_off), vn = ld8(p.app_v + app_in_off);
 #pragma unroll
@@ -173,6 +170,19 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
                 for (int i = 0; i < kVec; ++i) st[g].acc[i] = __builtin_fmaf(pr, vf[t][i], st[g].acc[i]);
             }
             st[g].m = m_new;
+        }
+    }
+
+    if constexpr (APPEND) {
+        if (app_mine) {  // write the new token to the pool and fold its key into the page's (max, min) entry
+            const uint32_t e = p.last_page_len - 1u;
+            const half8 kn = ld8(p.app_k + app_in_off), vn = ld8(p.app_v + app_in_off);
+            half_t* dst = const_cast<half_t*>(head_base) + (size_t)p.last_page_idx * p.st.page + lane_off + (e / R) * step;
+            st8(dst, kn);
+            st8(dst + p.st.v_off, vn);
+            const ushort8 k8 = __builtin_bit_cast(ushort8, kn);
+            *reinterpret_cast<ushort8*>(app_mmax) = fold_max(app_mx, k8);
+            *reinterpret_cast<ushort8*>(app_mmax + p.st.v_off) = fold_min(app_mn, k8);
         }
     }
 
