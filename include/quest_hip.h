@@ -361,7 +361,10 @@ int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int
  * score rows) without its histogram pre-filter, 3 = second generation with the pre-filter, 4 = column-range ownership
  * (csrc/topk_colrange.cuh; where a head has several workgroups and aligned score rows -- 8-wave workgroups also on
  * short rows; built in round 4, measured slower than slot ownership, kept for A/B runs and tests), 5 = as 0 (A/B runs
- * under QUEST_COLRANGE=1).  0-3 and 5 are slot ownership.  All implement the same
+ * under QUEST_COLRANGE=1), 6 = third generation (csrc/topk_prefilter.cuh; rows beyond 4096 pages, at most 512 selected
+ * pages; falls back to the second generation inside the kernel when a wave holds more than 255 candidates; built in
+ * round 4, measured slower than the second generation at cfg 4, kept for A/B runs and tests).  0-3, 5 and 6 are slot
+ * ownership.  All implement the same
  * selection: bit-identical page SETS and (inspection) lists; the column-range variants fold a head's pages in a
  * different workgroup split, so outputs differ from the others' by fp32 merge order (tests: <= 2e-3).  Tuning / test aid. */
 int quest_decode_set_front_end(quest_decode_handler_t* h, int generation);

@@ -3,6 +3,7 @@
 #pragma once
 #include "estimate_device.cuh"
 #include "topk_colrange.cuh"
+#include "topk_prefilter.cuh"
 
 // Developer aid (scripts/timeline.py): -DQUEST_TIMELINE makes one workgroup of sparse_decode_kernel write
 // clock stamps of its phases into the `lse` buffer instead of the log-sum-exp.
@@ -485,6 +486,9 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
         Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
+        constexpr bool kFe3 = FC >= 16 && FC <= 32 && NW == 8;  // instantiations that carry the third-generation front end
+        [[maybe_unused]] uint2 raw3[kFe3 ? FC / 4 : 1];
+        __shared__ Fe3Smem<kFe3 ? NW : 1> f3;
         // live lengths of a state-driven launch: ONE scalar load (n_pages, last page's length and id are adjacent),
         // issued before the vector loads below and consumed after them
         // (unconditional, from q's bytes when there is no state: a load under a branch is waited for at the join)
@@ -523,6 +527,13 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 own_keys = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
             fe2_clear<NT>(sm);
+        } else if (kFe3 && vec_front == 6) {  // third generation (long rows): the thread's own FC columns
+            if constexpr (kFe3) {
+                fe3_issue<FC>(srow, n_cap, raw3);
+                fe2_clear<NT>(sm);
+                if (threadIdx.x == 0) f3.abort = 0u;
+
+            }
         } else if (vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
             fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
             fe2_clear<NT>(sm);
@@ -540,10 +551,33 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         }
         plan_slots();
         const uint32_t n = p.n_scores;
-        if (n > 0 && vec_front == 2) {
+        bool second_gen = vec_front == 2;
+        if constexpr (kFe3) {
+            if (n > 0 && vec_front == 6) {
+                QUEST_STAMP(1);
+                const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
+                const bool done = fe3_select<NT, FC>(sm, f3, raw3, srow, sv.indices, n, p.n_sel, slot_begin, slot_end, s_sel,
+                                                     p.sel_val_out ? p.sel_val_out + out_row : nullptr,
+                                                     p.sel_idx_out ? p.sel_idx_out + out_row : nullptr
+#ifdef QUEST_TIMELINE
+                                                     , sub_out
+#endif
+                );
+                QUEST_STAMP(4);
+                if (done) {
+                    __syncthreads();
+                    QUEST_STAMP(5);
+                } else {  // block-uniform and rare (a wave with > 256 candidates, k > 512): the second generation, from scratch
+                    fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, false, n_cap, raw);
+                    fe2_clear<NT>(sm);
+                    second_gen = true;
+                }
+            }
+        }
+        if (n > 0 && second_gen) {
             QUEST_STAMP(1);
             const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
-            const bool ids_staged = p.stage_ids && fe2_has_ids(FC);
+            const bool ids_staged = p.stage_ids && fe2_has_ids(FC) && vec_front == 2;
             uint16_t* val_row = p.sel_val_out ? p.sel_val_out + out_row : nullptr;
             int32_t* idx_row_out = p.sel_idx_out ? p.sel_idx_out + out_row : nullptr;
             fe2_select<NT, FC>(sm, s_bm, raw, srow, sv.indices,
@@ -560,7 +594,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 __syncthreads();
             }
             QUEST_STAMP(5);
-        } else if (FC <= 16 && n > 0) {  // first-generation front end (unaligned score rows; rows <= 4096 columns)
+        } else if (FC <= 16 && n > 0 && vec_front != 6) {  // first-generation front end (unaligned score rows; rows <= 4096 columns)
             // block-uniform; a one-page sequence has no row to select from (only the current page)
             // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n).
             const uint32_t cpt = p.cpt;

@@ -390,7 +390,7 @@ extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) 
 }
 
 extern "C" int quest_decode_set_front_end(quest_decode_handler_t* h, int generation) {
-    if (!h || generation < 0 || generation > 5) return QUEST_EINVAL;
+    if (!h || generation < 0 || generation > 6) return QUEST_EINVAL;
     h->front_end = generation;
     return 0;
 }
@@ -522,6 +522,13 @@ static int launch_decode_fc(quest_decode_handler* h, const DecodeParams& p, uint
         constexpr int VFA = FC == 8 ? 3 : 2, VFB = FC == 8 ? 1 : 2, VFC = FC == 8 ? 4 : 5;
         if constexpr (FC == 8 || FC == 16 || FC == 24 || FC == 32) {
             info[3] = 1u;
+            if constexpr (FC != 8) {
+                if (p.vec_front == 6u) {  // third generation (topk_prefilter.cuh), second-generation code as its cold fallback
+                    hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, 6>), grid, dim3(8 * kWave), 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
+                    QUEST_LAUNCH_CHECK();
+                    goto merge;
+                }
+            }
             if (p.vec_front == (uint32_t)VFC) {
                 hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFC>), grid, dim3(8 * kWave), 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
                 QUEST_LAUNCH_CHECK();
@@ -647,7 +654,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         rows_aligned = aligned;
         int gen = 1;
         if (aligned) {
-            if (forced == 2 || forced == 3 || ((forced == 0 || forced == 4) && n_scores > 4096u)) gen = 2;
+            if (forced == 2 || forced == 3 || forced == 6 || ((forced == 0 || forced == 4) && n_scores > 4096u)) gen = 2;
         }
         if (gen != 1) {
             p.vec_front = 2;
@@ -724,6 +731,21 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
             // (second-generation ownership: fc / 8 granules of 4 columns per lane, i.e. rl <= 32 fc -- what 16 workgroups
             // per head need at the instantiation's longest row)
             else if (p.vec_front == 2 && (fc == 16 || fc == 24 || fc == 32) && rl <= (uint32_t)(fc / 8) * (uint32_t)kColRangeMax) p.vec_front = 5;
+        }
+        // Third-generation front end (round 4, topk_prefilter.cuh) for long rows (> 4096 columns, 16-32 keys per thread in
+        // 8-wave workgroups): one pass over a thread's keys compacts the candidates above a per-wave lower bound of the
+        // threshold (~4 % of the row), the rest of the selection runs on <= 4 keys per thread.  Built, parity-green on
+        // crafted rows incl. its two fallbacks (tests/test_gpu_long_rows.py), and measured SLOWER than the second
+        // generation at cfg 4: 22.4 vs 19.6 us per launch.  The phases behind the compaction are indeed short (threshold +
+        // slots 1.0 us against 4.6 for bitmaps, rank scan and page resolve), but converting, bounding and compacting 24 keys
+        // per thread costs as many issue slots as the second generation's histogram and bitmap passes, and the slowest wave
+        // of a workgroup reaches the page-list barrier 4.5 us after the fastest (2.3 in the second generation):
+        // profiles/r04_timeline_front_end_cfg4_third_generation.log.  OFF by default; quest_decode_set_front_end(h, 6).
+        // Needs 8-byte aligned score rows readable up to the next multiple of 4 columns and k <= 512.
+        if (p.vec_front == 2 && forced == 6 && waves == 8 && (fc == 16 || fc == 24 || fc == 32) && kv.page_size == 16 &&
+            h->n_sel <= 512u && n_scores <= 512u * (uint32_t)fc) {
+            p.vec_front = 6;
+            p.stage_ids = 0;
         }
         p.chunks_inv = (uint32_t)(0x100000000ull / h->n_chunks) + 1u;  // (n_chunks == 1: unused)
         p.table_vec = table_vec ? 1u : 0u;

@@ -131,14 +131,15 @@ __device__ __forceinline__ void topk_load_keys(const uint16_t* keys_s, uint32_t 
 // Shared tail of the selection routines: with T / need known (cur), count the thread's keys above and at the threshold
 // and turn the block-wide exclusive prefix into the cursor (output slot of the thread's first selected column, rank of
 // its first tied column).
-template <int NT, int C>
-__device__ __forceinline__ TopkCursor topk_finish(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t cpt,
-                                                 TopkCursor cur, long long* sub) {
-    const uint32_t c0 = threadIdx.x * cpt;
+// `valid(i)`: whether key[i] is a live entry of the thread (the contiguous-ownership callers pass "i < cpt && c0 + i < n";
+// the long-row front end of topk_prefilter.cuh owns compacted candidates and passes its own mask).
+template <int NT, int C, typename Valid>
+__device__ __forceinline__ TopkCursor topk_finish_v(TopkSmem<NT>& sm, const uint32_t (&key)[C], Valid valid, TopkCursor cur,
+                                                   long long* sub) {
     uint32_t gt = 0, eq = 0;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        const bool in = (uint32_t)i < cpt && c0 + i < n;
+        const bool in = valid(i);
         gt += in && key[i] > cur.T;
         eq += in && key[i] == cur.T;
     }
@@ -153,12 +154,20 @@ __device__ __forceinline__ TopkCursor topk_finish(TopkSmem<NT>& sm, const uint32
 }
 
 template <int NT, int C>
-__device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k,
-                                                  uint32_t cpt, long long* sub = nullptr) {
+__device__ __forceinline__ TopkCursor topk_finish(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t cpt,
+                                                 TopkCursor cur, long long* sub) {
+    const uint32_t c0 = threadIdx.x * cpt;
+    return topk_finish_v<NT, C>(sm, key, [&](int i) { return (uint32_t)i < cpt && c0 + i < n; }, cur, sub);
+}
+
+// abort: optional LDS word; when it is non-zero after the histogram barrier (block-uniform) the selection stops and the
+// returned cursor has T == 0xffffffff (the caller falls back to another front end).
+template <int NT, int C, typename Valid>
+__device__ __forceinline__ TopkCursor topk_select_v(TopkSmem<NT>& sm, const uint32_t (&key)[C], Valid valid, uint32_t k,
+                                                    const uint32_t* abort = nullptr, long long* sub = nullptr) {
     constexpr int BPT = kBins1 / NT;  // histogram bins per thread in the suffix scan
     static_assert(kBins1 % NT == 0 && NT >= kWave, "thread count must divide the bin count");
     const uint32_t tid = threadIdx.x;
-    const uint32_t c0 = tid * cpt;
 
     // Bins are taken over the row's own key range [kmin, kmax], not over the 16-bit key space: page scores
     // of one head sit in one or two binades, where fixed top-11-bit bins put ~100 keys on each of ~20
@@ -174,10 +183,15 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
     const uint32_t low_mask = (1u << shift) - 1u;
 #pragma unroll
     for (int i = 0; i < C; ++i)
-        if ((uint32_t)i < cpt && c0 + i < n) atomicAdd(&sm.hist1[(key[i] - kmin) >> shift], 1u);
+        if (valid(i)) atomicAdd(&sm.hist1[(key[i] - kmin) >> shift], 1u);
     QUEST_SUBSTAMP(0);
     __syncthreads();
     QUEST_SUBSTAMP(1);
+    if (abort && *abort) {
+        TopkCursor none;
+        none.T = 0xffffffffu, none.need = none.pos = none.eq_rank = 0u;
+        return none;
+    }
 
     {  // suffix scan from the top bin: thread t owns bins kBins1-1-BPT*t .. kBins1-BPT*(t+1), descending
         // the thread's BPT bins are one contiguous, BPT*4-byte aligned block: fetch it with 8/16-byte LDS
@@ -232,7 +246,7 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
     } else {
 #pragma unroll
         for (int i = 0; i < C; ++i)
-            if ((uint32_t)i < cpt && c0 + i < n && ((key[i] - kmin) >> shift) == thr_bin)
+            if (valid(i) && ((key[i] - kmin) >> shift) == thr_bin)
                 atomicAdd(&sm.hist2[(key[i] - kmin) & low_mask], 1u);
         __syncthreads();
         QUEST_SUBSTAMP(5);
@@ -253,7 +267,14 @@ __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32
         cur.need = sm.misc[3];
     }
 
-    return topk_finish<NT, C>(sm, key, n, cpt, cur, sub);
+    return topk_finish_v<NT, C>(sm, key, valid, cur, sub);
+}
+
+template <int NT, int C>
+__device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k,
+                                                  uint32_t cpt, long long* sub = nullptr) {
+    const uint32_t c0 = threadIdx.x * cpt;
+    return topk_select_v<NT, C>(sm, key, [&](int i) { return (uint32_t)i < cpt && c0 + i < n; }, k, nullptr, sub);
 }
 
 // (A low-bits variant -- bins = key & 2047, so that the range publish and the histogram atomics share one barrier, with

@@ -86,6 +86,13 @@ for fused in variants:
     info = (h2 if fused in ("dyn", "dyn-slots") else h).last_launch_info()
     print(f"== {label}: variant {info['front_end_variant']}, {info['workgroups_per_head']} workgroups per head; "
           f"{cyc_per_us:.0f} cycles/us, workgroup lifetime {float(t[9]) / cyc_per_us:.2f} us")
+    if info["front_end_variant"] == 6:
+        for i, nme in enumerate(names):
+            print(f"  {float(t[i]) / cyc_per_us:6.2f} us  {nme}")
+        for i, nme in enumerate(["keys converted, wave bound + max published", "barrier A", "candidates compacted + re-read, page ids requested",
+                                 "topk_select on <= 4 keys per thread done", "slots written"]):
+            print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  fe3_select: {nme}")
+        continue
     if info["front_end_variant"] in (4, 5):
         cn = ["entry", "own keys arrived + converted", "range published", "barrier", "threshold known",
               "page list built (per wave)", "all K/V folded", "row butterfly + LDS write", "barrier", "partial written"]

@@ -137,10 +137,11 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     torch.testing.assert_close(o2[0].float(), o_ref, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
     # the same step (the append is idempotent) without and with the histogram pre-filter of the long-row front end
-    # (csrc/topk_bitmap.cuh; the default above is "with"): same pages, same bits; and through the column-range form
+    # (csrc/topk_bitmap.cuh; the default above is "with") and through the third generation (csrc/topk_prefilter.cuh,
+    # measured slower, not the default): same pages, same slots, same bits; and through the column-range form
     # (csrc/topk_colrange.cuh, measured slower and therefore not the default): same page lists, outputs within the fp32
     # merge-order bound (a different workgroup split)
-    for gen in (2, 3, 4):
+    for gen in (2, 3, 6, 4):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl._decode_handler.set_front_end(gen)
         sel_i2 = torch.full_like(sel_i, -1)
@@ -149,7 +150,7 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
         o3 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, qu.score_scratch(ctl).zero_())
         ctl._decode_handler.set_selection_out(None, None)
         assert torch.equal(sel_i2, sel_i), f"front end {gen}: page lists differ"
-        assert ctl._decode_handler.last_launch_info()["front_end_variant"] == (5 if gen == 4 else 2)
+        assert ctl._decode_handler.last_launch_info()["front_end_variant"] == {2: 2, 3: 2, 6: 6, 4: 5}[gen]
         if gen == 4:
             torch.testing.assert_close(o3.float(), o2.float(), rtol=2e-3, atol=2e-3)
             torch.testing.assert_close(o3[0].float(), o_ref, rtol=5e-3, atol=5e-3)

@@ -398,7 +398,7 @@ def test_round3_entry_points_validate_arguments_without_gpu():
     assert lib.quest_decode_handler_create(ctypes.byref(h), 0) == 0
     assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, one, 10, 4, None, None, None, None) == -1
     assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, None, 10, 16, None, None, None, None) == -1
-    assert lib.quest_decode_set_front_end(h, 5) == 0 and lib.quest_decode_set_front_end(h, 6) == -1
+    assert lib.quest_decode_set_front_end(h, 6) == 0 and lib.quest_decode_set_front_end(h, 7) == -1
     info = (ctypes.c_uint32 * 6)()
     assert lib.quest_decode_last_launch_info(h, info) == 0 and list(info) == [0] * 6  # nothing launched yet
     assert lib.quest_decode_last_launch_info(None, info) == -1
