@@ -19,3 +19,7 @@ for t in ("default","driver","cfg2","cfg4","cfg5","cfg3x8"):
     for k in ("batched_8seq","cfg5_8seq_gqa"):
         if k in d: print("   ", k, {x: d[k].get(x) for x in ("us_per_sequence_layer","chain_frac_of_hbm_peak","dominant_kernel_launch_us","dominant_kernel_frac_algorithmic","speedup_vs_batched_dense")})
 PY
+# end to end (random-weight checkpoint in HF layout, Llama-2-7B shapes): one sequence and 8 sequences per step
+python scripts/bench_textgen.py --make-checkpoint /tmp/quest_ckpt --generate 64 > $O/r04_e2e_textgen_fused_layers.json 2> $O/r04_e2e_textgen.err || { tail -5 $O/r04_e2e_textgen.err; exit 1; }
+python scripts/bench_textgen.py --seqs 8 > $O/r04_e2e_textgen_8seq_fused_layers.json 2> $O/r04_e2e_textgen_8seq.err || { tail -5 $O/r04_e2e_textgen_8seq.err; exit 1; }
+cut -c1-700 $O/r04_e2e_textgen_fused_layers.json; cat $O/r04_e2e_textgen_8seq_fused_layers.json
