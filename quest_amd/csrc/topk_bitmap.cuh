@@ -256,20 +256,32 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
     {
         uint32_t thr_bin = 0, above = 0;
         if (!kFe2Solo || wave == 0) {
-            const uint32_t base = kBins1 - 32u * (lane + 1u);
+            // Only the bins [0, nb) can hold keys (nb = the row's key range in bins; with the pre-filter the range starts
+            // at the lower bound of the threshold and is a few hundred bins, not 2048): the lanes share THOSE bins, top
+            // down -- lane l owns the bpl bins below top - bpl l, bpl = ceil(nb / 64) <= 32 -- so the loop runs bpl times
+            // instead of 32 (round 4: the threshold phase of a cfg-4 workgroup was 0.96 us of 32 LDS reads per lane).
+            // Reads are rotated by the lane number so that the lanes of a read group hit different banks.
+            const uint32_t nb = (range >> shift) + 1u;                 // <= kBins1
+            const uint32_t bpl = (nb + 63u) >> 6;                      // wave-uniform, 1 .. 32
+            const uint32_t top = bpl << 6;                             // bins [nb, top) are empty (cleared), top <= kBins1
+            const uint32_t base = top - bpl * (lane + 1u);
+            const uint32_t rot = lane % bpl;                           // (one division per thread, outside the loop)
             uint32_t tot = 0;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) tot += sm.hist1[base + ((j + lane) & 31u)];
+            for (uint32_t j = 0; j < bpl; ++j) {
+                uint32_t jj = j + rot;
+                jj = jj >= bpl ? jj - bpl : jj;
+                tot += sm.hist1[base + jj];
+            }
             const uint32_t incl = wave_scan_incl_dpp(tot);
             const unsigned long long m1 = __ballot(incl >= k);
             const uint32_t L = (uint32_t)__builtin_ctzll(m1);  // m1 != 0: the row holds n >= k keys
             const uint32_t above_l = (uint32_t)__builtin_amdgcn_readlane((int)(incl - tot), (int)L);
-            const uint32_t base_l = kBins1 - 32u * (L + 1u);
-            const uint32_t c = lane < 32u ? sm.hist1[base_l + 31u - lane] : 0u;  // bins of lane L, descending
+            const uint32_t base_l = top - bpl * (L + 1u);
+            const uint32_t c = lane < bpl ? sm.hist1[base_l + bpl - 1u - lane] : 0u;  // bins of lane L, descending
             const uint32_t incl2 = wave_scan_incl_dpp(c);
-            const unsigned long long m2 = __ballot(lane < 32u && above_l + incl2 >= k);
+            const unsigned long long m2 = __ballot(lane < bpl && above_l + incl2 >= k);
             const uint32_t I = (uint32_t)__builtin_ctzll(m2);
-            thr_bin = base_l + 31u - I;
+            thr_bin = base_l + bpl - 1u - I;
             above = above_l + (uint32_t)__builtin_amdgcn_readlane((int)(incl2 - c), (int)I);
             if (kFe2Solo && lane == 0) {
                 sm.misc[0] = thr_bin;
