@@ -80,6 +80,10 @@ def parse(argv=None):
                     help="independent sequences per GPU (config 5 uses 8), decoded with ONE launch per op over a "
                          "shared pool (grid.z = sequence) unless --multi-seq-mode streams")
     ap.add_argument("--multi-seq-mode", choices=["batched", "streams"], default="batched")
+    ap.add_argument("--seq-groups", type=int, default=1,
+                    help="batched mode: split the local sequences into this many groups, each a batched workload over its "
+                         "own pool on its own stream (one hipGraph for all): a group's selection prologue and dispatch "
+                         "gaps run under another group's streaming (experiment, DESIGN.md 3.5)")
     ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
     ap.add_argument("--separate-dense-append", action="store_true",
                     help="full-KV layers: issue the decode append as its own launch (three launches per layer, as before "
@@ -592,6 +596,10 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
                and not a.unfused)
     if stub:
         ws = [StubWorkload(a)]
+    elif batched and a.seq_groups > 1:
+        assert n_local % a.seq_groups == 0, "--seq-groups must divide the sequences per GPU"
+        per = n_local // a.seq_groups
+        ws = [BatchedWorkload(a, dev, per, seq_id0=i * per) for i in range(a.seq_groups)]
     elif batched:
         ws = [BatchedWorkload(a, dev, n_local)]
     else:
