@@ -38,9 +38,9 @@ def _torch_attention(q, k, v, logical_pages, L):
     return (p[:, None] @ vs).squeeze(1)
 
 
-def _expected(q_np, meta_pool_np, meta_table, meta_last_len, kv_table, budget):
+def _expected(q_np, meta_pool_np, meta_table, meta_last_len, kv_table, budget, layout=0):
     """Oracle chain on the device's own metadata bytes: scores, then (values, physical ids) of the top budget-1."""
-    meta = oracle.Paged(meta_pool_np, np.asarray(meta_table, np.int32), meta_last_len, oracle.NHD)
+    meta = oracle.Paged(meta_pool_np, np.asarray(meta_table, np.int32), meta_last_len, layout)
     est = oracle.estimate(q_np, meta)
     Hq = q_np.shape[1]
     table = np.asarray(kv_table, np.int32)
@@ -257,14 +257,20 @@ def _prefill(ctl, k, v):
     ctl.end_forward()
 
 
-def test_cfg3_headline_on_the_timed_path():
+@pytest.mark.parametrize("layout", [0, 1], ids=["NHD", "HND"])
+def test_cfg3_headline_on_the_timed_path(layout):
     """BASELINE configs[2] (the headline: Hq = Hkv = 32, D = 128, L = 32768, budget 2048 tokens = 128 pages) through the
     launches bench.py TIMES -- device-resident step state, `step_advance_dyn` + `decode_layer_dyn`, pool capacity of the
     bench's default run (2179 pages -> 8 keys per thread, 8-wave workgroups, 16 per head) -- against the oracle: pools,
     page scores, selected pages (ids + values) bit-exact, attention within 5e-3 of fp32 torch over the selected tokens
     and 2e-3 of the eager fused launch.  Asserts the launch IS sparse_decode_kernel<128,16,8,8,3> and that the other
-    front ends (column-range ownership, scalar-load staging) select the same pages."""
+    front ends (column-range ownership, scalar-load staging) select the same pages.  Both pool layouts (the reference's
+    default NHD is the bench's; HND puts a (page, head) tile in 4 contiguous KiB)."""
     import quest_amd.utils as qu
+
+    def entries(pool_pages):  # [n, 2, ...] pages of a pool layer -> (K-slot rows, V-slot rows) as [n * S, H, D]
+        x = pool_pages if layout == 0 else pool_pages.permute(0, 1, 3, 2, 4)
+        return x[:, 0].reshape(-1, H, D), x[:, 1].reshape(-1, H, D)
 
     L, H, B = 32768, 32, 128
     n_pages = L // PAGE
@@ -272,7 +278,7 @@ def test_cfg3_headline_on_the_timed_path():
     k = torch.randn(L, H, D, generator=g, device=DEV, dtype=torch.float16)
     v = torch.randn(L, H, D, generator=g, device=DEV, dtype=torch.float16)
     q = torch.randn(1, H, D, generator=g, device=DEV, dtype=torch.float16)
-    ctl = qu.InferenceController(1, H, D, PAGE, B, L + 2084, torch.float16, torch.device(DEV), shuffle_seed=33)
+    ctl = qu.InferenceController(1, H, D, PAGE, B, L + 2084, torch.float16, torch.device(DEV), shuffle_seed=33, layout=layout)
     _prefill(ctl, k, v)
     # eager fused launches (host-planned entry points) first: they leave the cache at L tokens
     ctl.prepare_metadata(1)
@@ -282,12 +288,11 @@ def test_cfg3_headline_on_the_timed_path():
     assert ctl._decode_handler.last_launch_info()["front_end_variant"] == 3
     ctl.end_forward()
     kp = k.view(n_pages, PAGE, H, D)
-    meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]
-    assert torch.equal(meta[:, 0].reshape(-1, H, D)[:n_pages], kp.amax(1))
-    assert torch.equal(meta[:, 1].reshape(-1, H, D)[:n_pages], kp.amin(1))
+    mmax, mmin = entries(ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()])
+    assert torch.equal(mmax[:n_pages], kp.amax(1)) and torch.equal(mmin[:n_pages], kp.amin(1))
     kv_table = list(ctl.kv_cache.indicies)
     e_est, ev, ei = _expected(q.cpu().numpy(), ctl.metadata_cache.buf_layer(0).cpu().numpy(), ctl.metadata_cache.indicies,
-                              ctl.metadata_cache.last_page_len, kv_table, B)
+                              ctl.metadata_cache.last_page_len, kv_table, B, layout)
     assert np.array_equal(U16(est.cpu().numpy()), U16(e_est))
     assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
     assert np.array_equal(U16(ctl.topk_dout_buffer.cpu().numpy()), U16(ev))
@@ -328,11 +333,11 @@ def test_cfg3_headline_on_the_timed_path():
     ctl._decode_handler.set_front_end(0)
     assert torch.equal(outs[0], o_eager) and torch.equal(outs[1], o_eager)  # same slot split: same bits
     assert not torch.equal(outs[4], o_eager)  # column ranges: another split (within 2e-3, asserted above)
-    meta = ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()]
-    assert torch.equal(meta[:, 0].reshape(-1, H, D)[:n_pages], kp.amax(1))
-    assert torch.equal(meta[:, 1].reshape(-1, H, D)[:n_pages], kp.amin(1))
-    last, slot = kv_table[-1], (L - 1) % PAGE
-    assert torch.equal(ctl.kv_cache.buf_layer(0)[last, 0, slot], k[-1]) and torch.equal(ctl.kv_cache.buf_layer(0)[last, 1, slot], v[-1])
+    mmax, mmin = entries(ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()])
+    assert torch.equal(mmax[:n_pages], kp.amax(1)) and torch.equal(mmin[:n_pages], kp.amin(1))
+    kk, vv = entries(ctl.kv_cache.buf_layer(0)[torch.tensor(kv_table[-1:], device=DEV)])
+    slot = (L - 1) % PAGE
+    assert torch.equal(kk[slot], k[-1]) and torch.equal(vv[slot], v[-1])
 
 
 @pytest.mark.parametrize("extra_tokens,stride", [(280, 2068), (264, 2068), (328, 2072)])
