@@ -400,6 +400,13 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
         if (p.n_chunks == 1) {
             sv.o[(size_t)hq * D + f] = (half_t)(acc / den);
             if (QUEST_LSE_ENABLED && p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
+#ifdef QUEST_WALLSTAMPS
+            if (f == 0 && sv.ws && p.ws_stride >= (uint32_t)D + 8u) {  // (this build allocates the workspace for one-chunk plans too)
+                unsigned* u = reinterpret_cast<unsigned*>(sv.ws + (size_t)hq * p.ws_stride + D + 2);
+                u[0] = ws_entry, u[1] = ws_fe, u[2] = ws_gather, u[3] = (unsigned)wall_clock64();
+                u[4] = slot_end > slot_begin ? slot_end - slot_begin : 0u;
+            }
+#endif
         } else {
             float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
             w[f] = acc;

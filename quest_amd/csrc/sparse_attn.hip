@@ -451,7 +451,12 @@ extern "C" int quest_decode_begin_forward(quest_decode_handler_t* h, uint32_t n_
     h->ws_stride = (head_dim + 2 + 31) / 32 * 32;
     const uint32_t max_chunks = h->n_chunks > h->shared_chunks ? h->n_chunks : h->shared_chunks;
     const size_t need = (size_t)h->batch * num_qo_heads * max_chunks * h->ws_stride * sizeof(float);
-    if (max_chunks > 1 && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
+#ifdef QUEST_WALLSTAMPS
+    const bool want_ws = true;  // one-chunk plans leave their per-workgroup stamps in the workspace as well
+#else
+    const bool want_ws = max_chunks > 1;
+#endif
+    if (want_ws && need > h->ws_bytes) {  // grow-only; reused across begin/end cycles
         float* bigger = nullptr;
         hipError_t e = hipMalloc((void**)&bigger, need);
         if (e != hipSuccess) return (int)e;

@@ -5,7 +5,9 @@ via QUEST_HIP_LIB, replays the graph and reads the stamps every workgroup of the
 partial-state record.
 
     python scripts/wallstamps.py --build            (here, cross-compiles)
-    python scripts/wallstamps.py [--front-end N]    (on the GPU box; N = quest_decode_set_front_end value, default 0)
+    python scripts/wallstamps.py [--front-end N] [--config N] [--ppc N] [--seqs N]
+                                                    (on the GPU box; N = quest_decode_set_front_end value, default 0;
+                                                     --seqs N: the batched launches of N sequences per GPU)
 """
 import ctypes
 import os
@@ -30,27 +32,38 @@ from quest_amd._lib import check, lib  # noqa: E402
 fe = int(sys.argv[sys.argv.index("--front-end") + 1]) if "--front-end" in sys.argv else 0
 cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "3"
 ppc = int(sys.argv[sys.argv.index("--ppc") + 1]) if "--ppc" in sys.argv else 0
-a = bench.parse(["--config", cfg, "--steps", "300"] + (["--pages-per-chunk", str(ppc)] if ppc else []))
+seqs = int(sys.argv[sys.argv.index("--seqs") + 1]) if "--seqs" in sys.argv else 1
+a = bench.parse(["--config", cfg, "--steps", "100" if seqs > 1 else "300"] + (["--pages-per-chunk", str(ppc)] if ppc else [])
+                + (["--seqs-per-gpu", str(seqs)] if seqs > 1 else []))
 dev = torch.device("cuda", 0)
-w = bench.Workload(a, dev)
-ctl = w.ctl
 from quest_amd import _kernels  # noqa: E402
 
-h = ctl._decode_handler
-h.set_front_end(fe)
-max_n = ctl.max_pages - 1
-bench_q = w.q
-o = [w.q[l].clone() for l in range(a.layers)]
-w.qu.step_advance_dyn(ctl)
-for l in range(a.layers):  # fill the score scratch of... (one scratch: the last layer's scores stay)
-    _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
-                                 ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n, ctl.layout)
+if a.seqs_per_gpu > 1:
+    seqs = a.seqs_per_gpu
+    w = bench.BatchedWorkload(a, dev, seqs)
+    ctl = w.ctl
+    h = ctl._decode_handler
+    h.set_front_end(fe)
+    max_n = ctl.max_pages - 1
+    w.qu.step_advance_batched(ctl)
 
+    def layer(l):  # the step's pair of launches (the scores must be this layer's)
+        _kernels.append_estimate_batched(w.k1[l], w.v1[l], ctl.kv_layer(l), ctl.kv_tables, w.q[l], w.scores,
+                                         ctl.metadata_layer(l), ctl.meta_tables, ctl.step_states, max_n, ctl.layout)
+        h.forward_fused_topk_batched(w.q[l], w.o[l], ctl.kv_layer(l), ctl.kv_tables, w.scores, ctl.step_states, max_n)
+else:
+    w = bench.Workload(a, dev)
+    ctl = w.ctl
+    h = ctl._decode_handler
+    h.set_front_end(fe)
+    max_n = ctl.max_pages - 1
+    o = [w.q[l].clone() for l in range(a.layers)]
+    w.qu.step_advance_dyn(ctl)
 
-def layer(l):  # the step's pair of launches (the scores must be this layer's)
-    _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
-                                 ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n, ctl.layout)
-    h.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores, ctl.step_state, max_n)
+    def layer(l):  # the step's pair of launches (the scores must be this layer's)
+        _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
+                                     ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n, ctl.layout)
+        h.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores, ctl.step_state, max_n)
 
 
 h.set_skip_merge(True)
@@ -69,7 +82,7 @@ info = h.last_launch_info()
 ptr, nbytes, rec = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32()
 check(lib.quest_decode_debug_workspace(h._wrapper._h, ctypes.byref(ptr), ctypes.byref(nbytes), ctypes.byref(rec)), "ws")
 hip = ctypes.CDLL("libamdhip64.so")
-H, C, R, D = a.heads, info["workgroups_per_head"], rec.value, a.head_dim
+H, C, R, D = a.heads * seqs, info["workgroups_per_head"], rec.value, a.head_dim
 host = np.empty(H * C * R, np.float32)
 rows = []
 for rep in range(12):
@@ -79,7 +92,7 @@ for rep in range(12):
     u = host.view(np.uint32).reshape(H, C, R)[:, :, D + 2:D + 7].astype(np.int64)
     if rep >= 2:
         rows.append(u.copy())
-print(f"== cfg {cfg}, front end {fe}: variant {info['front_end_variant']}, {info['waves']} waves, {C} workgroups per head "
+print(f"== cfg {cfg}, {seqs} sequence(s) per launch, front end {fe}: variant {info['front_end_variant']}, {info['waves']} waves, {C} workgroups per head "
       f"(last layer's launch, {len(rows)} replays; 10 ns ticks -> us)")
 for name, fn in (("kernel span (last end - first entry)", lambda u, t0: (u[..., 3].max() - t0)),
                  ("entry of the last workgroup to start", lambda u, t0: (u[..., 0].max() - t0)),
