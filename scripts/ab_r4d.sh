@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record: QUEST_FUSED_WAVES=16 existed only in the experiment tree -- 16-wave workgroups at cfg 3, 13.3-15.1 vs 12.07 us; git log -S QUEST_FUSED_WAVES.  QUEST_COLRANGE=1 with QUEST_TUNING=1 still selects column ranges.)
 # Round 4: 8-wave vs 16-wave workgroups (one per CU), column-range vs slot ownership, cfg 3.
 set -o pipefail
 O=$PWD/gpurun_out; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-4 experiment: the QUEST_SHARED_WAVES knob and the 8-wave group-shared instantiations were removed after this measurement -- 18.4 vs 17.8 us at cfg 2; git log -S QUEST_SHARED_WAVES)
 set -o pipefail
 O=$PWD/gpurun_out; mkdir -p $O
 for rep in 1 2; do

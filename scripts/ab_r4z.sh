@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-4 experiment: the QUEST_LONG_ROW_WAVES knob and the 16-wave long-row instantiation were removed after this measurement -- 21.3 vs 19.3 us at cfg 4; git log -S QUEST_LONG_ROW_WAVES)
 set -o pipefail
 O=$PWD/gpurun_out; mkdir -p $O
 QUEST_TUNING=1 QUEST_LONG_ROW_WAVES=16 timeout -k 10 300 python -m pytest tests/test_gpu_long_rows.py -m gpu -q -x -k "8192 or 16384 or 6000" > $O/r4z_tests.log 2>&1; echo "tests exit $?"; tail -3 $O/r4z_tests.log
