@@ -422,3 +422,84 @@ def test_cfg2_longchat_4096_tokens_budget_512_pages_full_kv():
         torch.testing.assert_close(o[0].float(), ref, rtol=5e-3, atol=5e-3)
         assert (o[0].float() - ref).abs().max() < 2e-3
     assert ctl.kv_cache.seqlen == L + 1 and len(ctl.kv_cache.indicies) == 257
+
+
+def test_cfg3_graph_replay_growth_at_full_size():
+    """The timed path while the sequence GROWS at the headline shape: one captured step (device-side reservation + fused
+    append/estimate + fused top-k/attention + merge) replayed for 90 tokens from 32724 tokens on, across five KV-page
+    boundaries and the metadata-page boundary at page 2048.  Every 30 tokens and at the end: page scores and selected
+    pages bit-exact vs the oracle on the device's own metadata, attention within 5e-3 of fp32 torch over the selected tokens;
+    at the end every appended token is in the pool and every page's metadata is the extrema of its keys."""
+    import quest_amd.utils as qu
+
+    H, B, steps = 32, 128, 90
+    L0 = 2045 * PAGE + 4
+    g = torch.Generator(device=DEV).manual_seed(11)
+    k0 = torch.randn(L0, H, D, generator=g, device=DEV, dtype=torch.float16)
+    v0 = torch.randn(L0, H, D, generator=g, device=DEV, dtype=torch.float16)
+    new_q = torch.randn(steps, 1, H, D, generator=g, device=DEV, dtype=torch.float16)
+    new_k = torch.randn(steps, 1, H, D, generator=g, device=DEV, dtype=torch.float16)
+    new_v = torch.randn(steps, 1, H, D, generator=g, device=DEV, dtype=torch.float16)
+    ctl = qu.InferenceController(1, H, D, PAGE, B, L0 + 2084, torch.float16, torch.device(DEV), shuffle_seed=44)
+    ctl.prepare_metadata(L0)
+    ctl.begin_forward(L0)
+    qu.append_kv(k0, v0, ctl, 0)
+    ctl.end_forward()
+    ctl.enable_device_state()
+    ctl.begin_graph_decode()
+    qbuf, kbuf, vbuf = torch.empty_like(new_q[0]), torch.empty_like(new_k[0]), torch.empty_like(new_v[0])
+    scores = qu.score_scratch(ctl).zero_()
+    sel_v = torch.zeros(1, H, B - 1, dtype=torch.float16, device=DEV)
+    sel_i = torch.full((1, H, B - 1), -1, dtype=torch.int32, device=DEV)
+    ctl._decode_handler.set_selection_out(sel_v, sel_i)
+    out = [None]
+
+    def step():
+        qu.step_advance_dyn(ctl)
+        out[0] = qu.decode_layer_dyn(qbuf, kbuf, vbuf, ctl, 0, scores)
+
+    qbuf.copy_(new_q[0]); kbuf.copy_(new_k[0]); vbuf.copy_(new_v[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()  # warm-up with token 0's inputs (the first replay appends the same token again: idempotent)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ctl.sync_device_state()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    info = ctl._decode_handler.last_launch_info()
+    assert (info["keys_per_thread"], info["waves"], info["front_end_variant"], info["workgroups_per_head"]) == (8, 8, 3, 16), info
+    for t in range(steps):
+        qbuf.copy_(new_q[t]); kbuf.copy_(new_k[t]); vbuf.copy_(new_v[t])
+        graph.replay()
+        ctl.prepare_metadata(1)
+        if t % 30 == 29 or t == steps - 1:
+            L = L0 + t + 1
+            n_pages = (L + PAGE - 1) // PAGE
+            kv_table = list(ctl.kv_cache.indicies)
+            assert len(kv_table) == n_pages and ctl.step_state.cpu().tolist()[:2] == [L, n_pages]
+            e_est, ev, ei = _expected(new_q[t].cpu().numpy(), ctl.metadata_cache.buf_layer(0).cpu().numpy(),
+                                      ctl.metadata_cache.indicies, ctl.metadata_cache.last_page_len, kv_table, B)
+            assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est)), f"token {t}: page scores"
+            assert np.array_equal(sel_i[0].cpu().numpy(), ei), f"token {t}: selected pages"
+            assert np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
+            k_all = torch.cat([k0, new_k[: t + 1, 0]])
+            v_all = torch.cat([v0, new_v[: t + 1, 0]])
+            o_ref = _torch_attention(new_q[t, 0], k_all, v_all, _logical(kv_table, ei), L)
+            torch.testing.assert_close(out[0][0].float(), o_ref, rtol=5e-3, atol=5e-3)
+    ctl._decode_handler.set_selection_out(None, None)
+    L = L0 + steps
+    n_pages = (L + PAGE - 1) // PAGE
+    assert n_pages == 2051 and len(ctl.metadata_cache.indicies) == 129  # crossed page 2048 = a new metadata page
+    k_all = torch.cat([k0, new_k[:, 0]])
+    v_all = torch.cat([v0, new_v[:, 0]])
+    pool = ctl.kv_cache.buf_layer(0)[torch.tensor(ctl.kv_cache.indicies, device=DEV)]  # [n_pages, 2, S, H, D]
+    assert torch.equal(pool[:, 0].reshape(-1, H, D)[:L], k_all) and torch.equal(pool[:, 1].reshape(-1, H, D)[:L], v_all)
+    meta = ctl.metadata_cache.buf_layer(0)[torch.tensor(ctl.metadata_cache.indicies, device=DEV)]
+    pad = n_pages * PAGE - L
+    kp_max = torch.cat([k_all, torch.full((pad, H, D), -65504.0, dtype=torch.float16, device=DEV)]).view(n_pages, PAGE, H, D).amax(1)
+    kp_min = torch.cat([k_all, torch.full((pad, H, D), 65504.0, dtype=torch.float16, device=DEV)]).view(n_pages, PAGE, H, D).amin(1)
+    assert torch.equal(meta[:, 0].reshape(-1, H, D)[:n_pages], kp_max)
+    assert torch.equal(meta[:, 1].reshape(-1, H, D)[:n_pages], kp_min)
