@@ -63,7 +63,11 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
     constexpr int LPR = D / kVec, R = kWave / LPR, S_T = 16, T = (S_T + R - 1) / R;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int row = lane / LPR, col = lane % LPR;
-    const uint32_t chunk = blockIdx.x, hk = blockIdx.y;
+    // grid order (launch_shared): (chunks, kv heads) or, with the NHD pool, (kv heads, chunks) -- p.xcd_period != 0, the
+    // preloaded field the per-head kernel uses for its own grid order -- so that workgroups adjacent in dispatch order read
+    // the 256-byte pieces of the SAME token rows next to each other (a page's rows are 8 KiB of heads side by side)
+    const bool heads_first = p.xcd_period != 0;
+    const uint32_t chunk = heads_first ? blockIdx.y : blockIdx.x, hk = heads_first ? blockIdx.x : blockIdx.y;
     const SeqView sv = select_sequence(p, a_num_qo_heads, D, blockIdx.z);
     if (p.state) {  // state-driven launch: the plan (chunks) was made for the pool capacity; workgroups whose
                     // chunk lies past the live page list write an empty partial (weight 0 in the merge)
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
     const uint32_t step = R * p.st.entry;
     RowState<D> st[GS];
 
-    [[maybe_unused]] const size_t app_in_off = ((size_t)blockIdx.z * gridDim.y + hk) * D + col * kVec;
+    [[maybe_unused]] const size_t app_in_off = ((size_t)blockIdx.z * (a_num_qo_heads / GS) + hk) * D + col * kVec;
     // APPEND: the lanes (of the ONE wave per kv head that attends the current page) that hold the new token's row.  Their
     // metadata loads are issued here and consumed after the page loop; the stores come after the loop as well -- issued in
     // front of it they sat in the wave's vmcnt queue ahead of its K/V loads, whose first wait then also waited for the
@@ -782,11 +786,17 @@ extern "C" int quest_decode_forward(quest_decode_handler_t* h, const void* q, vo
 }
 
 template <int D>
-static int launch_shared(const quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t gs,
+static int launch_shared(const quest_decode_handler* h, const DecodeParams& p_in, uint32_t num_qo_heads, uint32_t gs,
                          hipStream_t s, uint32_t n_seqs) {
     // (8-wave workgroups for group sizes 1 / 2 -- 16 waves per CU instead of 8, each with one page in flight -- measured
     // slower in round 4: cfg 2 18.4 vs 17.8 us per layer, the 32K dense kernel 94.4 vs 92.4 us)
+    static const char* order_env = quest_tuning_env("QUEST_SHARED_HEADS_FIRST");
+    const bool nhd = p_in.st.head < p_in.st.entry;
+    const bool heads_first = order_env ? atoi(order_env) != 0 : nhd && num_qo_heads / gs > 1;
+    DecodeParams p = p_in;
+    p.xcd_period = heads_first ? 1u : 0u;
     dim3 grid(p.n_chunks, num_qo_heads / gs, n_seqs), block(4 * kWave);
+    if (heads_first) grid = dim3(num_qo_heads / gs, p.n_chunks, n_seqs);
 #define QUEST_SHARED_CASE(GS)                                                                                                  \
     case GS:                                                                                                                   \
         if (p.app_k)                                                                                                           \
