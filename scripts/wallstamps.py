@@ -119,3 +119,12 @@ for i in order:
     hq, c = divmod(int(i), C)
     r = u[hq, c]
     print(f"    ({hq:2d},{c:2d}) {int(r[4]):3d}  {(r[0]-t0)*0.01:5.2f} {(r[1]-t0)*0.01:5.2f} {(r[2]-t0)*0.01:5.2f} {(r[3]-t0)*0.01:5.2f}")
+if "--per-head" in sys.argv:  # front end per head, mean over the head's workgroups and the replays: data- or placement-dependent?
+    fe_all = np.stack([(x[..., 1] - x[..., 0]) * 0.01 for x in rows])  # [replay][head][chunk]
+    per_head = fe_all.mean(axis=(0, 2))
+    spread = fe_all.mean(axis=2).std(axis=0)
+    print("  front end per head (us, mean over workgroups and replays; std over replays):")
+    for h0 in range(0, H, 8):
+        print("    " + "  ".join(f"{h0 + i:3d}: {per_head[h0 + i]:5.2f}±{spread[h0 + i]:.2f}" for i in range(min(8, H - h0))))
+    per_chunk = fe_all.mean(axis=(0, 1))
+    print("  front end per chunk index (us): " + " ".join(f"{x:.2f}" for x in per_chunk))
