@@ -254,6 +254,11 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
 // (The kernel parameters it needs travel BY VALUE in AttendArgs, built field by field by the caller: handing the
 // callers' modified copy of DecodeParams over by reference left a 32-byte slice of it in memory, which the compiler then
 // "promoted" to LDS -- 16 KiB per workgroup, one workgroup per CU instead of two, 24 us instead of 12 at cfg 3.)
+#ifdef QUEST_TL_FIRST_HEAD  // timeline builds: stamp a workgroup of head 0 (the FIRST workgroup dispatched to its CU) instead
+#define QUEST_TL_HEAD(n) 0u  // of the middle head (the second one, which waits for the first one's issue slots)
+#else
+#define QUEST_TL_HEAD(n) ((n) / 2)
+#endif
 struct AttendArgs {
     const half_t* kv;
     PoolStrides st;
@@ -717,7 +722,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
     } QUEST_TL_ARG QUEST_WS_ARG);
 #ifdef QUEST_TIMELINE
     QUEST_STAMP(9);
-    if (p.lse && chunk == p.n_chunks / 2 && hq == num_qo_heads / 2 && seq == 0 && threadIdx.x == 0) {
+    if (p.lse && chunk == p.n_chunks / 2 && hq == QUEST_TL_HEAD(num_qo_heads) && seq == 0 && threadIdx.x == 0) {
         for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
         if constexpr (FC > 0)
             for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
@@ -827,7 +832,7 @@ __device__ __forceinline__ void sparse_decode_colrange_body(DecodeParams p, cons
                             [&](uint32_t slot) -> int32_t { return s_list[slot]; } QUEST_TL_ARG QUEST_WS_ARG);
 #ifdef QUEST_TIMELINE
     QUEST_STAMP(9);
-    if (p.lse && chunk == p.n_chunks / 2 && hq == num_qo_heads / 2 && seq == 0 && threadIdx.x == 0) {
+    if (p.lse && chunk == p.n_chunks / 2 && hq == QUEST_TL_HEAD(num_qo_heads) && seq == 0 && threadIdx.x == 0) {
         for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
         for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
         p.lse[10] = (float)(wall_clock64() - wall0);

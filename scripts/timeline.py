@@ -14,7 +14,8 @@ VARIANT = os.path.join(ROOT, "quest_amd", "libquest_hip_timeline.so")
 
 if "--build" in sys.argv:
     from quest_amd.build import build_variant
-    print(build_variant(VARIANT, ["-DQUEST_TIMELINE"]))
+    # TL_FIRST_HEAD=1: stamp a workgroup of head 0 (first workgroup of its CU) instead of the middle head
+    print(build_variant(VARIANT, ["-DQUEST_TIMELINE"] + (["-DQUEST_TL_FIRST_HEAD"] if os.environ.get("TL_FIRST_HEAD") else [])))
     sys.exit(0)
 
 os.environ["QUEST_HIP_LIB"] = VARIANT
