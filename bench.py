@@ -84,6 +84,10 @@ def parse(argv=None):
                     help="batched mode: split the local sequences into this many groups, each a batched workload over its "
                          "own pool on its own stream (one hipGraph for all): a group's selection prologue and dispatch "
                          "gaps run under another group's streaming (experiment, DESIGN.md 3.5)")
+    ap.add_argument("--layer-launches", choices=["auto", "one", "two"], default="auto",
+                    help="batched sparse layers: one launch per layer (a workgroup per (sequence, head) appends, scores into "
+                         "LDS, selects and gathers: csrc/layer_device.cuh) or the two launches append+estimate | "
+                         "top-k+attention; auto = one launch where the plan allows it (MHA batches that fill the chip)")
     ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
     ap.add_argument("--separate-dense-append", action="store_true",
                     help="full-KV layers: issue the decode append as its own launch (three launches per layer, as before "
@@ -316,6 +320,9 @@ class BatchedWorkload:
             self.ctl._decode_handler.set_pages_per_chunk(a.pages_per_chunk)
         self.ctl.begin_graph_decode()
         self.scores = qu.score_scratch(self.ctl)
+        if a.layer_launches != "auto":
+            self.ctl.one_launch_layers = a.layer_launches == "one"
+        self.one_launch = False  # set by the first step: did the layers take the one-launch kernel?
 
     def step(self):
         qu, b, a = self.qu, self.ctl, self.a
@@ -323,6 +330,7 @@ class BatchedWorkload:
         for layer in range(a.layers):
             qu.decode_layer_batched(self.q[layer], self.k1[layer], self.v1[layer], b, layer, self.scores,
                                     out=self.o[layer])
+        self.one_launch = b._decode_handler.last_launch_info()["front_end_variant"] == 7
 
     def after_replay(self):
         self.ctl.prepare_metadata(1)
@@ -435,6 +443,49 @@ def step_op_times(w, a, bpl, reps=10):
                                            ctl.step_state, max_n)
 
     ppc, chunks = handler.plan_info()
+    if isinstance(w, BatchedWorkload) and w.one_launch:
+        # the timed step's layer is ONE launch (layer_decode_kernel): it is the dominant -- the only -- kernel
+        def layer(l):
+            assert handler.layer_fused_batched(w.k1[l], w.v1[l], b.metadata_layer(l), b.meta_tables, w.q[l], w.o[l],
+                                               b.kv_layer(l), b.kv_tables, b.step_states, max_n, b.page_budgets)
+
+        t_layer = time_kernel_loop(layer, a.layers, reps)
+        li = handler.last_launch_info()
+        assert li["front_end_variant"] == 7, li
+        kname = f"layer_decode_kernel<{a.head_dim},{li['keys_per_thread']},{li['waves']}>"
+        alg = n * bpl["chain"]
+        achieved = alg / (t_layer * 1e-6) / 1e9
+        t_ae = time_kernel_loop(ae, a.layers, reps)   # the two launches it replaces, for comparison
+        t_ts = time_kernel_loop(ts, a.layers, reps)
+        ops = {"layer_us": t_layer, "two_launch_form_append_estimate_us": t_ae, "two_launch_form_topk_sparse_attn_us": t_ts,
+               "note": "per launch inside a hipGraph of one launch per layer (each on its own pool), dependent-launch "
+                       "boundary included; layer_us = the launch of the timed step"}
+        roof = {"bound": "hbm",
+                "kernel": f"{kname} (the whole layer in one launch: a workgroup per (sequence, head) appends, scores its "
+                          "head's pages into LDS, selects from LDS, gathers the selected K/V pages; algorithmic bytes = the "
+                          "chain's, SURVEY 8d: A + E + T + S)",
+                "kernel_name": kname, "launch": li,
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg, "launch_us": t_layer, "sequences_per_launch": n,
+                "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}}
+        t_ae_ts = t_layer
+    else:
+        t_ae_ts = None
+    if t_ae_ts is None:
+        ops, roof, t_ae_ts = _two_launch_op_times(w, a, bpl, reps, ae, ts, handler, ppc, chunks, n)
+    if isinstance(w, BatchedWorkload) and not a.no_dense:
+        # full-KV decode of the same batch in one launch (group-shared kernel over every page of every sequence)
+        b.begin_graph_decode(dense_layers=True)
+        t_dense = time_kernel_loop(lambda l: b._dense_handler.forward_shared_batched(w.q[l], w.o[l], b.kv_layer(l),
+                                                                                      b.kv_tables, b.step_states),
+                                   a.layers, 3)
+        ops.update({"batched_dense_full_kv_us": t_dense, "batched_dense_full_kv_us_per_sequence": t_dense / n,
+                    "batched_dense_gbs": n * bpl["dense"] / (t_dense * 1e-6) / 1e9,
+                    "speedup_vs_batched_dense_ops": t_dense / t_ae_ts})
+    return ops, roof
+
+
+def _two_launch_op_times(w, a, bpl, reps, ae, ts, handler, ppc, chunks, n):
     t_ae = time_kernel_loop(ae, a.layers, reps)
     t_ts = time_kernel_loop(ts, a.layers, reps)
     handler.set_skip_merge(True)  # the attention kernel by itself (partial states stay in the workspace)
@@ -458,16 +509,7 @@ def step_op_times(w, a, bpl, reps=10):
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": alg, "launch_us": t_ts_kernel, "sequences_per_launch": n,
             "op_us_with_merge": t_ts, "plan": {"pages_per_workgroup": ppc, "workgroups_per_head": chunks}}
-    if isinstance(w, BatchedWorkload) and not a.no_dense:
-        # full-KV decode of the same batch in one launch (group-shared kernel over every page of every sequence)
-        b.begin_graph_decode(dense_layers=True)
-        t_dense = time_kernel_loop(lambda l: b._dense_handler.forward_shared_batched(w.q[l], w.o[l], b.kv_layer(l),
-                                                                                      b.kv_tables, b.step_states),
-                                   a.layers, 3)
-        ops.update({"batched_dense_full_kv_us": t_dense, "batched_dense_full_kv_us_per_sequence": t_dense / n,
-                    "batched_dense_gbs": n * bpl["dense"] / (t_dense * 1e-6) / 1e9,
-                    "speedup_vs_batched_dense_ops": t_dense / (t_ae + t_ts)})
-    return ops, roof
+    return ops, roof, t_ae + t_ts
 
 
 def reference_op_times(w, a, bpl, reps=10):
@@ -703,7 +745,8 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
                        "kv_layout": a.layout, "mode": a.mode, "seed": a.seed, "skip_layers": a.skip_layers,
                        "launches_per_layer": "5 (reference op sequence)" if a.unfused else
-                       "3 (append+estimate | top-k+sparse attn | merge)",
+                       "1 (a workgroup per (sequence, head): append + estimate into LDS + top-k from LDS + sparse attn)"
+                       if getattr(w, "one_launch", False) else "3 (append+estimate | top-k+sparse attn | merge)",
                        "sequences_per_gpu": n_local,
                        "multi_sequence": ("batched launches, shared pool" if batched else "one stream per sequence")
                        if n_local > 1 else None,
@@ -835,7 +878,8 @@ def main():
                 if not stub:
                     torch.cuda.empty_cache()
                 a2 = parse(["--config", str(overrides["config"]), "--steps", str(a.side_steps), "--warmup", str(a.warmup),
-                            "--seed", str(a.seed), "--no-cpu-baseline", "--gpus", str(a.gpus)]
+                            "--seed", str(a.seed), "--no-cpu-baseline", "--gpus", str(a.gpus),
+                            "--layer-launches", a.layer_launches]
                            + (["--seqs-per-gpu", str(overrides["seqs_per_gpu"])] if "seqs_per_gpu" in overrides else []))
                 try:
                     full = measure(a2, dev, dist, world_seen, rank, stub, side=True)
@@ -857,6 +901,10 @@ def main():
                     "dominant_kernel": roof.get("kernel"), "dominant_kernel_launch_us": roof.get("launch_us"),
                     "dominant_kernel_frac_algorithmic": roof.get("frac"), "dominant_kernel_frac_hbm_pmc": roof.get("frac_hbm_pmc"),
                     "dominant_kernel_traffic_bytes": roof.get("traffic"), "traffic_source": roof.get("traffic_source"),
+                    "launches_per_layer": full["config"]["launches_per_layer"],
+                    "two_launch_form_us": ([ops.get("two_launch_form_append_estimate_us"),
+                                            ops.get("two_launch_form_topk_sparse_attn_us")]
+                                           if "layer_us" in ops else None),
                     "append_estimate_us": ops.get("append_estimate_us"),
                     "append_estimate_frac_of_hbm_peak": ops.get("append_estimate_frac_of_hbm_peak"),
                     "batched_dense_full_kv_us_per_sequence": ops.get("batched_dense_full_kv_us_per_sequence"),

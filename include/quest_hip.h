@@ -303,6 +303,24 @@ int quest_decode_append_forward_shared_batched(quest_decode_handler_t* h, const 
                                                const quest_step_state_t* state, quest_batch_t batch, float* lse,
                                                quest_stream_t stream);
 /*
+ * One launch per layer of a batched decode step (round 5): quest_append_estimate_batched +
+ * quest_decode_forward_fused_topk_batched as ONE grid of (sequence, query head) workgroups, each of which owns its head
+ * end to end -- appends its kv head's new token (QuestAttention.py:106, page.cu:6-99), scores its head's pages into LDS
+ * (:136, estimate.cu:6-84), selects from LDS (:144, topk.cu:7-46) and gathers the selected pages + the current one
+ * (:147-157, approx_attn.cu:68-151).  No score scratch, no cross-workgroup hand-off, the same pool bytes, selections and
+ * outputs as the two launches.  k, v: [n_seqs][kv heads][head_dim] (not yet in the pool); metadata / paged_kv: the
+ * layer's pools (same geometry) with indices = the stacked page tables; max_n_scores = page capacity - 1.
+ * scores_out: optional inspection copy of the page scores, [n_seqs][num_qo_heads][score_stride] fp16 (NULL: they stay
+ * in LDS); the selection can be inspected with quest_decode_set_selection_out.
+ * Serves plans with ONE workgroup per head (quest_decode_set_batch + begin_forward on a batch that fills the chip),
+ * page_size 16, head_dim 64 / 128, at most 127 selected pages, rows up to 4096 pages; QUEST_EUNSUPPORTED otherwise
+ * (issue the two launches then).
+ */
+int quest_decode_layer_fused_batched(quest_decode_handler_t* h, const void* k, const void* v, quest_paged_kv_t metadata,
+                                     const void* q, void* o, quest_paged_kv_t paged_kv, uint32_t num_qo_heads,
+                                     uint32_t max_n_scores, const quest_step_state_t* state, quest_batch_t batch,
+                                     void* scores_out, uint32_t score_stride, float* lse, quest_stream_t stream);
+/*
  * The four operators of a decode step one by one for a whole batch (the state-driven counterparts of
  * append_kv_cache_decode / estimate_attn_score / topk_filtering / BatchDecodeWithPagedKVCache.forward, bsk_ops.h:38-116,
  * as quest/utils/__init__.py:141-276 calls them per request): quest_append_kv_cache_decode_batched above, and

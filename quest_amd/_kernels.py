@@ -832,6 +832,43 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
                                                           state.data_ptr(), b, None, _stream(q)),
               "BatchDecodeWithPagedKVCache")
 
+    def layer_fused_batched(self, k, v, metadata_data, meta_tables, q, o, paged_kv_data, kv_tables, state,
+                            max_n_scores: int, budgets=None, scores_out=None) -> bool:
+        """One launch per layer of a batched step: ``append_estimate_batched`` + ``forward_fused_topk_batched`` as one
+        grid of (sequence, head) workgroups that keep the page scores in LDS (csrc/layer_device.cuh).  Same pool bytes,
+        selections and outputs.  ``scores_out``: optional ``[n, Hq, >= max_n_scores]`` fp16 inspection copy of the
+        scores.  Returns False (nothing launched) when the plan / shape is outside what the launch serves."""
+        for t, n in ((k, "k"), (v, "v"), (metadata_data, "metadata_data"), (q, "q"), (o, "o"),
+                     (paged_kv_data, "paged_kv_data"), (state, "state")):
+            _check_input(t, n)
+        b = _batch(state, kv_tables, meta_tables, budgets)
+        _check_dim(3, q, "q")
+        _check_dim(3, k, "k")
+        _check_eq(q.size(0), b.n_seqs, "q.size(0), n_seqs")
+        _check_eq(k.size(0), b.n_seqs, "k.size(0), n_seqs")
+        _check_eq(tuple(o.shape), tuple(q.shape), "o.shape, q.shape")
+        _check_eq(tuple(k.shape), tuple(v.shape), "k.shape, v.shape")
+        _check_half(q, "BatchDecodeWithPagedKVCache")
+        _check_half(k, "BatchDecodeWithPagedKVCache")
+        kv = _paged(paged_kv_data, kv_tables, None, 1, 0, self._layout)
+        _check_eq(tuple(k.shape[-2:]), (kv.num_heads, kv.head_dim), "k.shape[-2:], (kv heads, head_dim)")
+        meta = _paged(metadata_data, meta_tables, None, 1, 0, self._layout)
+        sc_ptr, sc_stride = None, 0
+        if scores_out is not None:
+            _check_input(scores_out, "scores_out")
+            _check_dim(3, scores_out, "scores_out")
+            _check_eq(tuple(scores_out.shape[:2]), tuple(q.shape[:2]), "scores_out.shape[:2], (n_seqs, num_qo_heads)")
+            _check_ge(scores_out.size(2), max_n_scores, "scores_out.size(2), max_n_scores")
+            _check_half(scores_out, "BatchDecodeWithPagedKVCache")
+            sc_ptr, sc_stride = scores_out.data_ptr(), scores_out.size(2)
+        code = lib.quest_decode_layer_fused_batched(self._h, k.data_ptr(), v.data_ptr(), meta, q.data_ptr(), o.data_ptr(), kv,
+                                                    q.size(1), int(max_n_scores), state.data_ptr(), b, sc_ptr, sc_stride,
+                                                    None, _stream(q))
+        if code == -2:
+            return False
+        check(code, "BatchDecodeWithPagedKVCache")
+        return True
+
     def forward_shared_batched(self, q, o, paged_kv_data, kv_tables, state) -> None:
         for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (state, "state")):
             _check_input(t, n)

@@ -77,6 +77,8 @@ SIGNATURES = {
                                                       c_vp, Batch, c_vp]),
     "quest_decode_forward_fused_topk_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32,
                                                                 c_vp, Batch, c_vp, c_vp]),
+    "quest_decode_layer_fused_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_vp, c_vp, PagedKV, c_u32, c_u32, c_vp,
+                                                         Batch, c_vp, c_u32, c_vp, c_vp]),
     "quest_append_kv_cache_decode_batched": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp, Batch, c_vp]),
     "quest_decode_forward_shared_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, Batch, c_vp, c_vp]),
     "quest_apply_rope_in_place_batched": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, Batch,

@@ -278,11 +278,24 @@ __device__ __forceinline__ AttendArgs attend_args(const DecodeParams& p) {
     a.lse = p.lse;
     return a;
 }
-template <int D, int S_T, int NW, typename PageOf>
+// APPEND (layer_decode_kernel, layer_device.cuh): the decode append rides in the gather.  The new token's row of the
+// sequence's current page is not in the pool yet: the wave that folds the current page takes it from the inputs (k / v of
+// this kv head) instead, and the ONE workgroup per kv head marked `writer` stores it -- and the page's folded (max, min)
+// metadata entry -- after the page loop (stores in front of it would sit in the wave's vmcnt queue ahead of its K/V
+// loads).  `mx` / `mn`: the metadata entry as it was before this token (requested at kernel entry, unconditionally).
+struct AppendRow {
+    const half_t* k;   // the kv head's new key / value [D]
+    const half_t* v;
+    half_t* meta_entry;  // the current page's metadata entry of this kv head (max; min is st.v_off further)
+    ushort8 mx, mn;
+    bool writer;
+};
+struct NoAppend {};
+template <int D, int S_T, int NW, bool APPEND = false, typename PageOf, typename App = NoAppend>
 __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView sv, const half8 q_raw, const uint32_t chunk,
                                              const uint32_t hq, const uint32_t slot_begin, const uint32_t slot_end,
                                              const uint32_t n_listed, const int wave, const int lane,
-                                             PageOf page_of QUEST_TL_PARAM QUEST_WS_PARAM) {
+                                             PageOf page_of QUEST_TL_PARAM QUEST_WS_PARAM, const App app = App{}) {
     constexpr int LPR = D / kVec, R = kWave / LPR;
     const int row = lane / LPR, col = lane % LPR;
     RowState<D> st;
@@ -291,6 +304,13 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
     const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
     float8 qv = to_f32(q_raw);
     qv *= p.scale_log2;
+    [[maybe_unused]] half8 app_kn, app_vn;
+    [[maybe_unused]] const uint32_t app_e = p.last_page_len - 1u;  // row of the new token in the current page
+    if constexpr (APPEND) {
+        static_assert(S_T > 0, "the fused append serves the compile-time page size");
+        app_kn = ld8(app.k + col * kVec);
+        app_vn = ld8(app.v + col * kVec);
+    }
     // physical page of a slot: a listed page, or the sequence's current page for slots at or beyond n_listed
     auto slot_page = [&](uint32_t slot) -> int32_t {
         if (slot >= n_listed) return p.last_page_idx;
@@ -326,6 +346,14 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
                     k[T + t] = ld8_kv(b1 + lane_off + t * step);
                     v[T + t] = ld8_kv(b1 + lane_off + t * step + p.st.v_off);
                 }
+                if constexpr (APPEND) {
+                    if (s0 >= n_listed || s1 >= n_listed) {  // wave-uniform: one of the two is the current page
+                        const int at = s0 >= n_listed ? 0 : T;
+#pragma unroll
+                        for (int t = 0; t < 2 * T; ++t)
+                            if (t >= at && t < at + T && (uint32_t)((t - at) * R + row) == app_e) k[t] = app_kn, v[t] = app_vn;
+                    }
+                }
                 fold_groups<D, 2 * T>(st, qv, k, v, left, row);
             } else {
                 half8 k0[T], v0[T];
@@ -335,6 +363,13 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
                     k0[t] = k[t];
                     v0[t] = v[t];
                     left0[t] = left[t];
+                }
+                if constexpr (APPEND) {
+                    if (s0 >= n_listed) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            if ((uint32_t)(t * R + row) == app_e) k0[t] = app_kn, v0[t] = app_vn;
+                    }
                 }
                 fold_groups<D, T>(st, qv, k0, v0, left0, row);
             }
@@ -360,6 +395,21 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
         }
     }
 
+    if constexpr (APPEND) {
+        // the wave that folded the current page (slot n_listed), the row of lanes at the new token's position
+        if (app.writer && slot_begin <= n_listed && n_listed < slot_end && (uint32_t)wave == (n_listed - slot_begin) % NW &&
+            (uint32_t)row == app_e % R) {
+            half_t* dst = const_cast<half_t*>(head_base) + (size_t)p.last_page_idx * p.st.page + lane_off + (app_e / R) * (R * p.st.entry);
+            st8(dst, app_kn);
+            st8(dst + p.st.v_off, app_vn);
+            const ushort8 k8 = __builtin_bit_cast(ushort8, app_kn);
+            // a token that opens a page starts from the sentinels, not from stale pool bytes
+            const ushort8 mx0 = app_e > 0 ? app.mx : (ushort8)(kHalfNegMax), mn0 = app_e > 0 ? app.mn : (ushort8)(kHalfMax);
+            uint16_t* me = reinterpret_cast<uint16_t*>(app.meta_entry) + col * kVec;
+            *reinterpret_cast<ushort8*>(me) = fold_max(mx0, k8);
+            *reinterpret_cast<ushort8*>(me + p.st.v_off) = fold_min(mn0, k8);
+        }
+    }
     QUEST_STAMP(6);
 #ifdef QUEST_WALLSTAMPS
     const unsigned ws_gather = (unsigned)wall_clock64();

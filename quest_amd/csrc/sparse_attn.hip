@@ -25,6 +25,7 @@
 
 #include "append_device.cuh"
 #include "decode_device.cuh"
+#include "layer_device.cuh"
 
 namespace quest {
 
@@ -42,6 +43,15 @@ __global__ __launch_bounds__(NW* kWave, (D >= 256 && NW >= 8) ? NW / 4 : NW / 2)
     if constexpr (VF == 4) sparse_decode_colrange_body<D, FC, NW, 1, 1>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else if constexpr (VF == 5) sparse_decode_colrange_body<D, FC, NW, 2, FC / 8>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+}
+
+// One launch per layer of a batched step: the workgroup of a (sequence, query head) appends, scores its head's pages into
+// LDS, selects from LDS and gathers (layer_device.cuh).  grid (1, Hq, n_seqs) -- the per-head-list kernel's, so the same
+// XCD-aware row order applies.
+template <int D, int FC, int NW>
+__global__ __launch_bounds__(NW* kWave, NW / 2) void layer_decode_kernel(QUEST_LAYER_HEAD_PARAMS, LayerParams p) {
+    layer_decode_body<D, FC, NW>(a_q, a_state, a_meta, a_meta_tables, a_kv_tables, a_n_cap, a_meta_table_stride,
+                                 a_kv_table_stride, a_pack, a_num_qo_heads, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -956,6 +966,86 @@ extern "C" int quest_decode_forward_fused_topk_batched(quest_decode_handler_t* h
     if (batch.n_seqs > 1 && batch.kv_table_stride < max_n_scores + 1) return QUEST_EINVAL;
     return decode_entry(h, q, o, kv, num_qo_heads, scores, max_n_scores, nullptr, nullptr, lse, (hipStream_t)stream,
                         score_stride, state, batch);
+}
+
+// append + estimate + top-k + sparse attention of one layer for a whole batch in ONE launch (layer_device.cuh).
+// QUEST_EUNSUPPORTED when the plan or the shape is outside what the launch serves: the caller then issues
+// quest_append_estimate_batched + quest_decode_forward_fused_topk_batched (same bits).
+extern "C" int quest_decode_layer_fused_batched(quest_decode_handler_t* h, const void* k, const void* v,
+                                                quest_paged_kv_t metadata, const void* q, void* o, quest_paged_kv_t kv,
+                                                uint32_t num_qo_heads, uint32_t max_n_scores,
+                                                const quest_step_state_t* state, quest_batch_t batch, void* scores_out,
+                                                uint32_t score_stride, float* lse, quest_stream_t stream) {
+    if (!h || !k || !v || !q || !o || !state || batch.n_seqs == 0 || max_n_scores == 0) return QUEST_EINVAL;
+    if (!h->started) return QUEST_ESTATE;
+    if (batch.n_seqs > h->batch) return QUEST_ESTATE;
+    kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
+    if (int e = check_pool(kv)) return e;
+    if (int e = check_pool(metadata)) return e;
+    if (kv.layout != h->layout || kv.head_dim != h->head_dim || kv.page_size != h->page_size ||
+        kv.num_heads != h->num_kv_heads || num_qo_heads != h->num_qo_heads)
+        return QUEST_EINVAL;
+    // the append and the estimate address the metadata pool with the KV pool's strides: same geometry required
+    if (metadata.layout != kv.layout || metadata.head_dim != kv.head_dim || metadata.page_size != kv.page_size ||
+        metadata.num_heads != kv.num_heads)
+        return QUEST_EINVAL;
+    if (scores_out && score_stride < max_n_scores) return QUEST_EINVAL;
+    if (batch.n_seqs > 1 && (batch.kv_table_stride < max_n_scores + 1 ||
+                             (uint64_t)batch.meta_table_stride * metadata.page_size < max_n_scores))
+        return QUEST_EINVAL;
+    // served: one workgroup per head (the planner's split for a batch that fills the chip), the whole selection in one
+    // workgroup's LDS list, page size 16, head_dim 128 / 64, rows the 8-keys-per-thread selection covers
+    constexpr uint32_t NW = 8, NT = NW * kWave, FC = 8;
+    if (h->n_chunks != 1 || h->n_sel + 1 > (uint32_t)kFusedMaxPpc || h->n_sel == 0) return QUEST_EUNSUPPORTED;
+    if (kv.page_size != 16 || (kv.head_dim != 128 && kv.head_dim != 64)) return QUEST_EUNSUPPORTED;
+    if (max_n_scores > FC * NT) return QUEST_EUNSUPPORTED;
+    LayerParams p{};
+    p.q = (const half_t*)q;
+    p.state = state;
+    p.meta = (const half_t*)metadata.data;
+    p.meta_tables = metadata.indices;
+    p.kv_tables = kv.indices;
+    p.n_cap = max_n_scores;
+    p.meta_table_stride = batch.meta_table_stride;
+    p.kv_table_stride = batch.kv_table_stride;
+    const uint32_t per_thread = (max_n_scores + NT - 1) / NT, r4 = (per_thread + 3) / 4 * 4;
+    p.cpt = r4 <= FC ? r4 : per_thread;
+    p.group = num_qo_heads / kv.num_heads;
+    {   // XCD-aware row order for GQA: one workgroup per head -> period 8 (see plan_decode)
+        static const bool xcd_group = [] { const char* e = quest_tuning_env("QUEST_XCD_GROUP"); return !e || atoi(e) != 0; }();
+        p.xcd_period = (xcd_group && p.group > 1 && num_qo_heads % 8u == 0 && (num_qo_heads / 8u) % p.group == 0) ? 8u : 1u;
+    }
+    p.k_new = (const half_t*)k;
+    p.v_new = (const half_t*)v;
+    p.kv = (half_t*)kv.data;
+    p.o = (half_t*)o;
+    p.lse = lse;
+#ifdef QUEST_WALLSTAMPS
+    p.ws = h->ws;
+#endif
+    p.budgets = batch.page_budgets;
+    p.scores_out = (uint16_t*)scores_out;
+    p.score_stride = score_stride;
+    p.sel_val_out = (uint16_t*)h->sel_val_out;
+    p.sel_idx_out = h->sel_idx_out;
+    p.sel_stride = h->n_sel;
+    p.st = pool_strides(kv);
+    p.n_sel = h->n_sel;
+    p.num_kv_heads = kv.num_heads;
+    p.ids_lds_offset = (uint32_t)((((size_t)max_n_scores * 2) + 15) & ~(size_t)15);
+    p.ws_stride = h->ws_stride;
+    p.scale_log2 = (float)(1.4426950408889634 / sqrt((double)kv.head_dim));
+    const size_t lds = (size_t)p.ids_lds_offset + (size_t)(max_n_scores + 1u) * 4u;
+    dim3 grid(1, num_qo_heads, batch.n_seqs), block(NT);
+    hipStream_t s = (hipStream_t)stream;
+    if (kv.head_dim == 128)
+        hipLaunchKernelGGL((layer_decode_kernel<128, FC, NW>), grid, block, lds, s, QUEST_LAYER_HEAD_ARGS(p, num_qo_heads), p);
+    else
+        hipLaunchKernelGGL((layer_decode_kernel<64, FC, NW>), grid, block, lds, s, QUEST_LAYER_HEAD_ARGS(p, num_qo_heads), p);
+    QUEST_LAUNCH_CHECK();
+    uint32_t* info = h->last_launch;  // front-end variant 7 = the one-launch layer (keys from LDS)
+    info[0] = FC, info[1] = NW, info[2] = 7u, info[3] = 1u, info[4] = 1u, info[5] = batch.n_seqs;
+    return 0;
 }
 
 extern "C" int quest_decode_forward_batched(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,

@@ -259,14 +259,32 @@ def step_advance_batched(bController: BatchedInferenceController) -> None:
 def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bController: BatchedInferenceController,
                          layer_idx: int, scores: torch.Tensor, rope_scale: Optional[float] = None,
                          rope_theta: Optional[float] = None, apply_rope: bool = False,
-                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``decode_layer_dyn`` for every sequence at once; ``scores`` is ``[n_seqs, Hq, >= max_pages]`` fp16."""
+                         out: Optional[torch.Tensor] = None, one_launch: Optional[bool] = None,
+                         write_scores: bool = False) -> torch.Tensor:
+    """``decode_layer_dyn`` for every sequence at once; ``scores`` is ``[n_seqs, Hq, >= max_pages]`` fp16.
+
+    ``one_launch``: None (default) = the controller's choice (``BatchedInferenceController.one_launch_layers``): ONE
+    launch per layer where the plan allows it -- one workgroup per (sequence, head) that appends, scores its head's pages
+    into LDS, selects from LDS and gathers (csrc/layer_device.cuh; the batch must fill the chip) -- else the two launches
+    append+estimate | top-k+attention; True / False force one of them (True raises where the one-launch form does not
+    apply).  Both produce the same pool bytes, selections and outputs.
+    ``write_scores``: the one-launch form also writes its page scores to ``scores`` (inspection; they otherwise never
+    leave the CU)."""
     b = bController
     _need_state(b)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_batched(q, k, scale, theta, b.step_states)
     max_n = b.max_pages - 1
+    if (b.one_launch_layers if one_launch is None else one_launch):
+        o = torch.empty_like(q) if out is None else out
+        if b._decode_handler.layer_fused_batched(k, v, b.metadata_layer(layer_idx), b.meta_tables, q, o, b.kv_layer(layer_idx),
+                                                 b.kv_tables, b.step_states, max_n, b.page_budgets,
+                                                 scores if write_scores else None):
+            return o
+        if one_launch:
+            raise RuntimeError("the one-launch layer does not serve this plan / shape (needs one workgroup per head, "
+                               "page_size 16, head_dim 64 / 128, <= 127 selected pages, rows <= 4096 pages)")
     _kernels.append_estimate_batched(k, v, b.kv_layer(layer_idx), b.kv_tables, q, scores, b.metadata_layer(layer_idx),
                                      b.meta_tables, b.step_states, max_n, b.layout)
     o = torch.empty_like(q) if out is None else out

@@ -246,6 +246,9 @@ class BatchedInferenceController:
         self.topk_dout_buffer = self.topk_dindices_buffer = None
         self._planned = None
         self._graph_planned = 0       # budget begin_graph_decode planned for (0: no graph plan)
+        # decode_layer_batched: one launch per layer (csrc/layer_device.cuh) where the plan allows it.  With GQA the query
+        # heads of a group would each stream their kv head's metadata (re-reads the two-launch form does not have)
+        self.one_launch_layers = self.num_heads == self.num_kv_heads
 
     # ---- per-sequence page budgets + eager (host-planned) batched steps.  The reference keeps one controller and one
     # page budget per request and loops over requests in Python (controller.py:39-41, :80-129: five list -> tensor

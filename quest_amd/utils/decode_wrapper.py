@@ -63,6 +63,11 @@ class BatchDecodeWithPagedKVCacheWrapper:
                                    budgets=None) -> None:
         self._wrapper.forward_fused_topk_batched(q, o, paged_kv_data, kv_tables, scores, state, max_n_scores, budgets)
 
+    def layer_fused_batched(self, k, v, metadata_data, meta_tables, q, o, paged_kv_data, kv_tables, state, max_n_scores: int,
+                            budgets=None, scores_out=None) -> bool:
+        return self._wrapper.layer_fused_batched(k, v, metadata_data, meta_tables, q, o, paged_kv_data, kv_tables, state,
+                                                 max_n_scores, budgets, scores_out)
+
     def forward_batched(self, q, o, paged_kv_data, indices, state, budgets=None) -> None:
         self._wrapper.forward_batched(q, o, paged_kv_data, indices, state, budgets)
 

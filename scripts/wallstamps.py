@@ -34,7 +34,8 @@ cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "3
 ppc = int(sys.argv[sys.argv.index("--ppc") + 1]) if "--ppc" in sys.argv else 0
 seqs = int(sys.argv[sys.argv.index("--seqs") + 1]) if "--seqs" in sys.argv else 1
 a = bench.parse(["--config", cfg, "--steps", "100" if seqs > 1 else "300"] + (["--pages-per-chunk", str(ppc)] if ppc else [])
-                + (["--seqs-per-gpu", str(seqs)] if seqs > 1 else []))
+                + (["--seqs-per-gpu", str(seqs)] if seqs > 1 else [])
+                + (sys.argv[sys.argv.index("--bench-args") + 1].split() if "--bench-args" in sys.argv else []))
 dev = torch.device("cuda", 0)
 from quest_amd import _kernels  # noqa: E402
 
@@ -47,7 +48,13 @@ if a.seqs_per_gpu > 1:
     max_n = ctl.max_pages - 1
     w.qu.step_advance_batched(ctl)
 
+    one_launch = "--one-launch" in sys.argv  # the one-launch layer (csrc/layer_device.cuh) instead of the pair
+
     def layer(l):  # the step's pair of launches (the scores must be this layer's)
+        if one_launch:
+            assert h.layer_fused_batched(w.k1[l], w.v1[l], ctl.metadata_layer(l), ctl.meta_tables, w.q[l], w.o[l],
+                                         ctl.kv_layer(l), ctl.kv_tables, ctl.step_states, max_n)
+            return
         _kernels.append_estimate_batched(w.k1[l], w.v1[l], ctl.kv_layer(l), ctl.kv_tables, w.q[l], w.scores,
                                          ctl.metadata_layer(l), ctl.meta_tables, ctl.step_states, max_n, ctl.layout)
         h.forward_fused_topk_batched(w.q[l], w.o[l], ctl.kv_layer(l), ctl.kv_tables, w.scores, ctl.step_states, max_n)
@@ -89,19 +96,27 @@ for rep in range(12):
     g.replay()
     torch.cuda.synchronize()
     assert hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), ptr, ctypes.c_size_t(host.nbytes), 2) == 0
-    u = host.view(np.uint32).reshape(H, C, R)[:, :, D + 2:D + 7].astype(np.int64)
+    u = host.view(np.uint32).reshape(H, C, R)[:, :, D + 2:D + 8].astype(np.int64)
     if rep >= 2:
         rows.append(u.copy())
 print(f"== cfg {cfg}, {seqs} sequence(s) per launch, front end {fe}: variant {info['front_end_variant']}, {info['waves']} waves, {C} workgroups per head "
       f"(last layer's launch, {len(rows)} replays; 10 ns ticks -> us)")
-for name, fn in (("kernel span (last end - first entry)", lambda u, t0: (u[..., 3].max() - t0)),
+for name, fn in ((("kernel span (last end - first entry)", lambda u, t0: (u[..., 3].max() - t0)),
                  ("entry of the last workgroup to start", lambda u, t0: (u[..., 0].max() - t0)),
                  ("median page list known", lambda u, t0: np.median(u[..., 1] - t0)),
                  ("  latest page list known", lambda u, t0: (u[..., 1].max() - t0)),
                  ("median wave-0 pages folded", lambda u, t0: np.median(u[..., 2] - t0)),
                  ("  latest wave-0 pages folded", lambda u, t0: (u[..., 2].max() - t0)),
-                 ("median partial written", lambda u, t0: np.median(u[..., 3] - t0))):
+                 ("median partial written", lambda u, t0: np.median(u[..., 3] - t0)))
+                + ((("median wave-0 scores done (one-launch layer)", lambda u, t0: np.median(u[..., 5] - t0)),
+                    ("  latest wave-0 scores done", lambda u, t0: (u[..., 5].max() - t0)),
+                    ("median end", lambda u, t0: np.median(u[..., 3] - t0)),
+                    ("  p10 / p90 end", lambda u, t0: np.percentile(u[..., 3] - t0, 10) + 1j * np.percentile(u[..., 3] - t0, 90)))
+                   if info["front_end_variant"] == 7 else ())):
     vals = [fn(u, u[..., 0].min()) * 0.01 for u in rows]
+    if np.iscomplexobj(np.asarray(vals)):
+        print(f"  {name:42s} {np.median([v.real for v in vals]):6.2f} / {np.median([v.imag for v in vals]):6.2f} us")
+        continue
     print(f"  {name:42s} {np.median(vals):6.2f} us  (min {min(vals):.2f}, max {max(vals):.2f})")
 u = rows[-1]
 t0 = u[..., 0].min()
@@ -128,3 +143,14 @@ if "--per-head" in sys.argv:  # front end per head, mean over the head's workgro
         print("    " + "  ".join(f"{h0 + i:3d}: {per_head[h0 + i]:5.2f}±{spread[h0 + i]:.2f}" for i in range(min(8, H - h0))))
     per_chunk = fe_all.mean(axis=(0, 1))
     print("  front end per chunk index (us): " + " ".join(f"{x:.2f}" for x in per_chunk))
+if "--matrix" in sys.argv and seqs > 1:  # medians over the replays, one row per sequence, one column per head
+    allr = np.stack(rows)  # [replay][seq*head][chunk][field]
+    t0s = allr[..., 0].min(axis=(1, 2))[:, None, None]
+    for name, col in (("scores done (wave 0)", 5), ("page list known", 1), ("end", 3)):
+        if col == 5 and info["front_end_variant"] != 7:
+            continue
+        m = np.median((allr[..., col] - t0s) * 0.01, axis=0)[:, 0].reshape(seqs, a.heads)
+        print(f"  {name}, us after the first entry (rows = sequences, columns = heads):")
+        for r in m:
+            print("    " + " ".join(f"{x:5.1f}" for x in r))
+        print("    column means: " + " ".join(f"{x:5.1f}" for x in m.mean(axis=0)))

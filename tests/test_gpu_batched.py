@@ -397,3 +397,118 @@ def _logical_pages(ctl, phys):
     table = ctl.kv_cache.indicies
     inv = {p: j for j, p in enumerate(table)}
     return torch.tensor([[inv[int(x)] for x in row] for row in phys.cpu().tolist()], dtype=torch.int64).reshape(phys.shape[0], -1)
+
+
+@pytest.mark.parametrize("Hq,Hkv,layout,D,B,lens,budgets,odd_q", [
+    # MHA, lengths across page / metadata-page boundaries during the replay, one sequence within the budget, one with 1 page
+    (4, 4, 0, 128, 7, (16 * 31 + 10, 16 * 15 + 16, 16 * 40 + 1, 19, 7), None, False),
+    (8, 8, 1, 128, 12, (16 * 47 + 3, 16 * 12 + 15, 16 * 16 + 16), None, False),
+    (4, 4, 0, 64, 9, (16 * 33 + 9, 16 * 50 + 16), None, False),
+    # per-sequence budgets below / above the page count
+    (4, 4, 0, 128, 30, (16 * 40 + 3, 16 * 9 + 16, 16 * 25 + 1, 5), (7, 30, 26, 4), False),
+    # zero / infinite query elements: the literal form of the estimate
+    (4, 4, 0, 128, 7, (16 * 21 + 5, 16 * 35 + 16), None, True),
+    # GQA: the query heads of a group are separate workgroups that re-read their kv head's metadata; one of them appends
+    (8, 2, 0, 128, 7, (16 * 22 + 3, 16 * 30 + 16, 16 * 17 + 1), None, False),
+    (32, 8, 0, 128, 6, (16 * 20 + 5, 16 * 9 + 16, 16 * 31 + 1, 16 * 12 + 7, 16 * 25 + 3, 16 * 8 + 2, 16 * 17 + 9, 16 * 30 + 16), None, False),
+])
+def test_one_launch_layer_equals_two_launches(Hq, Hkv, layout, D, B, lens, budgets, odd_q):
+    """The one-launch layer of a batched step (csrc/layer_device.cuh: a workgroup per (sequence, head) appends, scores its
+    head's pages into LDS, selects from LDS and gathers) against the two launches it replaces (append+estimate |
+    top-k+attention), both captured and replayed over the same tokens with one workgroup per head: page scores, selected
+    values and pages, outputs, step states and -- at the end -- every pool byte must be IDENTICAL (torch.equal)."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    layers, steps, n = 2, 40, len(lens)
+    # a capacity beyond 1024 pages: the two-launch form then gathers with 8-wave workgroups like the one-launch kernel (a
+    # head's pages are dealt over the waves, so another wave count is another fp32 fold order)
+    cap = 16 * 1040
+    ks = [cuda(inputs(400 + i, L, Hq, Hkv, D)[1]) for i, L in enumerate(lens)]
+    vs = [cuda(inputs(400 + i, L, Hq, Hkv, D)[2]) for i, L in enumerate(lens)]
+    g = torch.Generator(device=dev).manual_seed(15)
+    new_q = torch.randn(steps, layers, n, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, layers, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, layers, n, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    if odd_q:
+        new_q[::2, :, :, 0, 5] = 0.0
+        new_q[1::3, :, :, 1, 17] = float("inf")
+        new_q[::5, :, 0, 2, 40] = float("-inf")
+
+    class Run:
+        def __init__(self, one_launch):
+            self.one = one_launch
+            b = self.b = qu.BatchedInferenceController(n, layers, Hq, D, PAGE, B, cap, torch.float16, dev, num_kv_heads=Hkv,
+                                                       layout=layout, shuffle_seed=9)
+            for i in range(n):
+                _prefill(b.seqs[i], ks[i], vs[i], layers)
+            if budgets is not None:
+                b.set_page_budgets(budgets)
+            b.enable_device_state()
+            b._decode_handler.set_pages_per_chunk(B)  # one workgroup per head, whatever the batch size
+            b.begin_graph_decode()
+            assert b._decode_handler.plan_info() == (B, 1)
+            self.q = torch.empty(layers, n, Hq, D, device=dev, dtype=torch.float16)
+            self.k = torch.empty(layers, n, Hkv, D, device=dev, dtype=torch.float16)
+            self.v = torch.empty(layers, n, Hkv, D, device=dev, dtype=torch.float16)
+            self.scores = torch.zeros(layers, n, Hq, (b.max_pages + 7) // 8 * 8, device=dev, dtype=torch.float16)
+            self.o = torch.empty(layers, n, Hq, D, device=dev, dtype=torch.float16)
+            # the selection of the LAST layer of a step (one inspection buffer per handler)
+            self.sel_v = torch.zeros(n, Hq, B - 1, dtype=torch.float16, device=dev)
+            self.sel_i = torch.full((n, Hq, B - 1), -1, dtype=torch.int32, device=dev)
+            b._decode_handler.set_selection_out(self.sel_v, self.sel_i)
+            self.set_inputs(0)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.step()  # warm-up; the first replay folds the same token again (idempotent)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            info = b._decode_handler.last_launch_info()
+            assert info["front_end_variant"] == (7 if one_launch else info["front_end_variant"]) and info["workgroups_per_head"] == 1
+            assert (info["front_end_variant"] == 7) == one_launch and info["waves"] == 8, info
+            b.sync_device_state()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.step()
+            b.sync_device_state()
+
+        def set_inputs(self, t):
+            self.q.copy_(new_q[t]); self.k.copy_(new_k[t]); self.v.copy_(new_v[t])
+
+        def step(self):
+            qu.step_advance_batched(self.b)
+            for l in range(layers):
+                qu.decode_layer_batched(self.q[l], self.k[l], self.v[l], self.b, l, self.scores[l], apply_rope=True,
+                                        out=self.o[l], one_launch=self.one, write_scores=True)
+
+    def same(a, b):  # bit patterns (outputs / scores of non-finite queries are NaN: NaN != NaN under torch.equal)
+        return torch.equal(a.contiguous().view(torch.int16), b.contiguous().view(torch.int16))
+
+    two, one = Run(False), Run(True)
+    for t in range(steps):
+        for r in (two, one):
+            r.set_inputs(t)
+            r.graph.replay()
+            r.b.prepare_metadata(1)
+        assert torch.equal(one.b.step_states, two.b.step_states), f"token {t}: step states"
+        for i, c in enumerate(one.b.seqs):
+            n_out = len(c.kv_cache.indicies) - 1
+            assert same(one.scores[:, i, :, :n_out], two.scores[:, i, :, :n_out]), f"token {t} seq {i}: page scores"
+            k_i = min((budgets[i] if budgets else B) - 1, n_out)
+            assert torch.equal(one.sel_i[i, :, :k_i], two.sel_i[i, :, :k_i]), f"token {t} seq {i}: selected pages"
+            assert same(one.sel_v[i, :, :k_i], two.sel_v[i, :, :k_i]), f"token {t} seq {i}: selected values"
+        assert same(one.o, two.o), f"token {t}: outputs"
+    for r in (two, one):
+        r.b._decode_handler.set_selection_out(None, None)
+    for l in range(layers):  # same shuffle seed -> same physical pages: the pools must agree byte for byte on every page in use
+        for c1, c2 in zip(one.b.seqs, two.b.seqs):
+            assert list(c1.kv_cache.indicies) == list(c2.kv_cache.indicies)
+            L = c1.kv_cache.seqlen
+            k1, v1 = _gather(one.b.kv_layer(l), c1.kv_cache.indicies, L, layout)
+            k2, v2 = _gather(two.b.kv_layer(l), c2.kv_cache.indicies, L, layout)
+            assert torch.equal(k1, k2) and torch.equal(v1, v2), f"layer {l}: KV pool"
+            np_ = len(c1.kv_cache.indicies)
+            a1, b1 = _gather(one.b.metadata_layer(l), c1.metadata_cache.indicies, np_, layout)
+            a2, b2 = _gather(two.b.metadata_layer(l), c2.metadata_cache.indicies, np_, layout)
+            assert torch.equal(a1, a2) and torch.equal(b1, b2), f"layer {l}: metadata pool"

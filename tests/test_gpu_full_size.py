@@ -340,12 +340,15 @@ def test_cfg3_headline_on_the_timed_path(layout):
     assert torch.equal(kk[slot], k[-1]) and torch.equal(vv[slot], v[-1])
 
 
-@pytest.mark.parametrize("extra_tokens,stride", [(280, 2068), (264, 2068), (328, 2072)])
-def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride):
-    """The `batched_8seq` side measurement of bench.py (8 x cfg-3 MHA sequences, one launch per op) through its timed
-    entry points at the bench's own pool capacities -- 2066 / 2065 / 2069 pages per sequence, none a multiple of 4, which
-    used to push every batched launch onto the scalar-load front end: the stacked tables' stride is padded, the
-    launch is the vector-fed one-variant kernel, and results match the oracle per sequence."""
+@pytest.mark.parametrize("extra_tokens,stride,one_launch", [(280, 2068, True), (280, 2068, False), (264, 2068, True),
+                                                            (328, 2072, True), (328, 2072, False)])
+def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride, one_launch):
+    """The `batched_8seq` side measurement of bench.py (8 x cfg-3 MHA sequences) through its timed entry points at the
+    bench's own pool capacities -- 2066 / 2065 / 2069 pages per sequence, none a multiple of 4, which used to push every
+    batched launch onto the scalar-load front end.  one_launch: the layer as ONE launch (layer_decode_kernel: what the
+    bench times since round 5) or as the two launches append+estimate | top-k+attention (the stacked tables' stride is
+    padded, the launch is the vector-fed one-variant kernel).  Either way results match the oracle per sequence; the
+    one-launch run also repeats the layer with the two launches and requires identical bits."""
     import quest_amd.utils as qu
 
     n, H, B, L = 8, 32, 128, 32768
@@ -371,11 +374,21 @@ def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride
     b._decode_handler.set_selection_out(sel_v, sel_i)
     scores = qu.score_scratch(b).zero_()
     qu.step_advance_batched(b)
-    o = qu.decode_layer_batched(q, k1, v1, b, 0, scores)
-    b._decode_handler.set_selection_out(None, None)
+    assert b.one_launch_layers  # MHA: the default of the timed path
+    o = qu.decode_layer_batched(q, k1, v1, b, 0, scores, one_launch=one_launch, write_scores=True)
     info = b._decode_handler.last_launch_info()
-    assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": 1, "specialised": True,
+    assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": 7 if one_launch else 1, "specialised": True,
                     "workgroups_per_head": 1, "n_seqs": 8}, info
+    if one_launch:  # the same layer again as two launches (the append is idempotent): identical bits
+        sel_v2, sel_i2, scores2 = torch.zeros_like(sel_v), torch.full_like(sel_i, -1), torch.zeros_like(scores)
+        b._decode_handler.set_selection_out(sel_v2, sel_i2)
+        o2 = qu.decode_layer_batched(q, k1, v1, b, 0, scores2, one_launch=False)
+        assert b._decode_handler.last_launch_info()["front_end_variant"] == 1
+        assert torch.equal(o, o2) and torch.equal(sel_i, sel_i2) and torch.equal(sel_v, sel_v2)
+        for i, Li in enumerate(lens):
+            n_out = (Li + PAGE - 1) // PAGE - 1
+            assert torch.equal(scores[i, :, :n_out], scores2[i, :, :n_out])
+    b._decode_handler.set_selection_out(None, None)
     b.prepare_metadata(1)
     meta_np = b.metadata_layer(0).cpu().numpy()
     for i, (c, Li) in enumerate(zip(b.seqs, lens)):
