@@ -39,7 +39,20 @@ template <int D, int S_T, int FC, int NW, int VF = -1>
 __global__ __launch_bounds__(NW* kWave, (D >= 256 && NW >= 8) ? NW / 4 : NW / 2) void sparse_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
     QUEST_DECODE_HEAD_TAKE(p);
     uint32_t hq = blockIdx.y;
-    if (p.xcd_period > 1) hq = (hq % p.xcd_period) * (a_num_qo_heads / p.xcd_period) + hq / p.xcd_period;
+    const uint32_t period = p.xcd_period & 255u, slow = p.xcd_period >> 8;
+    if (period > 1) {
+        hq = (hq % period) * (a_num_qo_heads / period) + hq / period;
+    } else if (slow) {
+        // slow-class heads first (plan_decode): rows [0, Hq/4) serve the heads = slow - 1 mod 4, the rest follow in order
+        const uint32_t sr = slow - 1u, quarter = a_num_qo_heads >> 2;
+        if (hq < quarter) {
+            hq = 4u * hq + sr;
+        } else {
+            const uint32_t r = hq - quarter;
+            hq = 4u * (r / 3u) + ((sr + 1u + r % 3u) & 3u);
+        }
+    }
+    p.xcd_period = period;
     if constexpr (VF == 4) sparse_decode_colrange_body<D, FC, NW, 1, 1>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else if constexpr (VF == 5) sparse_decode_colrange_body<D, FC, NW, 2, FC / 8>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
@@ -702,6 +715,20 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         const uint32_t period = 8u / gcd;
         p.xcd_period = (xcd_group && p.group > 1 && period > 1 && num_qo_heads % period == 0 &&
                         (num_qo_heads / period) % p.group == 0) ? period : 1u;
+        // Dispatch order by address class (round 5, scripts/probe/addr_class_probe.hip): on the NHD pool a head's K/V rows
+        // are 256-byte pieces at one offset inside every 1 KiB, and pieces whose address bits 8-9 are 01 are served ~20 %
+        // slower than the others under mixed traffic -- heads 1, 5, 9, ... of a 128-wide MHA pool.  A single sequence's
+        // launch is two workgroups per CU, dispatched rows-first: the first 16 rows' workgroups get ahead of the second
+        // 16 (they start their gather ~1 us earlier and finish ~2 us earlier), so the slow heads go FIRST, where they
+        // have that slack, instead of deciding the end of the launch from the second half.
+        // Measured at cfg 3, same box, us per launch: 12.04 -> 11.82 (profiles/r05_ab_slow_class_heads_first.txt);
+        // QUEST_SLOW_FIRST=0 keeps the plain order (A/B).  Same work per head, same bits.
+        static const int slow_env = [] { const char* e = quest_tuning_env("QUEST_SLOW_FIRST"); return e ? atoi(e) : 1; }();
+        if (slow_env && p.xcd_period == 1 && p.group == 1 && kv.layout == QUEST_LAYOUT_NHD && kv.head_dim == 128 &&
+            num_qo_heads % 4u == 0 && batch.n_seqs == 1) {
+            const uint32_t c0 = (uint32_t)(((uintptr_t)kv.data >> 8) & 3u);  // class of head 0
+            p.xcd_period |= (1u + ((1u - c0) & 3u)) << 8;
+        }
     }
     // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor
     fc = 0;

@@ -154,3 +154,11 @@ if "--matrix" in sys.argv and seqs > 1:  # medians over the replays, one row per
         for r in m:
             print("    " + " ".join(f"{x:5.1f}" for x in r))
         print("    column means: " + " ".join(f"{x:5.1f}" for x in m.mean(axis=0)))
+if "--per-head" in sys.argv:  # end of the gather / of the workgroup per head: is a head's address class (NHD: bits 8-9 = head mod 4) visible?
+    allr = np.stack(rows)
+    t0s = allr[..., 0].min(axis=(1, 2))[:, None, None]
+    for name, col in (("wave-0 pages folded", 2), ("end", 3)):
+        m = np.median((allr[..., col] - t0s) * 0.01, axis=0)  # [head][chunk]
+        print(f"  {name} per head (us after the first entry; mean / max over the head's workgroups):")
+        for h0 in range(0, H, 8):
+            print("    " + "  ".join(f"{h0 + i:3d}: {m[h0 + i].mean():5.2f}/{m[h0 + i].max():5.2f}" for i in range(min(8, H - h0))))
