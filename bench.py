@@ -88,6 +88,9 @@ def parse(argv=None):
                     help="batched sparse layers: one launch per layer (a workgroup per (sequence, head) appends, scores into "
                          "LDS, selects and gathers: csrc/layer_device.cuh) or the two launches append+estimate | "
                          "top-k+attention; auto = one launch where the plan allows it (MHA batches that fill the chip)")
+    ap.add_argument("--tiles", choices=["auto", "on", "off"], default="auto",
+                    help="single-sequence sparse layers: the tiles launches (the estimate hands per-8-page score maxima to the "
+                         "attention launch, which selects in two short passes); auto = pools of 4097 pages and more (cfg 4)")
     ap.add_argument("--pages-per-chunk", type=int, default=0, help="override the decode planner (tuning)")
     ap.add_argument("--separate-dense-append", action="store_true",
                     help="full-KV layers: issue the decode append as its own launch (three launches per layer, as before "
@@ -225,10 +228,13 @@ class Workload:
         if self.dyn:
             # state-driven stepping: the graph's first node reserves the token on the device
             ctl.enable_device_state()
+            if a.tiles != "auto":
+                ctl.tiles_min_pages = 0 if a.tiles == "on" else 1 << 30
             if a.pages_per_chunk:
                 ctl._decode_handler.set_pages_per_chunk(a.pages_per_chunk)
             ctl.begin_graph_decode(dense_layers=self.dense)
             self.scores = qu.score_scratch(ctl)
+            self.tiles = ctl.max_pages - 1 >= ctl.tiles_min_pages and ctl.inference_page_budget - 1 <= 256
         else:
             ctl.prepare_metadata(1)
 
@@ -434,13 +440,13 @@ def step_op_times(w, a, bpl, reps=10):
         o = [w.q[l].clone() for l in range(a.layers)]
 
         def ae(l):
-            _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
-                                         ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n,
-                                         ctl.layout)
+            assert _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l],
+                                                w.scores, ctl.metadata_cache.buf_layer(l), ctl.meta_table_full,
+                                                ctl.step_state, max_n, ctl.layout, tiles=w.tiles)
 
         def ts(l):
-            handler.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores,
-                                           ctl.step_state, max_n)
+            assert handler.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores,
+                                                  ctl.step_state, max_n, tiles=w.tiles)
 
     ppc, chunks = handler.plan_info()
     if isinstance(w, BatchedWorkload) and w.one_launch:

@@ -222,6 +222,25 @@ int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q
                                         uint32_t max_n_scores, const quest_step_state_t* state, float* lse,
                                         quest_stream_t stream);
 
+/*
+ * The same pair for LONG score rows (round 5; cfg 4: 8191 pages), with TILE MAXIMA handed across the kernel boundary: the
+ * estimate workgroup that holds the scores of 8 consecutive pages also stores the largest of them (as an order-preserving
+ * 16-bit key) at o[h][tile_max_offset + page / 8], and the attention launch selects in two short passes -- the top-k TILES by
+ * maximum (a sufficient candidate set under the declared tie rule: csrc/decode_device.cuh sparse_decode_tiles_body), then the
+ * exact top-k over those tiles' 8 k scores -- instead of passes over the whole row in every workgroup of a head.  Same
+ * selection, same outputs as quest_append_estimate_dyn + quest_decode_forward_fused_topk_dyn.
+ * tile_max_offset must be max_n rounded up to 8 columns; rows 16-byte aligned with
+ * stride >= tile_max_offset + ceil(max_n / 8) rounded up to 4.  Plans with at most 256 selected pages, page_size 16, rows
+ * up to 16384 pages; QUEST_EUNSUPPORTED otherwise.
+ */
+int quest_append_estimate_tiles_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                    uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out, uint32_t tile_max_offset,
+                                    quest_paged_kv_t metadata, const quest_step_state_t* state, quest_stream_t stream);
+int quest_decode_forward_fused_topk_tiles_dyn(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
+                                              uint32_t num_qo_heads, const void* scores, uint32_t score_stride,
+                                              uint32_t max_n_scores, uint32_t tile_max_offset,
+                                              const quest_step_state_t* state, float* lse, quest_stream_t stream);
+
 /* quest_append_kv_cache_decode with lengths / last-page ids from `state` (dense layers of a replayed step). */
 int quest_append_kv_cache_decode_dyn(const void* k, const void* v, quest_paged_kv_t kv, quest_paged_kv_t metadata,
                                      const quest_step_state_t* state, quest_stream_t stream);

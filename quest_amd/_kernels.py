@@ -412,9 +412,22 @@ def step_state_advance(state, kv_table, meta_table, page_size: int) -> None:
                                        kv_table.numel(), meta_table.numel(), _stream(state)), "step_state_advance")
 
 
+def tile_max_offset(max_n: int) -> int:
+    """Column offset of the tile maxima in a score row of the tiles launches: the scores padded to 8 columns."""
+    return (int(max_n) + 7) // 8 * 8
+
+
+def tiles_row_stride(max_n: int) -> int:
+    """Smallest row stride (fp16 columns, a multiple of 8) of a score scratch that also holds the tile maxima."""
+    return (tile_max_offset(max_n) + ((int(max_n) + 7) // 8 + 3) // 4 * 4 + 7) // 8 * 8
+
+
 def append_estimate_dyn(k, v, kv_data, kv_table, q, o, metadata_data, meta_table, state, max_n_out: int,
-                        layout: int) -> None:
-    """append_estimate whose lengths / last-page ids / n_out come from ``state``; ``o`` is ``[Hq, stride]``."""
+                        layout: int, tiles: bool = False) -> bool:
+    """append_estimate whose lengths / last-page ids / n_out come from ``state``; ``o`` is ``[Hq, stride]``.
+    ``tiles``: also store the rows' tile maxima (per 8 pages the largest score, as a 16-bit key) at column
+    ``tile_max_offset(max_n_out)`` -- ``o`` must be ``[Hq, >= tiles_row_stride(max_n_out)]``; returns False (nothing
+    launched) where the estimate's tile is not 8 pages wide."""
     for t, n in ((k, "k"), (v, "v"), (kv_data, "kv_data"), (kv_table, "kv_table"), (q, "q"), (o, "o"),
                  (metadata_data, "metadata_data"), (meta_table, "meta_table"), (state, "state")):
         _check_input(t, n)
@@ -428,9 +441,19 @@ def append_estimate_dyn(k, v, kv_data, kv_table, q, o, metadata_data, meta_table
     _check_half(q, "Estimate_attn_score")
     kv = _paged(kv_data, kv_table, None, 1, 0, layout)
     meta = _paged(metadata_data, meta_table, None, 1, 0, layout)
+    if tiles:
+        _check_ge(o.size(1), tiles_row_stride(max_n_out), "o.size(1), tiles_row_stride(max_n_out)")
+        code = lib.quest_append_estimate_tiles_dyn(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1),
+                                                   o.size(1), int(max_n_out), tile_max_offset(max_n_out), meta,
+                                                   state.data_ptr(), _stream(k))
+        if code == -2:
+            return False
+        check(code, "append_estimate_dyn")
+        return True
     check(lib.quest_append_estimate_dyn(k.data_ptr(), v.data_ptr(), kv, q.data_ptr(), o.data_ptr(), q.size(1),
                                         o.size(1), int(max_n_out), meta, state.data_ptr(), _stream(k)),
           "append_estimate_dyn")
+    return True
 
 
 def append_kv_cache_decode_dyn(k, v, kv_data, kv_table, metadata_data, meta_table, state, layout: int) -> None:
@@ -776,8 +799,12 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         check(code, "BatchDecodeWithPagedKVCache")
         return True
 
-    def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
-        """forward_fused_topk whose row length and current page come from ``state`` (graph replay)."""
+    def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int,
+                               tiles: bool = False) -> bool:
+        """forward_fused_topk whose row length and current page come from ``state`` (graph replay).
+        ``tiles``: the rows carry their tile maxima (``append_estimate_dyn(..., tiles=True)`` wrote them): two short
+        selection passes instead of passes over the whole row; returns False (nothing launched) where the plan is
+        outside what the tiles launch serves (more than 256 selected pages, page size != 16)."""
         for t, n in ((q, "q"), (o, "o"), (paged_kv_data, "paged_kv_data"), (page_table, "page_table"),
                      (scores, "scores"), (state, "state")):
             _check_input(t, n)
@@ -786,10 +813,21 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         _check_ge(scores.size(1), max_n_scores, "scores.size(1), max_n_scores")
         _check_half(q, "BatchDecodeWithPagedKVCache")
         kv = _paged(paged_kv_data, page_table, None, 1, 0, self._layout)
+        if tiles:
+            _check_ge(scores.size(1), tiles_row_stride(max_n_scores), "scores.size(1), tiles_row_stride(max_n_scores)")
+            code = lib.quest_decode_forward_fused_topk_tiles_dyn(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1),
+                                                                 scores.data_ptr(), scores.size(1), int(max_n_scores),
+                                                                 tile_max_offset(max_n_scores), state.data_ptr(), None,
+                                                                 _stream(q))
+            if code == -2:
+                return False
+            check(code, "BatchDecodeWithPagedKVCache")
+            return True
         check(lib.quest_decode_forward_fused_topk_dyn(self._h, q.data_ptr(), o.data_ptr(), kv, q.size(1),
                                                       scores.data_ptr(), scores.size(1), int(max_n_scores),
                                                       state.data_ptr(), None, _stream(q)),
               "BatchDecodeWithPagedKVCache")
+        return True
 
     def set_batch(self, n_seqs: int) -> None:
         """Sequences per launch the NEXT begin_forward plans for (workspace, work split)."""

@@ -65,6 +65,10 @@ SIGNATURES = {
                                                   c_vp]),
     "quest_decode_forward_fused_topk_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32, c_vp,
                                                             c_vp, c_vp]),
+    "quest_append_estimate_tiles_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, PagedKV,
+                                                        c_vp, c_vp]),
+    "quest_decode_forward_fused_topk_tiles_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32, c_u32,
+                                                                  c_vp, c_vp, c_vp]),
     "quest_append_kv_cache_decode_dyn": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp, c_vp]),
     "quest_decode_append_forward_shared_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp,
                                                               c_vp]),

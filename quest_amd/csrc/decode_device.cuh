@@ -781,6 +781,136 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
 #endif
 }
 
+// ---- tiles front end (round 5): long score rows whose producer also left TILE MAXIMA -- per run of 8 columns the largest
+// key of the run (quest_append_estimate_tiles_dyn: the estimate workgroup that holds those 8 scores writes it beside the
+// row).  Two passes of the SAME selection routine instead of four issue-bound passes over 16-32 keys per thread:
+//   1. top-k1 of the row's ceil(n / 8) tile keys, k1 = min(k, tiles), under the declared tie rule (lowest tile first among
+//      equal maxima).  These k1 tiles are a sufficient candidate set: with B = the k1-th largest maximum, at least k scores
+//      reach B (one per selected tile), so the threshold T >= B; every score > B lies in a tile whose maximum is > B (all of
+//      them selected); and the ties the rule needs at T == B are taken lowest column first, of which the a tiles with a
+//      maximum > B hold at least a scores above B -- at most k - a tied scores are needed, and the first k - a tied tiles in
+//      column order already hold that many at lower columns than any later tile.
+//   2. the k1 candidate tiles arrive compacted in ascending column order (a tile's slot of pass 1 = its rank); thread j takes
+//      half a tile (tile j / 2, columns 4 (j & 1) ..): one 8-byte load of scores and one 16-byte load of page ids, then the
+//      short-row selection over <= 4 keys per thread with the validity mask -- same threshold, same ties, same slots as the
+//      selection over the whole row (tests/test_gpu_long_rows.py, test_gpu_full_size.py cfg 4).
+// Serves k <= 256 (two threads per candidate tile at 512 threads) and rows up to 16384 columns (4 tile keys per thread).
+constexpr int kTileCols = 8;
+template <int D, int NW>
+__device__ __forceinline__ void sparse_decode_tiles_body(DecodeParams p, const uint32_t chunk, const uint32_t hq,
+                                                         const uint32_t seq, const uint32_t num_qo_heads) {
+    constexpr int LPR = D / kVec, NT = NW * kWave, TM = 4, KC = 4;
+    static_assert(NT == 512, "two threads per candidate tile, k <= 256");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int col = lane % LPR;
+    const uint32_t tid = threadIdx.x;
+#ifdef QUEST_TIMELINE
+    long long tl[10] = {};
+    const long long wall0 = wall_clock64();
+    QUEST_STAMP(0);
+#endif
+    QUEST_WS_ENTRY
+    const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
+    const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);  // first used after the selection
+    __shared__ TopkSmem<NT> sm;
+    __shared__ int32_t s_sel[kFusedMaxPpc];
+    __shared__ uint32_t s_tiles[NT / 2];
+    const uint32_t n_cap = p.n_scores, tiles_cap = (n_cap + kTileCols - 1) / kTileCols;
+    const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
+    const uint16_t* trow = srow + ((n_cap + 7u) & ~7u);  // the maxima follow the scores padded to 8 columns (host-checked)
+    const int4 live = *(p.state ? reinterpret_cast<const int4*>(sv.state) : reinterpret_cast<const int4*>(p.q));
+    // pass-1 loads: the thread's own p.cpt (2 or 4) tile keys, two unconditional 4-byte loads (the second repeats the
+    // first at 2 keys per thread); addresses depend on the capacity only
+    const uint32_t cpt_t = p.cpt, t0 = tid * cpt_t, t0c = t0 < tiles_cap ? t0 : 0u;
+    const uint32_t tlo = *reinterpret_cast<const uint32_t*>(trow + t0c);
+    const uint32_t thi = *reinterpret_cast<const uint32_t*>(trow + t0c + (cpt_t == 4u ? 2u : 0u));
+    topk_clear<NT>(sm);
+    const int32_t budget_raw = ld_uniform_i32(p.budgets ? p.budgets + seq : reinterpret_cast<const int32_t*>(p.q));
+    if (p.state) {
+        p.n_scores = (uint32_t)(live.y - 1);
+        p.last_page_len = (uint32_t)live.z;
+        p.last_page_idx = live.w;
+        if (p.budgets) p.n_sel = min(p.n_sel, (uint32_t)max(budget_raw - 1, 0));
+        p.n_sel = min(p.n_sel, p.n_scores);
+    }
+    const uint32_t n = p.n_scores;
+    const uint32_t n_slots = p.n_sel + 1, slot_begin = chunk * p.pages_per_chunk;
+    const uint32_t slot_end = min(n_slots, slot_begin + p.pages_per_chunk);
+    if (n > 0 && p.n_sel > 0) {  // block-uniform
+        const uint32_t n_tiles = (n + kTileCols - 1) / kTileCols, k1 = min(p.n_sel, n_tiles);
+        // ---- pass 1: the k1 tiles with the largest maxima
+        uint32_t tkey[TM] = {tlo & 0xffffu, tlo >> 16, thi & 0xffffu, thi >> 16};
+        uint32_t mm = kMmNeutral;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            if ((uint32_t)i < cpt_t && t0 + i < n_tiles) mm = pk_max_u16(mm, mm_pack(tkey[i]));
+        QUEST_STAMP(1);
+        topk_publish_range<NT>(sm, mm);
+        __syncthreads();
+        TopkCursor cur = topk_select<NT, TM>(sm, tkey, n_tiles, k1, cpt_t);
+        QUEST_STAMP(2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            uint32_t slot;
+            if (topk_take(cur, tkey[i], (uint32_t)i < cpt_t && t0 + i < n_tiles, slot)) s_tiles[slot] = t0 + i;
+        }
+        topk_clear<NT>(sm);  // (pass 1 has read its histograms: its last barrier lies behind us)
+        __syncthreads();
+        QUEST_STAMP(3);
+        // ---- pass 2: half a candidate tile per thread
+        const uint32_t cand = tid >> 1;
+        const bool active = cand < k1;
+        const uint32_t c0 = s_tiles[active ? cand : 0u] * kTileCols + KC * (tid & 1u);  // < n_cap rounded up to 8
+        const uint2 kraw = *reinterpret_cast<const uint2*>(srow + c0);
+        uint4 ids;
+        const uint32_t table_len = n_cap + 1u;
+        if (p.table_vec && c0 + 4u <= table_len) {
+            ids = *reinterpret_cast<const uint4*>(sv.indices + c0);
+        } else {  // unaligned tables, or the tail of a table whose length is not a multiple of 4
+            const uint32_t last = table_len - 1u;
+            ids.x = (uint32_t)sv.indices[c0 < last ? c0 : last];
+            ids.y = (uint32_t)sv.indices[c0 + 1u < last ? c0 + 1u : last];
+            ids.z = (uint32_t)sv.indices[c0 + 2u < last ? c0 + 2u : last];
+            ids.w = (uint32_t)sv.indices[c0 + 3u < last ? c0 + 3u : last];
+        }
+        uint32_t key[KC] = {half_key((uint16_t)(kraw.x & 0xffffu)), half_key((uint16_t)(kraw.x >> 16)),
+                            half_key((uint16_t)(kraw.y & 0xffffu)), half_key((uint16_t)(kraw.y >> 16))};
+        auto valid = [&](int i) { return active && c0 + (uint32_t)i < n; };
+        mm = kMmNeutral;
+#pragma unroll
+        for (int i = 0; i < KC; ++i)
+            if (valid(i)) mm = pk_max_u16(mm, mm_pack(key[i]));
+        topk_publish_range<NT>(sm, mm);
+        __syncthreads();
+        QUEST_STAMP(4);
+        TopkCursor cur2 = topk_select_v<NT, KC>(sm, key, valid, p.n_sel);
+        const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
+        const uint32_t idw[KC] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+            uint32_t slot;
+            if (topk_take(cur2, key[i], valid(i), slot)) {
+                if (slot >= slot_begin && slot < slot_end) s_sel[slot - slot_begin] = (int32_t)idw[i];
+                if (p.sel_idx_out && chunk == 0) {  // the inspection copy is written once per head
+                    p.sel_idx_out[out_row + slot] = (int32_t)idw[i];
+                    if (p.sel_val_out) p.sel_val_out[out_row + slot] = key_to_half_bits(key[i]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    QUEST_STAMP(5);
+    attend_slots<D, 16, NW>(attend_args(p), sv, q_raw, chunk, hq, slot_begin, slot_end, p.n_sel, wave, lane,
+                            [&](uint32_t slot) -> int32_t { return s_sel[slot - slot_begin]; } QUEST_TL_ARG QUEST_WS_ARG);
+#ifdef QUEST_TIMELINE
+    QUEST_STAMP(9);
+    if (p.lse && chunk == p.n_chunks / 2 && hq == QUEST_TL_HEAD(num_qo_heads) && seq == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
+        p.lse[10] = (float)(wall_clock64() - wall0);
+    }
+#endif
+}
+
 // ---- column-range ownership (round 4; topk_colrange.cuh has the design note).  Workgroup `chunk` of a head owns the
 // columns [chunk * rl, chunk * rl + rl) of the head's score row, rl = ceil(n / n_chunks) rounded up to 4 (<= 256), and
 // gathers the selected pages among them (NG granules of 4 columns per lane: rl <= 256 NG); the last workgroup of a head also takes the sequence's current page.  After the

@@ -140,8 +140,11 @@ extern "C" int quest_estimate_attn_score(const void* q, void* o, uint32_t num_qo
 static int append_estimate_state(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
                                  uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
                                  quest_paged_kv_t metadata, const quest_step_state_t* state, quest_batch_t batch,
-                                 quest_stream_t stream) {
+                                 quest_stream_t stream, uint32_t tile_off = 0) {
     if (!k || !v || !state || max_n_out == 0 || o_stride < max_n_out || batch.n_seqs == 0) return QUEST_EINVAL;
+    if (tile_off && (tile_off % 8u != 0 || tile_off < ((max_n_out + 7u) & ~7u) ||
+                     o_stride < tile_off + ((((max_n_out + 7u) / 8u) + 3u) & ~3u)))
+        return QUEST_EINVAL;  // the maxima live behind the scores of the same row, readable in 8-byte pieces
     kv.last_page_len = metadata.last_page_len = 1;  // placeholders; the kernel reads the real ones from `state`
     if (int e = check_pool(kv)) return e;
     if (int e = check_pool(metadata)) return e;
@@ -154,6 +157,7 @@ static int append_estimate_state(const void* k, const void* v, quest_paged_kv_t 
     tail.state = state;
     tail.o_stride = o_stride;
     tail.meta_table_stride = batch.meta_table_stride;
+    tail.tile_off = tile_off;
     return estimate_entry(q, o, num_qo_heads, max_n_out, metadata, tail, (hipStream_t)stream, batch.n_seqs);
 }
 
@@ -177,6 +181,16 @@ extern "C" int quest_append_estimate_dyn(const void* k, const void* v, quest_pag
                                          quest_stream_t stream) {
     const quest_batch_t one = {1, 0, 0, 0};
     return append_estimate_state(k, v, kv, q, o, num_qo_heads, o_stride, max_n_out, metadata, state, one, stream);
+}
+
+extern "C" int quest_append_estimate_tiles_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
+                                               uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
+                                               uint32_t tile_max_offset, quest_paged_kv_t metadata,
+                                               const quest_step_state_t* state, quest_stream_t stream) {
+    if (tile_max_offset == 0) return QUEST_EINVAL;
+    const quest_batch_t one = {1, 0, 0, 0};
+    return append_estimate_state(k, v, kv, q, o, num_qo_heads, o_stride, max_n_out, metadata, state, one, stream,
+                                 tile_max_offset);
 }
 
 extern "C" int quest_append_estimate_batched(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,

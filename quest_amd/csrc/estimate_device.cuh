@@ -33,6 +33,8 @@ struct AppendTail {  // optional decode-append riding in the same launch (blocks
     uint32_t tile_heads;              // kv heads per workgroup tile (power of two dividing num_heads, <= 8)
     uint32_t tile_log2;               // log2(tile_heads): tile rows and heads are powers of two -> shifts, not divisions
     uint32_t meta_table_stride;       // batched launches (blockIdx.y = sequence): entries between page tables
+    uint32_t tile_off;                // > 0: column offset (in every row of o) of the row's TILE MAXIMA: per run of 8 columns
+                                      // the largest order-preserving key of the run's scores (tiles front end, decode_device.cuh)
 };
 
 // Workgroup tile = EW entries x HW kv heads = 64 rows (D = 128): HW = tile_heads (8 for 8 or 32 kv heads), so
@@ -224,13 +226,24 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
     const uint32_t n_scores = HW * G * EW;
     for (uint32_t t = tid; t < n_scores; t += EWV * kWave) {
         const uint32_t qh = t >> ew_l2, e = e0 + (t & (EW - 1));
+        const half_t sc = out_s[t];
 #ifdef QUEST_EST_NOSTORE
-        if (e < n_out && out_s[t] == (half_t)12345.f)
+        if (e < n_out && sc == (half_t)12345.f)
 #else
         if (e < n_out)
 #endif
         {
-            o[((size_t)o_row0 + (size_t)h0 * G + qh) * tail.o_stride + e] = out_s[t];
+            o[((size_t)o_row0 + (size_t)h0 * G + qh) * tail.o_stride + e] = sc;
+        }
+        if (tail.tile_off) {  // launch-uniform: one key per (query head, run of 8 columns): the largest key of the run's valid
+                              // scores.  8 consecutive t = 8 consecutive lanes = one run (EW is a multiple of 8): three DPP steps
+            int key = e < n_out ? (int)half_key(half_bits(sc)) : 0;
+            key = max(key, dpp_i<kDppQuadXor1>(key));
+            key = max(key, dpp_i<kDppQuadXor2>(key));
+            key = max(key, dpp_i<kDppHalfMirror>(key));
+            if ((t & 7u) == 0 && e < n_out)
+                reinterpret_cast<uint16_t*>(o)[((size_t)o_row0 + (size_t)h0 * G + qh) * tail.o_stride + tail.tile_off + (e >> 3)] =
+                    (uint16_t)key;
         }
     }
 }

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(NW* kWave, (D >= 256 && NW >= 8) ? NW / 4 : NW / 2)
         }
     }
     p.xcd_period = period;
-    if constexpr (VF == 4) sparse_decode_colrange_body<D, FC, NW, 1, 1>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+    if constexpr (VF == 8) sparse_decode_tiles_body<D, NW>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
+    else if constexpr (VF == 4) sparse_decode_colrange_body<D, FC, NW, 1, 1>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else if constexpr (VF == 5) sparse_decode_colrange_body<D, FC, NW, 2, FC / 8>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
 }
@@ -548,6 +549,16 @@ static int launch_decode_fc(quest_decode_handler* h, const DecodeParams& p, uint
     //   FC 16 / 32, variant 2: second-generation front end of long rows (cfg 4)
     // QUEST_FE_SPECIALIZE=0 launches the generic kernel instead (A/B).
     static const bool specialize = [] { const char* e = quest_tuning_env("QUEST_FE_SPECIALIZE"); return !e || atoi(e) != 0; }();
+    if (p.vec_front == 8u) {  // tiles front end (plan_decode: page size 16, 8 waves)
+        if constexpr (FC == 8) {
+            info[3] = 1u;
+            hipLaunchKernelGGL((sparse_decode_kernel<D, 16, 8, 8, 8>), grid, dim3(8 * kWave), 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
+            QUEST_LAUNCH_CHECK();
+            goto merge;
+        } else {
+            return QUEST_EUNSUPPORTED;
+        }
+    }
     if (colrange && !(p.page_size == 16 && waves == 8 && (FC == 8 || FC == 16 || FC == 24 || FC == 32)))
         return QUEST_EUNSUPPORTED;  // plan_decode only picks the column-range variants for these instantiations
     if ((specialize || colrange) && p.page_size == 16 && waves == 8) {
@@ -615,7 +626,7 @@ static int launch_decode(quest_decode_handler* h, const DecodeParams& p, uint32_
 static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv, uint32_t num_qo_heads,
                        const void* scores, uint32_t n_scores, void* topk_val_out, int32_t* topk_idx_out, float* lse,
                        uint32_t score_stride, const quest_step_state_t* state, quest_batch_t batch, DecodeParams& p, int& fc,
-                       uint32_t& waves) {
+                       uint32_t& waves, uint32_t tile_off = 0) {
     if (state) kv.last_page_len = 1;  // placeholder; the kernel reads the real one from `state`
     if (!h || batch.n_seqs == 0) return QUEST_EINVAL;
     if (!h->started) return QUEST_ESTATE;
@@ -704,7 +715,17 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     }
     // rows beyond 4096 columns are served by the second-generation front end only (the first one spills there):
     // state-driven callers own the score scratch and give it an 8-byte aligned row stride (a multiple of 4 columns)
-    if (fused && !p.vec_front && n_scores > 4096u) return QUEST_EUNSUPPORTED;
+    if (fused && !p.vec_front && n_scores > 4096u && !tile_off) return QUEST_EUNSUPPORTED;
+    if (tile_off) {  // tiles front end (sparse_decode_tiles_body): the rows carry their tile maxima behind the scores
+        const uint32_t tiles_cap = (n_scores + 7u) / 8u;
+        if (!fused || tile_off != ((n_scores + 7u) & ~7u) || ((uintptr_t)scores & 15u) != 0 || p.score_stride % 8u != 0 ||
+            p.score_stride < tile_off + ((tiles_cap + 3u) & ~3u))
+            return QUEST_EINVAL;
+        if (kv.page_size != 16 || h->n_sel > 256u || tiles_cap > 4u * 512u || batch.n_seqs != 1) return QUEST_EUNSUPPORTED;
+        p.vec_front = 8;
+        p.stage_ids = 0;
+        p.ids_lds_offset = 0;
+    }
     p.state = state;
     p.table_stride = batch.kv_table_stride;
     p.budgets = state ? batch.page_budgets : nullptr;
@@ -734,7 +755,13 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     fc = 0;
     waves = h->dec_waves;
     p.cpt = 0;
-    if (fused) {
+    if (fused && p.vec_front == 8u) {
+        waves = 8;
+        fc = 8;
+        p.cpt = (n_scores + 7u) / 8u <= 2u * 512u ? 2u : 4u;  // tile keys per thread
+        p.table_vec = table_vec ? 1u : 0u;
+        p.chunks_inv = 0;
+    } else if (fused) {
         // the selection is VALU-issue bound (~1000 instructions per wave at 8 keys per thread), so rows
         // beyond 1024 pages get 8 waves (<= 4 keys per thread up to 2048 pages, <= 8 up to 4096); the
         // attention part runs the same with 4 or 8 waves.  Measured at cfg 3: 15.2 vs 15.8 us.
@@ -802,12 +829,12 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
 static int decode_entry(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,
                         uint32_t num_qo_heads, const void* scores, uint32_t n_scores, void* topk_val_out,
                         int32_t* topk_idx_out, float* lse, hipStream_t s, uint32_t score_stride = 0,
-                        const quest_step_state_t* state = nullptr, quest_batch_t batch = {1, 0, 0, 0}) {
+                        const quest_step_state_t* state = nullptr, quest_batch_t batch = {1, 0, 0, 0}, uint32_t tile_off = 0) {
     DecodeParams p;
     int fc;
     uint32_t waves;
     if (int e = plan_decode(h, q, o, kv, num_qo_heads, scores, n_scores, topk_val_out, topk_idx_out, lse, score_stride, state,
-                            batch, p, fc, waves))
+                            batch, p, fc, waves, tile_off))
         return e;
     switch (kv.head_dim) {
         case 64: return launch_decode<64>(h, p, num_qo_heads, fc, waves, s, batch.n_seqs);
@@ -982,6 +1009,16 @@ extern "C" int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, co
     // dispatch (keys per thread) is chosen for the longest row the graph will see
     return decode_entry(h, q, o, kv, num_qo_heads, scores, max_n_scores, nullptr, nullptr, lse, (hipStream_t)stream,
                         score_stride, state);
+}
+
+extern "C" int quest_decode_forward_fused_topk_tiles_dyn(quest_decode_handler_t* h, const void* q, void* o,
+                                                         quest_paged_kv_t kv, uint32_t num_qo_heads, const void* scores,
+                                                         uint32_t score_stride, uint32_t max_n_scores,
+                                                         uint32_t tile_max_offset, const quest_step_state_t* state, float* lse,
+                                                         quest_stream_t stream) {
+    if (!scores || !state || score_stride < max_n_scores || tile_max_offset == 0) return QUEST_EINVAL;
+    return decode_entry(h, q, o, kv, num_qo_heads, scores, max_n_scores, nullptr, nullptr, lse, (hipStream_t)stream,
+                        score_stride, state, {1, 0, 0, 0}, tile_max_offset);
 }
 
 extern "C" int quest_decode_forward_fused_topk_batched(quest_decode_handler_t* h, const void* q, void* o,

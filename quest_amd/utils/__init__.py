@@ -182,6 +182,9 @@ def score_scratch(controller) -> torch.Tensor:
     load (second-generation top-k front end, csrc/topk_bitmap.cuh).  Any ``[.., >= max_pages]`` fp16 tensor works;
     other strides take the first-generation front end (rows up to 4096 pages)."""
     stride = (controller.max_pages + 7) // 8 * 8
+    if not isinstance(controller, BatchedInferenceController):
+        # room for the rows' tile maxima behind the scores (long-row launches, ``decode_layer_dyn``)
+        stride = max(stride, _kernels.tiles_row_stride(controller.max_pages - 1))
     shape = (controller.num_heads, stride)
     if isinstance(controller, BatchedInferenceController):
         shape = (controller.n_seqs,) + shape
@@ -206,22 +209,34 @@ def step_advance_dyn(iController: InferenceController) -> None:
 
 def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
                      layer_idx: int, scores: torch.Tensor, rope_scale: Optional[float] = None,
-                     rope_theta: Optional[float] = None, apply_rope: bool = False) -> torch.Tensor:
+                     rope_theta: Optional[float] = None, apply_rope: bool = False,
+                     tiles: Optional[bool] = None) -> torch.Tensor:
     """One layer of a decode token in the sparse regime (pages > budget), every length read from the
     device-resident state: [RoPE] -> append+estimate -> top-k+attention (+merge).  ``scores`` is a
-    caller-owned ``[Hq, >= max_pages]`` fp16 scratch."""
+    caller-owned ``[Hq, >= max_pages]`` fp16 scratch (``score_scratch``).  ``tiles``: None = the tiles launches for pools
+    of at least ``iController.tiles_min_pages`` pages (where the scratch has room and the plan allows), True / False force."""
     ctl = iController
     _need_state(ctl)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
     max_n = ctl.max_pages - 1
-    _kernels.append_estimate_dyn(k, v, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, q, scores,
-                                 ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, ctl.step_state, max_n,
-                                 ctl.layout)
+    # long rows: the estimate hands the rows' tile maxima (per 8 pages the largest score) to the attention launch, which
+    # then selects in two short passes (csrc/decode_device.cuh sparse_decode_tiles_body); same selection, same outputs
+    tiles = (tiles if tiles is not None else max_n >= ctl.tiles_min_pages) and scores.dim() == 2 \
+        and scores.size(1) >= _kernels.tiles_row_stride(max_n) and ctl.inference_page_budget - 1 <= 256
+    tiles = _kernels.append_estimate_dyn(k, v, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, q, scores,
+                                         ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, ctl.step_state,
+                                         max_n, ctl.layout, tiles=True) if tiles else False
+    if not tiles:
+        _kernels.append_estimate_dyn(k, v, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, q, scores,
+                                     ctl.metadata_cache.buf_layer(layer_idx), ctl.meta_table_full, ctl.step_state, max_n,
+                                     ctl.layout)
     o = torch.empty_like(q)
-    ctl._decode_handler.forward_fused_topk_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, scores,
-                                               ctl.step_state, max_n)
+    if not (tiles and ctl._decode_handler.forward_fused_topk_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full,
+                                                                 scores, ctl.step_state, max_n, tiles=True)):
+        ctl._decode_handler.forward_fused_topk_dyn(q, o, ctl.kv_cache.buf_layer(layer_idx), ctl.kv_table_full, scores,
+                                                   ctl.step_state, max_n)
     return o
 
 

@@ -152,6 +152,9 @@ class InferenceController:
         self.kv_table_full = self.kv_cache.full_device_table()
         self.meta_table_full = self.metadata_cache.full_device_table()
         self.max_pages = self.kv_table_full.numel()
+        # decode_layer_dyn: pools from this many pages up take the tiles launches (tile maxima handed from the estimate
+        # to the attention launch); below, every workgroup of a head selects over the whole row
+        self.tiles_min_pages = getattr(self, "tiles_min_pages", 4097)
         self.step_state = torch.zeros(8, dtype=torch.int32, device=self.device)
         self.state_epoch += 1  # graphs captured before this call are stale
         self.sync_device_state()

@@ -53,8 +53,9 @@ class BatchDecodeWithPagedKVCacheWrapper:
         return self._wrapper.append_forward_shared_batched(k, v, metadata_data, meta_tables, q, o, paged_kv_data, kv_tables,
                                                            state)
 
-    def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int) -> None:
-        self._wrapper.forward_fused_topk_dyn(q, o, paged_kv_data, page_table, scores, state, max_n_scores)
+    def forward_fused_topk_dyn(self, q, o, paged_kv_data, page_table, scores, state, max_n_scores: int,
+                               tiles: bool = False) -> bool:
+        return self._wrapper.forward_fused_topk_dyn(q, o, paged_kv_data, page_table, scores, state, max_n_scores, tiles)
 
     def set_batch(self, n_seqs: int) -> None:
         self._wrapper.set_batch(n_seqs)

@@ -67,10 +67,14 @@ else:
     o = [w.q[l].clone() for l in range(a.layers)]
     w.qu.step_advance_dyn(ctl)
 
+    tiles = "--tiles" in sys.argv  # the tiles launches (tile maxima from the estimate to the attention launch)
+
     def layer(l):  # the step's pair of launches (the scores must be this layer's)
-        _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
-                                     ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n, ctl.layout)
-        h.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores, ctl.step_state, max_n)
+        assert _kernels.append_estimate_dyn(w.k1[l], w.v1[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.q[l], w.scores,
+                                            ctl.metadata_cache.buf_layer(l), ctl.meta_table_full, ctl.step_state, max_n,
+                                            ctl.layout, tiles=tiles)
+        assert h.forward_fused_topk_dyn(w.q[l], o[l], ctl.kv_cache.buf_layer(l), ctl.kv_table_full, w.scores, ctl.step_state,
+                                        max_n, tiles=tiles)
 
 
 h.set_skip_merge(True)

@@ -127,16 +127,17 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     qu.step_advance_dyn(ctl)
     o2 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
     ctl._decode_handler.set_selection_out(None, None)
-    # the launch bench.py --config 4 times: second-generation front end (granule ownership + histogram pre-filter), 24
-    # keys per thread, slot ownership
+    # the launch bench.py --config 4 times since round 5: the tiles front end (the estimate handed the rows' tile maxima
+    # over: top-255 tiles, then the exact top-255 over their 2040 scores), slot ownership
     info = ctl._decode_handler.last_launch_info()
-    assert (info["keys_per_thread"], info["front_end_variant"], info["waves"], info["specialised"]) == (24, 2, 8, True), info
+    assert (info["keys_per_thread"], info["front_end_variant"], info["waves"], info["specialised"]) == (8, 8, 8, True), info
     assert ctl.step_state.cpu().tolist()[:3] == [L, n_pages, PAGE]
     assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est))
     assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
     torch.testing.assert_close(o2[0].float(), o_ref, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
-    # the same step (the append is idempotent) without and with the histogram pre-filter of the long-row front end
+    # the same step (the append is idempotent) through the whole-row front ends (round 4's launch: second generation, 24
+    # keys per thread): without and with the histogram pre-filter of the long-row front end
     # (csrc/topk_bitmap.cuh; the default above is "with") and through the third generation (csrc/topk_prefilter.cuh,
     # measured slower, not the default): same pages, same slots, same bits; and through the column-range form
     # (csrc/topk_colrange.cuh, measured slower and therefore not the default): same page lists, outputs within the fp32
@@ -147,7 +148,7 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
         sel_i2 = torch.full_like(sel_i, -1)
         ctl._decode_handler.set_selection_out(None, sel_i2)
         qu.step_advance_dyn(ctl)
-        o3 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, qu.score_scratch(ctl).zero_())
+        o3 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, qu.score_scratch(ctl).zero_(), tiles=False)
         ctl._decode_handler.set_selection_out(None, None)
         assert torch.equal(sel_i2, sel_i), f"front end {gen}: page lists differ"
         assert ctl._decode_handler.last_launch_info()["front_end_variant"] == {2: 2, 3: 2, 6: 6, 4: 5}[gen]
