@@ -375,9 +375,9 @@ int quest_decode_plan_info(const quest_decode_handler_t* h, uint32_t* pages_per_
 /* Which kernel instantiation the handler's most recent per-head-list launch (quest_decode_forward*, fused or not) took:
  * info = {keys per thread of the fused top-k front end (0: index-tensor launch), waves per workgroup, front-end variant
  * (0 / 1 / 3: first generation with scalar / vector-fed staging arrays / keys straight into registers; 2: second
- * generation; 4 / 5: column-range ownership on the first / second generation's threshold phase), 1 if the one-variant
- * instantiation was launched (0: the generic kernel), workgroups per head, sequences}.  Tests and benches assert with it
- * that they run the kernel they mean to. */
+ * generation; 8: tiles -- the rows carry tile maxima; 7: the one-launch layer, quest_decode_layer_fused_batched), 1 if the
+ * one-variant instantiation was launched (0: the generic kernel), workgroups per head, sequences}.  Tests and benches
+ * assert with it that they run the kernel they mean to. */
 int quest_decode_last_launch_info(const quest_decode_handler_t* h, uint32_t info[6]);
 /* Developer aid: the handler's partial-state workspace ([sequences][heads][workgroups per head][record_floats] fp32:
  * acc[head_dim], m, d, spare).  Builds with -DQUEST_WALLSTAMPS leave per-workgroup wall-clock stamps in the spare words
@@ -395,15 +395,10 @@ int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip);
 int quest_decode_set_selection_out(quest_decode_handler_t* h, void* val_out, int32_t* idx_out);
 /* Which top-k front end the fused launches use: 0 = automatic (by row length and alignment), 1 = first generation
  * (csrc/topk_select.cuh; rows up to 4096 pages), 2 = second generation (csrc/topk_bitmap.cuh; needs 8-byte aligned
- * score rows) without its histogram pre-filter, 3 = second generation with the pre-filter, 4 = column-range ownership
- * (csrc/topk_colrange.cuh; where a head has several workgroups and aligned score rows -- 8-wave workgroups also on
- * short rows; built in round 4, measured slower than slot ownership, kept for A/B runs and tests), 5 = as 0 (A/B runs
- * under QUEST_COLRANGE=1), 6 = third generation (csrc/topk_prefilter.cuh; rows beyond 4096 pages, at most 512 selected
- * pages; falls back to the second generation inside the kernel when a wave holds more than 255 candidates; built in
- * round 4, measured slower than the second generation at cfg 4, kept for A/B runs and tests).  0-3, 5 and 6 are slot
- * ownership.  All implement the same
- * selection: bit-identical page SETS and (inspection) lists; the column-range variants fold a head's pages in a
- * different workgroup split, so outputs differ from the others' by fp32 merge order (tests: <= 2e-3).  Tuning / test aid. */
+ * score rows) without its histogram pre-filter, 3 = second generation with the pre-filter.  All are slot ownership and
+ * implement the same selection: bit-identical page lists and outputs.  Tuning / test aid.  (The tiles front end is chosen
+ * by calling quest_decode_forward_fused_topk_tiles_dyn.  Round 4's column-range ownership and third generation measured
+ * slower and were removed in round 5.) */
 int quest_decode_set_front_end(quest_decode_handler_t* h, int generation);
 /* Override the planner (0 = automatic).  Used by tuning sweeps. */
 int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);

@@ -928,9 +928,9 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
     def last_launch_info(self) -> dict:
         """Which kernel instantiation the handler's most recent per-head-list launch took: keys per thread of the fused
         front end (0 = index-tensor launch), waves per workgroup, front-end variant (DecodeParams.vec_front: 0 / 1 / 3
-        first generation staged / vector-staged / direct, 2 second generation, 4 / 5 column-range ownership on the
-        first / second generation's threshold phase), whether the one-variant instantiation was launched, workgroups
-        per head, sequences.  So that tests and benches can assert they run the same kernel."""
+        first generation staged / vector-staged / direct, 2 second generation, 8 tiles, 7 the one-launch layer), whether
+        the one-variant instantiation was launched, workgroups per head, sequences.  So that tests and benches can assert
+        they run the same kernel."""
         info = (ctypes.c_uint32 * 6)()
         check(lib.quest_decode_last_launch_info(self._h, info), "last_launch_info")
         return {"keys_per_thread": info[0], "waves": info[1], "front_end_variant": info[2], "specialised": bool(info[3]),
@@ -940,8 +940,8 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
         check(lib.quest_decode_set_pages_per_chunk(self._h, int(ppc)), "set_pages_per_chunk")
 
     def set_front_end(self, generation: int) -> None:
-        """Tuning / test aid: force the fused launches' top-k front end (0 = automatic; 1 / 2 / 3 = the slot-ownership
-        generations; 4 = column-range ownership also on short rows)."""
+        """Tuning / test aid: force the fused launches' top-k front end (0 = automatic; 1 = first generation, 2 / 3 =
+        second generation without / with its histogram pre-filter)."""
         check(lib.quest_decode_set_front_end(self._h, int(generation)), "set_front_end")
 
     def set_selection_out(self, val_out, idx_out) -> None:

@@ -14,7 +14,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libquest_hip.so")
 SOURCES = ["append.hip", "estimate.hip", "topk.hip", "sparse_attn.hip", "rope_norm.hip", "decode_layer.hip"]
-HEADERS = ["quest_common.cuh", "topk_select.cuh", "topk_bitmap.cuh", "append_device.cuh", "estimate_device.cuh", "decode_device.cuh", os.path.join("..", "..", "include", "quest_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          # first 16 kernarg dwords in SGPRs at wave launch (the kernels keep their pointers first): the first
@@ -134,4 +133,10 @@ def kernel_metadata(lib_path: str = LIB):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m quest_amd.build [--force]                       the product library
+    # python -m quest_amd.build --variant OUT.so -DFOO [-DBAR]  a tuning build (loaded with QUEST_HIP_LIB=OUT.so)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(os.path.abspath(sys.argv[i + 1]), [a for a in sys.argv[i + 2:] if a.startswith("-")]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -2,38 +2,8 @@
 // per-workgroup partial states (merge_states_kernel's fast path) and the workgroup body of sparse_decode_kernel (sparse_attn.hip, which also holds the reference citations and the design notes).
 #pragma once
 #include "estimate_device.cuh"
-#include "topk_colrange.cuh"
-#include "topk_prefilter.cuh"
-
-// Developer aid (scripts/timeline.py): -DQUEST_TIMELINE makes one workgroup of sparse_decode_kernel write
-// clock stamps of its phases into the `lse` buffer instead of the log-sum-exp.
-#ifdef QUEST_TIMELINE
-#define QUEST_LSE_ENABLED false
-#define QUEST_STAMP(i) \
-    do { __builtin_amdgcn_s_waitcnt(0); tl[i] = clock64(); } while (0)
-#define QUEST_TL_PARAM , long long* tl
-#define QUEST_TL_ARG , tl
-#else
-#define QUEST_LSE_ENABLED true
-#define QUEST_STAMP(i) \
-    do { } while (0)
-#define QUEST_TL_PARAM
-#define QUEST_TL_ARG
-#endif
-
-// Developer aid (scripts/wallstamps.py): -DQUEST_WALLSTAMPS makes EVERY workgroup of the fused launches leave four
-// wall-clock stamps (100 MHz, chip-wide: kernel entry, page list known, wave 0's pages folded, partial written) and its
-// page count in the spare floats of its partial-state record -- the distribution over the 512 workgroups of a launch in
-// the cold regime the bench measures, which the one-workgroup cycle timeline above cannot show.
-#ifdef QUEST_WALLSTAMPS
-#define QUEST_WS_PARAM , const unsigned ws_entry, const unsigned ws_fe
-#define QUEST_WS_ARG , ws_entry, (unsigned)wall_clock64()
-#define QUEST_WS_ENTRY const unsigned ws_entry = (unsigned)wall_clock64();
-#else
-#define QUEST_WS_PARAM
-#define QUEST_WS_ARG
-#define QUEST_WS_ENTRY
-#endif
+#include "stamps.cuh"
+#include "topk_bitmap.cuh"
 
 namespace quest {
 
@@ -69,9 +39,8 @@ struct DecodeParams {
     uint32_t vec_front;     // fused front end: 0 = first generation (topk_select.cuh); 1 = the same, staging arrays fed by
                             // 8/16-byte granule loads; 3 = the same, each thread loads its OWN cpt (4 or 8) columns and
                             // page ids straight into registers (no LDS staging); 2 = second generation
-                            // (topk_bitmap.cuh); 4 = column-range ownership (topk_colrange.cuh) on the ownership of 3
-                            // (sparse_decode_colrange_body); 5 = the same on the granule ownership of 2.  1-5 need
-                            // aligned score rows
+                            // (topk_bitmap.cuh); 8 = tiles (sparse_decode_tiles_body: the rows carry tile maxima).
+                            // 1-3 and 8 need aligned score rows
     uint32_t cpt;           // fused front end: columns per thread (thread t owns [t*cpt, t*cpt + cpt)), host-chosen
     // ---- beyond the preloaded block (one scalar load of the argument segment)
     uint32_t idx_stride;
@@ -95,8 +64,6 @@ struct DecodeParams {
     uint32_t xcd_period;  // > 1: grid row y serves query head (y % period) * (Hq / period) + y / period (see sparse_decode_kernel)
     uint32_t fe2_prefilter;  // second-generation front end: histogram only the keys above a per-wave lower bound (topk_bitmap.cuh)
     const int32_t* budgets;  // optional per-sequence page budgets (pages incl. the current one) of a batched launch
-    // column-range ownership (vec_front 4 / 5, topk_colrange.cuh)
-    uint32_t chunks_inv;     // floor(2^32 / n_chunks) + 1: x / n_chunks == mulhi(x, chunks_inv) for the row lengths served
     uint32_t table_vec;      // page table(s) 16-byte aligned: a lane's 4 page ids are one load
     // decode append folded into the group-shared (full-KV) launch: shared_decode_kernel<.., APPEND = true>
     const half_t* app_k;     // [n_seqs][kv heads][D]: the new token's key / value, not yet in the pool
@@ -254,11 +221,6 @@ __device__ __forceinline__ void merge_head_fast(const float* __restrict__ w, hal
 // (The kernel parameters it needs travel BY VALUE in AttendArgs, built field by field by the caller: handing the
 // callers' modified copy of DecodeParams over by reference left a 32-byte slice of it in memory, which the compiler then
 // "promoted" to LDS -- 16 KiB per workgroup, one workgroup per CU instead of two, 24 us instead of 12 at cfg 3.)
-#ifdef QUEST_TL_FIRST_HEAD  // timeline builds: stamp a workgroup of head 0 (the FIRST workgroup dispatched to its CU) instead
-#define QUEST_TL_HEAD(n) 0u  // of the middle head (the second one, which waits for the first one's issue slots)
-#else
-#define QUEST_TL_HEAD(n) ((n) / 2)
-#endif
 struct AttendArgs {
     const half_t* kv;
     PoolStrides st;
@@ -411,9 +373,7 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
         }
     }
     QUEST_STAMP(6);
-#ifdef QUEST_WALLSTAMPS
-    const unsigned ws_gather = (unsigned)wall_clock64();
-#endif
+    QUEST_WS_NOW(ws_gather)
     // rows of the wave -> one state (xor butterfly across rows; both partners get the same bits)
     for_each_row_distance<LPR>([&](auto off_c) {
         constexpr int OFF = decltype(off_c)::value;
@@ -455,26 +415,15 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
         if (p.n_chunks == 1) {
             sv.o[(size_t)hq * D + f] = (half_t)(acc / den);
             if (QUEST_LSE_ENABLED && p.lse && f == 0) sv.lse[hq] = (M + __builtin_amdgcn_logf(den)) * 0.6931471805599453f;
-#ifdef QUEST_WALLSTAMPS
-            if (f == 0 && sv.ws && p.ws_stride >= (uint32_t)D + 8u) {  // (this build allocates the workspace for one-chunk plans too)
-                unsigned* u = reinterpret_cast<unsigned*>(sv.ws + (size_t)hq * p.ws_stride + D + 2);
-                u[0] = ws_entry, u[1] = ws_fe, u[2] = ws_gather, u[3] = (unsigned)wall_clock64();
-                u[4] = slot_end > slot_begin ? slot_end - slot_begin : 0u;
-            }
-#endif
+            // (a wall-stamp build allocates the workspace for one-chunk plans too)
+            if (f == 0) QUEST_WS_RECORD(sv.ws ? sv.ws + (size_t)hq * p.ws_stride : nullptr, D, p.ws_stride, slot_end > slot_begin ? slot_end - slot_begin : 0u);
         } else {
             float* w = sv.ws + ((size_t)hq * p.n_chunks + chunk) * p.ws_stride;
             w[f] = acc;
             if (f == 0) {
                 w[D] = M;
                 w[D + 1] = den;
-#ifdef QUEST_WALLSTAMPS
-                if (p.ws_stride >= (uint32_t)D + 8u) {
-                    unsigned* u = reinterpret_cast<unsigned*>(w + D + 2);
-                    u[0] = ws_entry, u[1] = ws_fe, u[2] = ws_gather, u[3] = (unsigned)wall_clock64();
-                    u[4] = slot_end > slot_begin ? slot_end - slot_begin : 0u;
-                }
-#endif
+                QUEST_WS_RECORD(w, D, p.ws_stride, slot_end > slot_begin ? slot_end - slot_begin : 0u);
             }
         }
     }
@@ -506,12 +455,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
     const int col = lane % LPR;
     // Source order matters up to the first loads: everything above them uses only the preloaded arguments (see
     // DecodeParams); values that need the rest of the struct (kv head, slots, pool strides) are derived after them.
-#ifdef QUEST_TIMELINE
-    long long tl[10] = {};
-    long long sub_out[9] = {};
-    const long long wall0 = wall_clock64();
-    QUEST_STAMP(0);
-#endif
+    QUEST_TL_BEGIN
     QUEST_WS_ENTRY
     const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
     // state-driven launches pass the longest row the graph will see in p.n_scores (it sizes FC); the live
@@ -548,9 +492,6 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
         Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
-        constexpr bool kFe3 = FC >= 16 && FC <= 32 && NW == 8;  // instantiations that carry the third-generation front end
-        [[maybe_unused]] uint2 raw3[kFe3 ? FC / 4 : 1];
-        __shared__ Fe3Smem<kFe3 ? NW : 1> f3;
         // live lengths of a state-driven launch: ONE scalar load (n_pages, last page's length and id are adjacent),
         // issued before the vector loads below and consumed after them
         // (unconditional, from q's bytes when there is no state: a load under a branch is waited for at the join)
@@ -589,13 +530,6 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 own_keys = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
             fe2_clear<NT>(sm);
-        } else if (kFe3 && vec_front == 6) {  // third generation (long rows): the thread's own FC columns
-            if constexpr (kFe3) {
-                fe3_issue<FC>(srow, n_cap, raw3);
-                fe2_clear<NT>(sm);
-                if (threadIdx.x == 0) f3.abort = 0u;
-
-            }
         } else if (vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
             fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
             fe2_clear<NT>(sm);
@@ -613,29 +547,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         }
         plan_slots();
         const uint32_t n = p.n_scores;
-        bool second_gen = vec_front == 2;
-        if constexpr (kFe3) {
-            if (n > 0 && vec_front == 6) {
-                QUEST_STAMP(1);
-                const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
-                const bool done = fe3_select<NT, FC>(sm, f3, raw3, srow, sv.indices, n, p.n_sel, slot_begin, slot_end, s_sel,
-                                                     p.sel_val_out ? p.sel_val_out + out_row : nullptr,
-                                                     p.sel_idx_out ? p.sel_idx_out + out_row : nullptr
-#ifdef QUEST_TIMELINE
-                                                     , sub_out
-#endif
-                );
-                QUEST_STAMP(4);
-                if (done) {
-                    __syncthreads();
-                    QUEST_STAMP(5);
-                } else {  // block-uniform and rare (a wave with > 256 candidates, k > 512): the second generation, from scratch
-                    fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, false, n_cap, raw);
-                    fe2_clear<NT>(sm);
-                    second_gen = true;
-                }
-            }
-        }
+        const bool second_gen = vec_front == 2;
         if (n > 0 && second_gen) {
             QUEST_STAMP(1);
             const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
@@ -644,11 +556,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             int32_t* idx_row_out = p.sel_idx_out ? p.sel_idx_out + out_row : nullptr;
             fe2_select<NT, FC>(sm, s_bm, raw, srow, sv.indices,
                                ids_staged ? reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset) : nullptr, n_cap, n,
-                               p.n_sel, slot_begin, slot_end, s_sel, val_row, idx_row_out, p.fe2_prefilter != 0
-#ifdef QUEST_TIMELINE
-                               , sub_out
-#endif
-            );
+                               p.n_sel, slot_begin, slot_end, s_sel, val_row, idx_row_out, p.fe2_prefilter != 0, QUEST_TL_SUB);
             QUEST_STAMP(4);
             __syncthreads();
             if (!ids_staged) {  // block-uniform: columns -> pages, one parallel round trip
@@ -656,7 +564,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 __syncthreads();
             }
             QUEST_STAMP(5);
-        } else if (FC <= 16 && n > 0 && vec_front != 6) {  // first-generation front end (unaligned score rows; rows <= 4096 columns)
+        } else if (FC <= 16 && n > 0) {  // first-generation front end (unaligned score rows; rows <= 4096 columns)
             // block-uniform; a one-page sequence has no row to select from (only the current page)
             // Ownership is fixed by the host from the row CAPACITY (p.cpt; NT * cpt >= n_cap >= n).
             const uint32_t cpt = p.cpt;
@@ -712,20 +620,12 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
                 }
             }
             }
-#ifdef QUEST_TIMELINE
-            long long sub[9] = {};
-#else
-            long long* const sub = nullptr;
-#endif
             topk_publish_range<NT>(sm, mm);
             QUEST_STAMP(2);
             __syncthreads();
             QUEST_STAMP(3);
             if (!direct) topk_load_keys<FC>(keys_s, c0, n, cpt, key);
-            TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, sub);
-#ifdef QUEST_TIMELINE
-            for (int i = 0; i < 9; ++i) sub_out[i] = sub[i];
-#endif
+            TopkCursor cur = topk_select<NT, FC>(sm, key, n, p.n_sel, cpt, QUEST_TL_SUB);
             QUEST_STAMP(4);
             uint32_t my_slot[FC];
             bool mine[FC];
@@ -770,15 +670,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         if constexpr (FC > 0) return s_sel[slot - slot_begin];
         else return idx_row[slot];
     } QUEST_TL_ARG QUEST_WS_ARG);
-#ifdef QUEST_TIMELINE
-    QUEST_STAMP(9);
-    if (p.lse && chunk == p.n_chunks / 2 && hq == QUEST_TL_HEAD(num_qo_heads) && seq == 0 && threadIdx.x == 0) {
-        for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
-        if constexpr (FC > 0)
-            for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
-        p.lse[10] = (float)(wall_clock64() - wall0);  // 100 MHz ticks over the same span as tl[9] - tl[0]
-    }
-#endif
+    QUEST_TL_REPORT(p, chunk, hq, seq, num_qo_heads);
 }
 
 // ---- tiles front end (round 5): long score rows whose producer also left TILE MAXIMA -- per run of 8 columns the largest
@@ -804,11 +696,7 @@ __device__ __forceinline__ void sparse_decode_tiles_body(DecodeParams p, const u
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane % LPR;
     const uint32_t tid = threadIdx.x;
-#ifdef QUEST_TIMELINE
-    long long tl[10] = {};
-    const long long wall0 = wall_clock64();
-    QUEST_STAMP(0);
-#endif
+    QUEST_TL_BEGIN
     QUEST_WS_ENTRY
     const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
     const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);  // first used after the selection
@@ -847,7 +735,7 @@ __device__ __forceinline__ void sparse_decode_tiles_body(DecodeParams p, const u
         QUEST_STAMP(1);
         topk_publish_range<NT>(sm, mm);
         __syncthreads();
-        TopkCursor cur = topk_select<NT, TM>(sm, tkey, n_tiles, k1, cpt_t);
+        TopkCursor cur = topk_select<NT, TM>(sm, tkey, n_tiles, k1, cpt_t, QUEST_TL_SUB);
         QUEST_STAMP(2);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -902,123 +790,7 @@ __device__ __forceinline__ void sparse_decode_tiles_body(DecodeParams p, const u
     QUEST_STAMP(5);
     attend_slots<D, 16, NW>(attend_args(p), sv, q_raw, chunk, hq, slot_begin, slot_end, p.n_sel, wave, lane,
                             [&](uint32_t slot) -> int32_t { return s_sel[slot - slot_begin]; } QUEST_TL_ARG QUEST_WS_ARG);
-#ifdef QUEST_TIMELINE
-    QUEST_STAMP(9);
-    if (p.lse && chunk == p.n_chunks / 2 && hq == QUEST_TL_HEAD(num_qo_heads) && seq == 0 && threadIdx.x == 0) {
-        for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
-        p.lse[10] = (float)(wall_clock64() - wall0);
-    }
-#endif
-}
-
-// ---- column-range ownership (round 4; topk_colrange.cuh has the design note).  Workgroup `chunk` of a head owns the
-// columns [chunk * rl, chunk * rl + rl) of the head's score row, rl = ceil(n / n_chunks) rounded up to 4 (<= 256), and
-// gathers the selected pages among them (NG granules of 4 columns per lane: rl <= 256 NG); the last workgroup of a head also takes the sequence's current page.  After the
-// barrier that publishes the threshold there is no further exchange: no rank scan, no slot walk, no page-list barrier.
-// GEN 1: threshold-phase ownership of vec_front 3 (thread t loads its own p.cpt = 4 / 8 contiguous columns; rows up to
-// 4096 columns, FC = 8).  GEN 2: granule ownership of topk_bitmap.cuh with its pre-filter (rows up to FC * NT columns).
-template <int D, int FC, int NW, int GEN, int NG>
-__device__ __forceinline__ void sparse_decode_colrange_body(DecodeParams p, const uint32_t chunk, const uint32_t hq,
-                                                            const uint32_t seq, const uint32_t num_qo_heads) {
-    constexpr int LPR = D / kVec, NT = NW * kWave;
-    static_assert(GEN == 1 || GEN == 2, "threshold-phase ownership");
-    static_assert(GEN == 2 || FC == 8, "first-generation ownership: 8 keys per thread");
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int col = lane % LPR;
-#ifdef QUEST_TIMELINE
-    long long tl[10] = {};
-    long long sub_out[9] = {};
-    long long* const sub = sub_out;
-    const long long wall0 = wall_clock64();
-    QUEST_STAMP(0);
-#else
-    long long* const sub = nullptr;
-#endif
-    QUEST_WS_ENTRY
-    const SeqView sv = select_sequence(p, num_qo_heads, D, seq);
-    const half8 q_raw = ld8(sv.q + (size_t)hq * D + col * kVec);  // first used after the selection
-    __shared__ TopkSmem<NT> sm;
-    __shared__ int32_t s_list[kColRangeMax * NG];
-    const uint32_t n_cap = p.n_scores;
-    const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
-    // live lengths of a state-driven launch: one scalar load, issued before the vector loads, consumed after them
-    const int4 live = *(p.state ? reinterpret_cast<const int4*>(sv.state) : reinterpret_cast<const int4*>(p.q));
-
-    // ---- threshold-phase loads: addresses depend on the capacity only
-    uint32_t key[GEN == 1 ? FC : 1];
-    Fe2Raw<false> raw2[GEN == 2 ? FC / 4 : 1];
-    uint4 own_keys = make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t c0 = threadIdx.x * p.cpt;
-    if constexpr (GEN == 1) {
-        const uint32_t own_cc = c0 < n_cap ? c0 : 0u;
-        // two unconditional 8-byte loads (the second repeats the first at 4 columns per thread): see sparse_decode_body
-        const uint2 lo = *reinterpret_cast<const uint2*>(srow + own_cc);
-        const uint2 hi = *reinterpret_cast<const uint2*>(srow + own_cc + (p.cpt == 8 ? 4u : 0u));
-        own_keys = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    } else {
-        fe2_issue<NT, FC / 4, false>(srow, sv.indices, n_cap + 1u, false, n_cap, raw2);
-    }
-    fe2_clear<NT>(sm);
-    const int32_t budget_raw = ld_uniform_i32(p.budgets ? p.budgets + seq : reinterpret_cast<const int32_t*>(p.q));
-    if (p.state) {
-        p.n_scores = (uint32_t)(live.y - 1);
-        p.last_page_len = (uint32_t)live.z;
-        p.last_page_idx = live.w;
-        if (p.budgets) p.n_sel = min(p.n_sel, (uint32_t)max(budget_raw - 1, 0));
-        p.n_sel = min(p.n_sel, p.n_scores);
-    }
-    const uint32_t n = p.n_scores;
-    // ---- the workgroup's column range and the lane's 4 columns of it (scores + page ids): needed only once T is known
-    const uint32_t rl = (__umulhi(n + p.n_chunks - 1u, p.chunks_inv) + 3u) & ~3u;
-    const uint32_t rs = chunk * rl, re = min(rs + rl, n);
-    const uint32_t gc0 = rs + 4u * (uint32_t)lane;
-    ColRangeRaw graw[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        graw[g].k = make_uint2(0u, 0u);
-        graw[g].ids = make_uint4(0u, 0u, 0u, 0u);
-        if (g == 0 || (uint32_t)(g * kColRangeMax) < rl)  // block-uniform: NG covers the longest row of the instantiation
-            graw[g] = colrange_issue(srow, sv.indices, n_cap + 1u, n_cap, gc0 + (uint32_t)(g * kColRangeMax), p.table_vec != 0);
-    }
-    const bool last_chunk = chunk + 1u == p.n_chunks;
-    uint32_t n_listed = 0;
-    if (n > 0) {  // block-uniform; a one-page sequence has only its current page
-        ColRangeSel cs;
-        if constexpr (GEN == 1) {
-            uint32_t mm = kMmNeutral;
-            const uint32_t w[4] = {own_keys.x, own_keys.y, own_keys.z, own_keys.w};
-#pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                key[i] = half_key((uint16_t)((i & 1) ? w[(i >> 1) & 3] >> 16 : w[(i >> 1) & 3] & 0xffffu));
-                if ((uint32_t)i < p.cpt && c0 + i < n) mm = pk_max_u16(mm, mm_pack(key[i]));
-            }
-            QUEST_STAMP(1);
-            topk_publish_range<NT>(sm, mm);
-            QUEST_STAMP(2);
-            __syncthreads();
-            QUEST_STAMP(3);
-            cs = topk_threshold_colrange<NT, FC>(sm, key, n, p.n_sel, p.cpt, rs, sub);
-        } else {
-            QUEST_STAMP(1);
-            cs = fe2_threshold_colrange<NT, FC>(sm, raw2, n_cap, n, p.n_sel, rs, p.fe2_prefilter != 0, sub);
-        }
-        QUEST_STAMP(4);
-        const size_t out_row = ((size_t)seq * num_qo_heads + hq) * p.sel_stride;
-        n_listed = colrange_collect<NG>(cs, graw, gc0, rl, re, s_list, wave == 0, p.sel_idx_out ? p.sel_idx_out + out_row : nullptr,
-                                    p.sel_val_out ? p.sel_val_out + out_row : nullptr);
-        QUEST_STAMP(5);
-    }
-    attend_slots<D, 16, NW>(attend_args(p), sv, q_raw, chunk, hq, 0u, n_listed + (last_chunk ? 1u : 0u), n_listed, wave, lane,
-                            [&](uint32_t slot) -> int32_t { return s_list[slot]; } QUEST_TL_ARG QUEST_WS_ARG);
-#ifdef QUEST_TIMELINE
-    QUEST_STAMP(9);
-    if (p.lse && chunk == p.n_chunks / 2 && hq == QUEST_TL_HEAD(num_qo_heads) && seq == 0 && threadIdx.x == 0) {
-        for (int i = 0; i < 10; ++i) p.lse[i] = (float)(tl[i] - tl[0]);
-        for (int i = 0; i < 9; ++i) p.lse[16 + i] = (float)(sub_out[i] - tl[0]);
-        p.lse[10] = (float)(wall_clock64() - wall0);
-        p.lse[11] = (float)n_listed;
-    }
-#endif
+    QUEST_TL_REPORT(p, chunk, hq, seq, num_qo_heads);
 }
 
 }  // namespace quest

@@ -105,9 +105,7 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     uint32_t hq = blockIdx.y;
     if (xcd_period > 1) hq = (hq % xcd_period) * (a_num_qo_heads / xcd_period) + hq / xcd_period;
     const uint32_t hk = hq / group;
-#ifdef QUEST_TIMELINE
-    long long tl[10] = {};
-#endif
+    QUEST_TL_BEGIN
     QUEST_WS_ENTRY
 
     // ---- everything the first loads need comes from the preloaded arguments
@@ -222,9 +220,7 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     }
     if (!ids_parked) park_ids();  // waves without a round (short sequences)
     QUEST_STAMP(1);
-#ifdef QUEST_WALLSTAMPS
-    const unsigned ws_est = (unsigned)wall_clock64();  // this wave's share of the head's pages is scored
-#endif
+    QUEST_WS_NOW(ws_est)  // this wave's share of the head's pages is scored
 
     // ---- top-k over the head's keys, straight from LDS
     if (n > 0 && n_sel > 0) {  // block-uniform
@@ -270,10 +266,7 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     sv.state = stp;
     attend_slots<D, S_T, NW, true>(aa, sv, q_raw, 0u, hq, 0u, n_sel + 1u, n_sel, wave, lane,
                                    [&](uint32_t slot) -> int32_t { return s_sel[slot]; } QUEST_TL_ARG QUEST_WS_ARG, app);
-#ifdef QUEST_WALLSTAMPS
-    if (tid == 0 && sv.ws && p.ws_stride >= (uint32_t)D + 8u)
-        reinterpret_cast<unsigned*>(sv.ws + (size_t)hq * p.ws_stride + D + 2)[5] = ws_est;
-#endif
+    if (tid == 0) QUEST_WS_RECORD_EXTRA(sv.ws ? sv.ws + (size_t)hq * p.ws_stride : nullptr, D, p.ws_stride, 5, ws_est);
 }
 
 }  // namespace quest

@@ -54,8 +54,6 @@ __global__ __launch_bounds__(NW* kWave, (D >= 256 && NW >= 8) ? NW / 4 : NW / 2)
     }
     p.xcd_period = period;
     if constexpr (VF == 8) sparse_decode_tiles_body<D, NW>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
-    else if constexpr (VF == 4) sparse_decode_colrange_body<D, FC, NW, 1, 1>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
-    else if constexpr (VF == 5) sparse_decode_colrange_body<D, FC, NW, 2, FC / 8>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
     else sparse_decode_body<D, S_T, FC, NW, VF>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
 }
 
@@ -368,7 +366,7 @@ struct quest_decode_handler {
     uint32_t batch = 1;                          // sequences per launch the plan / workspace are made for
     uint32_t num_cus = 256;                      // compute units of the current device (MI355X: 256)
     bool skip_merge = false;                     // measurement aid: leave the partial states unmerged
-    int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation, 3 = 2 + pre-filter, 4 = column-range ownership where applicable (= 0 today)
+    int front_end = 0;                           // fused top-k front end: 0 = by row length, 1 / 2 = forced generation, 3 = 2 + pre-filter
     uint32_t last_launch[6] = {0, 0, 0, 0, 0, 0};  // quest_decode_last_launch_info
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
@@ -418,7 +416,7 @@ extern "C" int quest_decode_set_skip_merge(quest_decode_handler_t* h, int skip) 
 }
 
 extern "C" int quest_decode_set_front_end(quest_decode_handler_t* h, int generation) {
-    if (!h || generation < 0 || generation > 6) return QUEST_EINVAL;
+    if (!h || generation < 0 || generation > 3) return QUEST_EINVAL;
     h->front_end = generation;
     return 0;
 }
@@ -535,18 +533,18 @@ template <int D, int FC>
 static int launch_decode_fc(quest_decode_handler* h, const DecodeParams& p, uint32_t num_qo_heads, uint32_t waves,
                             hipStream_t s, uint32_t n_seqs) {
     dim3 grid(h->n_chunks, num_qo_heads, n_seqs);
-    const bool colrange = FC > 0 && (p.vec_front == 4 || p.vec_front == 5);  // no dynamic LDS: nothing is staged
-    const size_t lds = FC > 0 && !colrange ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0) : 0;  // the table has n_scores + 1 entries, staged in granules of 4
+    const size_t lds = FC > 0 ? (size_t)p.ids_lds_offset + (p.stage_ids ? (size_t)((p.n_scores + 4u) & ~3u) * 4 : 0) : 0;  // the table has n_scores + 1 entries, staged in granules of 4
     // what this launch is (quest_decode_last_launch_info): keys per thread, waves, front-end variant, one-variant
     // instantiation or the generic kernel, workgroups per head, sequences
     uint32_t* info = h->last_launch;
     info[0] = (uint32_t)FC, info[1] = waves, info[2] = FC > 0 ? p.vec_front : 0u, info[3] = 0u, info[4] = h->n_chunks, info[5] = n_seqs;
     // The common (keys per thread, front-end variant) pairs of 8-wave page-16 launches as their own compact
-    // instantiations -- the generic kernel carries all four front-end variants (27 KiB of code; the one-variant kernels
-    // are 10-14 KiB) and measured 0.57 us per launch slower at the headline shape:
+    // instantiations -- the generic kernel carries every front-end variant (27 KiB of code in round 3; the one-variant
+    // kernels are 10-14 KiB) and measured 0.57 us per launch slower at the headline shape:
     //   FC 8,  variant 3: single-sequence rows <= 4096 pages, keys and page ids straight into registers (cfg 3)
-    //   FC 8,  variant 1: the same rows in batched launches, staging arrays fed by vector loads (cfg 3 x 8, cfg 5)
-    //   FC 16 / 32, variant 2: second-generation front end of long rows (cfg 4)
+    //   FC 8,  variant 1: the same rows in batched launches, staging arrays fed by vector loads (cfg 5)
+    //   FC 8,  variant 8: tiles front end, rows that carry their tile maxima (cfg 4)
+    //   FC 16 / 24 / 32, variant 2: second-generation front end of long rows without tile maxima
     // QUEST_FE_SPECIALIZE=0 launches the generic kernel instead (A/B).
     static const bool specialize = [] { const char* e = quest_tuning_env("QUEST_FE_SPECIALIZE"); return !e || atoi(e) != 0; }();
     if (p.vec_front == 8u) {  // tiles front end (plan_decode: page size 16, 8 waves)
@@ -559,24 +557,10 @@ static int launch_decode_fc(quest_decode_handler* h, const DecodeParams& p, uint
             return QUEST_EUNSUPPORTED;
         }
     }
-    if (colrange && !(p.page_size == 16 && waves == 8 && (FC == 8 || FC == 16 || FC == 24 || FC == 32)))
-        return QUEST_EUNSUPPORTED;  // plan_decode only picks the column-range variants for these instantiations
-    if ((specialize || colrange) && p.page_size == 16 && waves == 8) {
-        constexpr int VFA = FC == 8 ? 3 : 2, VFB = FC == 8 ? 1 : 2, VFC = FC == 8 ? 4 : 5;
+    if (specialize && p.page_size == 16 && waves == 8) {
+        constexpr int VFA = FC == 8 ? 3 : 2, VFB = FC == 8 ? 1 : 2;
         if constexpr (FC == 8 || FC == 16 || FC == 24 || FC == 32) {
             info[3] = 1u;
-            if constexpr (FC != 8) {
-                if (p.vec_front == 6u) {  // third generation (topk_prefilter.cuh), second-generation code as its cold fallback
-                    hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, 6>), grid, dim3(8 * kWave), 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
-                    QUEST_LAUNCH_CHECK();
-                    goto merge;
-                }
-            }
-            if (p.vec_front == (uint32_t)VFC) {
-                hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFC>), grid, dim3(8 * kWave), 0, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
-                QUEST_LAUNCH_CHECK();
-                goto merge;
-            }
             if (p.vec_front == (uint32_t)VFA) {
                 hipLaunchKernelGGL((sparse_decode_kernel<D, 16, FC, 8, VFA>), grid, dim3(8 * kWave), lds, s, QUEST_DECODE_HEAD_ARGS(p, num_qo_heads), p);
                 QUEST_LAUNCH_CHECK();
@@ -677,7 +661,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
     p.ids_lds_offset = (uint32_t)((((size_t)n_scores * 2) + 15) & ~(size_t)15);
     p.vec_front = 0;
     int forced = 0;
-    bool table_vec = false, rows_aligned = false, no_colrange = false;
+    bool table_vec = false, rows_aligned = false;
     if (fused) {
         // second-generation front end (topk_bitmap.cuh): 8-byte loads of 4 scores straight from the row -> the rows
         // must be 8-byte aligned and readable up to the next multiple of 4 columns (the row stride covers it)
@@ -688,8 +672,6 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         // quest_decode_set_front_end / QUEST_FRONT_END=1 / 2 force a generation where it is applicable (tuning, tests).
         static const int env_forced = [] { const char* e = quest_tuning_env("QUEST_FRONT_END"); return e ? atoi(e) : 0; }();
         forced = h->front_end ? h->front_end : env_forced;
-        no_colrange = forced == 5;  // 5 = automatic choice among the slot-ownership variants
-        if (no_colrange) forced = 0;
         const uint32_t stride = p.score_stride;
         const bool aligned = ((uintptr_t)scores & 7u) == 0 && stride % 4u == 0 && stride >= ((n_scores + 3u) & ~3u);
         const bool table_aligned = ((uintptr_t)kv.indices & 15u) == 0 && (batch.n_seqs == 1 || batch.kv_table_stride % 4u == 0);
@@ -697,7 +679,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         rows_aligned = aligned;
         int gen = 1;
         if (aligned) {
-            if (forced == 2 || forced == 3 || forced == 6 || ((forced == 0 || forced == 4) && n_scores > 4096u)) gen = 2;
+            if (forced == 2 || forced == 3 || (forced == 0 && n_scores > 4096u)) gen = 2;
         }
         if (gen != 1) {
             p.vec_front = 2;
@@ -760,12 +742,11 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         fc = 8;
         p.cpt = (n_scores + 7u) / 8u <= 2u * 512u ? 2u : 4u;  // tile keys per thread
         p.table_vec = table_vec ? 1u : 0u;
-        p.chunks_inv = 0;
     } else if (fused) {
         // the selection is VALU-issue bound (~1000 instructions per wave at 8 keys per thread), so rows
         // beyond 1024 pages get 8 waves (<= 4 keys per thread up to 2048 pages, <= 8 up to 4096); the
         // attention part runs the same with 4 or 8 waves.  Measured at cfg 3: 15.2 vs 15.8 us.
-        if (kv.page_size == 16 && (n_scores > 4u * 4u * kWave || forced == 4)) waves = 8;
+        if (kv.page_size == 16 && n_scores > 4u * 4u * kWave) waves = 8;
         const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
         const uint32_t per_thread = (n_scores + nt - 1) / nt;
         // (24: rows of 8193-12288 columns at 512 threads -- cfg 4's capacity of ~8320 pages needs 17 keys per thread; the
@@ -787,40 +768,11 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
             (p.cpt == 4 || (p.cpt == 8 && ((uintptr_t)scores & 15u) == 0 && p.score_stride % 8u == 0 &&
                             p.score_stride >= ((n_scores + 7u) & ~7u)));
         if (direct_possible && direct_ok && p.vec_front == 1) p.vec_front = 3;
-        // Column-range ownership (round 4, topk_colrange.cuh): a workgroup gathers the selected pages of ITS range of
-        // columns -- no rank scan, no page-list hand-off after the threshold is known.  Built, parity-green, and measured
-        // SLOWER than slot ownership (us per launch, same box: cfg 3 13.27 vs 12.07; cfg 4 20.34 vs 19.54; with 16-wave
-        // workgroups 15.1 vs 13.3): the page list is known 0.7 us earlier (3.06 vs 3.78 us after kernel entry) but a
-        // range of 128 columns holds 8 +- 2.7 selected pages, a CU's two workgroups 16 +- 3.9, and the gather is bound by
-        // what ONE CU can have in flight: waves with two pages finish 2.4 us after waves with one, the last data of the
-        // launch arrives 7.2 us after the first request instead of 5.7 (profiles/r04_wallstamps_cfg3_*.log).  Exact slot
-        // ownership puts the same 8 pages on every workgroup.  So: OFF by default; quest_decode_set_front_end(h, 4)
-        // (or QUEST_TUNING=1 QUEST_COLRANGE=1) selects it where it is applicable -- more than one workgroup per head
-        // and a range a wave covers with 4 (first-generation threshold phase) or fc / 2 (second) columns per lane.
-        static const int colrange_env = [] { const char* e = quest_tuning_env("QUEST_COLRANGE"); return e ? atoi(e) : 0; }();
-        if ((forced == 4 || (colrange_env && forced == 0 && !no_colrange)) && h->n_chunks >= 2 && kv.page_size == 16 && waves == 8) {
-            const uint32_t rl = ((n_scores + h->n_chunks - 1) / h->n_chunks + 3u) & ~3u;
-            if (direct_possible && rl <= (uint32_t)kColRangeMax) p.vec_front = 4;
-            // (second-generation ownership: fc / 8 granules of 4 columns per lane, i.e. rl <= 32 fc -- what 16 workgroups
-            // per head need at the instantiation's longest row)
-            else if (p.vec_front == 2 && (fc == 16 || fc == 24 || fc == 32) && rl <= (uint32_t)(fc / 8) * (uint32_t)kColRangeMax) p.vec_front = 5;
-        }
-        // Third-generation front end (round 4, topk_prefilter.cuh) for long rows (> 4096 columns, 16-32 keys per thread in
-        // 8-wave workgroups): one pass over a thread's keys compacts the candidates above a per-wave lower bound of the
-        // threshold (~4 % of the row), the rest of the selection runs on <= 4 keys per thread.  Built, parity-green on
-        // crafted rows incl. its two fallbacks (tests/test_gpu_long_rows.py), and measured SLOWER than the second
-        // generation at cfg 4: 22.4 vs 19.6 us per launch.  The phases behind the compaction are indeed short (threshold +
-        // slots 1.0 us against 4.6 for bitmaps, rank scan and page resolve), but converting, bounding and compacting 24 keys
-        // per thread costs as many issue slots as the second generation's histogram and bitmap passes, and the slowest wave
-        // of a workgroup reaches the page-list barrier 4.5 us after the fastest (2.3 in the second generation):
-        // profiles/r04_timeline_front_end_cfg4_third_generation.log.  OFF by default; quest_decode_set_front_end(h, 6).
-        // Needs 8-byte aligned score rows readable up to the next multiple of 4 columns and k <= 512.
-        if (p.vec_front == 2 && forced == 6 && waves == 8 && (fc == 16 || fc == 24 || fc == 32) && kv.page_size == 16 &&
-            h->n_sel <= 512u && n_scores <= 512u * (uint32_t)fc) {
-            p.vec_front = 6;
-            p.stage_ids = 0;
-        }
-        p.chunks_inv = (uint32_t)(0x100000000ull / h->n_chunks) + 1u;  // (n_chunks == 1: unused)
+        // (Round 4 built two more front ends and measured both slower: column-range ownership -- a workgroup gathers the
+        // selected pages of ITS range of columns, no rank scan, no page-list hand-off: cfg 3 13.27 vs 12.07 us, cfg 4 20.34
+        // vs 19.54, the per-CU page imbalance costs more than the earlier page list returns -- and a third generation for
+        // long rows, pre-filter -> compact -> short-row select: 22.4 vs 19.6 us at cfg 4.  Removed from the tree in round 5,
+        // DESIGN.md 3.5; history: git log -S sparse_decode_colrange_body, -S fe3_select.)
         p.table_vec = table_vec ? 1u : 0u;
     }
     return 0;

@@ -13,6 +13,7 @@
 // -> exact T; packed block scan of per-thread (>T, ==T) counts -> output slots.
 #pragma once
 #include "quest_common.cuh"
+#include "stamps.cuh"
 
 namespace quest {
 
@@ -27,7 +28,7 @@ struct TopkSmem {
     uint32_t wave_tot[2][NT / kWave];  // one row per block scan, so a scan needs a single barrier
     uint32_t wave_mm[NT / kWave];      // per wave: (max key << 16) | (0xffff - min key)
     uint32_t wave_lb[NT / kWave];      // per wave: a key that at least ceil(k / waves) of the wave's keys reach (fe2 pre-filter)
-    uint32_t misc[8];                  // thr_bin, above, T, need_eq (topk_select); + bin word, T, need, lower counts (topk_colrange.cuh)
+    uint32_t misc[8];                  // thr_bin, above, T, need_eq (topk_select)
 };
 
 // Packed (max, 0xffff - min) of 16-bit keys: one v_pk_max_u16 combines both halves.
@@ -120,19 +121,11 @@ __device__ __forceinline__ void topk_load_keys(const uint16_t* keys_s, uint32_t 
 
 // Precondition: topk_clear() + topk_publish_range() + __syncthreads() already done; key[i] holds column
 // tid*cpt + i for i < cpt.
-#ifdef QUEST_TIMELINE
-#define QUEST_SUBSTAMP(i) \
-    do { if (sub) { __builtin_amdgcn_s_waitcnt(0); sub[i] = clock64(); } } while (0)
-#else
-#define QUEST_SUBSTAMP(i) \
-    do { } while (0)
-#endif
-
 // Shared tail of the selection routines: with T / need known (cur), count the thread's keys above and at the threshold
 // and turn the block-wide exclusive prefix into the cursor (output slot of the thread's first selected column, rank of
 // its first tied column).
 // `valid(i)`: whether key[i] is a live entry of the thread (the contiguous-ownership callers pass "i < cpt && c0 + i < n";
-// the long-row front end of topk_prefilter.cuh owns compacted candidates and passes its own mask).
+// the tiles front end owns compacted candidates and passes its own mask).
 template <int NT, int C, typename Valid>
 __device__ __forceinline__ TopkCursor topk_finish_v(TopkSmem<NT>& sm, const uint32_t (&key)[C], Valid valid, TopkCursor cur,
                                                    long long* sub) {
@@ -160,11 +153,9 @@ __device__ __forceinline__ TopkCursor topk_finish(TopkSmem<NT>& sm, const uint32
     return topk_finish_v<NT, C>(sm, key, [&](int i) { return (uint32_t)i < cpt && c0 + i < n; }, cur, sub);
 }
 
-// abort: optional LDS word; when it is non-zero after the histogram barrier (block-uniform) the selection stops and the
-// returned cursor has T == 0xffffffff (the caller falls back to another front end).
 template <int NT, int C, typename Valid>
 __device__ __forceinline__ TopkCursor topk_select_v(TopkSmem<NT>& sm, const uint32_t (&key)[C], Valid valid, uint32_t k,
-                                                    const uint32_t* abort = nullptr, long long* sub = nullptr) {
+                                                    long long* sub = nullptr) {
     constexpr int BPT = kBins1 / NT;  // histogram bins per thread in the suffix scan
     static_assert(kBins1 % NT == 0 && NT >= kWave, "thread count must divide the bin count");
     const uint32_t tid = threadIdx.x;
@@ -187,11 +178,6 @@ __device__ __forceinline__ TopkCursor topk_select_v(TopkSmem<NT>& sm, const uint
     QUEST_SUBSTAMP(0);
     __syncthreads();
     QUEST_SUBSTAMP(1);
-    if (abort && *abort) {
-        TopkCursor none;
-        none.T = 0xffffffffu, none.need = none.pos = none.eq_rank = 0u;
-        return none;
-    }
 
     {  // suffix scan from the top bin: thread t owns bins kBins1-1-BPT*t .. kBins1-BPT*(t+1), descending
         // the thread's BPT bins are one contiguous, BPT*4-byte aligned block: fetch it with 8/16-byte LDS
@@ -274,7 +260,7 @@ template <int NT, int C>
 __device__ __forceinline__ TopkCursor topk_select(TopkSmem<NT>& sm, const uint32_t (&key)[C], uint32_t n, uint32_t k,
                                                   uint32_t cpt, long long* sub = nullptr) {
     const uint32_t c0 = threadIdx.x * cpt;
-    return topk_select_v<NT, C>(sm, key, [&](int i) { return (uint32_t)i < cpt && c0 + i < n; }, k, nullptr, sub);
+    return topk_select_v<NT, C>(sm, key, [&](int i) { return (uint32_t)i < cpt && c0 + i < n; }, k, sub);
 }
 
 // (A low-bits variant -- bins = key & 2047, so that the range publish and the histogram atomics share one barrier, with

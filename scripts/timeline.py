@@ -51,7 +51,7 @@ for l in range(a.layers):
                                  c2.metadata_cache.buf_layer(l), c2.meta_table_full, c2.step_state, c2.max_pages - 1,
                                  c2.layout)
 h2 = c2._decode_handler
-variants = ("dyn",) if a.seqlen > 65536 else ("dyn", "dyn-slots", True, False)
+variants = ("dyn",) if a.seqlen > 65536 else ("dyn", True, False)
 for fused in variants:
     acc = torch.zeros(a.layers * 4, 32, device=dev)
     for rep in range(4):
@@ -59,8 +59,7 @@ for fused in variants:
             lse = acc[rep * a.layers + l]
             q = w.q[l]
             o = torch.empty_like(q)
-            if fused in ("dyn", "dyn-slots"):
-                h2.set_front_end(0 if fused == "dyn" else 5)
+            if fused == "dyn":
                 kv = _kernels._paged(c2.kv_cache.buf_layer(l), c2.kv_table_full, None, 1, 0, c2.layout)
                 check(lib.quest_decode_forward_fused_topk_dyn(h2._wrapper._h, w2.q[l].data_ptr(), o.data_ptr(), kv, q.size(1),
                                                               sc2[l].data_ptr(), sc2[l].size(1), c2.max_pages - 1,
@@ -82,36 +81,17 @@ for fused in variants:
     torch.cuda.synchronize()
     t = acc[a.layers:].cpu().median(dim=0).values  # skip the first (cold) round
     cyc_per_us = float(t[9] / (t[10] / 100.0)) if t[10] > 0 else float("nan")
-    label = {"dyn": "state-driven, default front end", "dyn-slots": "state-driven, slot-ownership front end (forced)",
-             True: "host-planned fused launch", False: "index list from memory (FC = 0)"}[fused]
-    info = (h2 if fused in ("dyn", "dyn-slots") else h).last_launch_info()
+    label = {"dyn": "state-driven, default front end", True: "host-planned fused launch",
+             False: "index list from memory (FC = 0)"}[fused]
+    info = (h2 if fused == "dyn" else h).last_launch_info()
     print(f"== {label}: variant {info['front_end_variant']}, {info['workgroups_per_head']} workgroups per head; "
           f"{cyc_per_us:.0f} cycles/us, workgroup lifetime {float(t[9]) / cyc_per_us:.2f} us")
-    if info["front_end_variant"] == 6:
-        for i, nme in enumerate(names):
-            print(f"  {float(t[i]) / cyc_per_us:6.2f} us  {nme}")
-        for i, nme in enumerate(["keys converted, wave bound + max published", "barrier A", "candidates compacted + re-read, page ids requested",
-                                 "topk_select on <= 4 keys per thread done", "slots written"]):
-            print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  fe3_select: {nme}")
-        continue
-    if info["front_end_variant"] in (4, 5):
-        cn = ["entry", "own keys arrived + converted", "range published", "barrier", "threshold known",
-              "page list built (per wave)", "all K/V folded", "row butterfly + LDS write", "barrier", "partial written"]
-        for i, nme in enumerate(cn):
-            print(f"  {float(t[i]) / cyc_per_us:6.2f} us  {nme}")
-        print(f"      pages of this workgroup: {float(t[11]):.0f}")
-        sn = (["hist atomics issued", "barrier", "bins read + summed", "block scan", "threshold bin published (barrier)",
-               "hist2 + barrier", "exact T + barrier"] if info["front_end_variant"] == 4 else
-              ["keys + range published", "barrier A", "hist atomics issued", "barrier B", "threshold (per wave)"])
-        for i, nme in enumerate(sn):
-            print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  {nme}")
-        continue
     for i, nme in enumerate(names):
         print(f"  {float(t[i]) / cyc_per_us:6.2f} us  {nme}")
-    if fused == "dyn" and False:
+    if info["front_end_variant"] == 2:
         subn = ["keys + range published", "barrier A", "hist atomics issued", "barrier B", "threshold (per wave)",
-                "bitmaps written", "barrier D", "ranks scanned", "-"]
-        for i, nme in enumerate(subn[:8]):
+                "bitmaps written", "barrier D", "ranks scanned"]
+        for i, nme in enumerate(subn):
             print(f"      {float(t[16 + i]) / cyc_per_us:6.2f} us  fe2_select: {nme}")
     elif fused:
         subn = ["hist1 atomics issued", "barrier", "bins read + summed", "block scan", "threshold bin published (barrier)",

@@ -20,13 +20,13 @@ def _one(meta, fragment):
 
 
 @pytest.mark.parametrize("fragment,max_lds", [
-    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi4E", 14 * 1024),   # cfg 3: column-range ownership, first generation
-    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi3E", 14 * 1024),   # the slot-ownership twin
-    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi1E", 14 * 1024),   # batched launches (cfg 3 x 8, cfg 5)
-    ("sparse_decode_kernelILi128ELi16ELi24ELi8ELi5E", 17 * 1024),  # cfg 4: column-range ownership, long rows
-    ("sparse_decode_kernelILi128ELi16ELi24ELi8ELi2E", 18 * 1024),
+    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi3E", 14 * 1024),   # cfg 3: the timed single-sequence launch
+    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi1E", 14 * 1024),   # batched two-launch form (cfg 5)
+    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi8E", 14 * 1024),   # cfg 4: tiles front end
+    ("sparse_decode_kernelILi128ELi16ELi24ELi8ELi2E", 18 * 1024),  # long rows without tile maxima
     ("sparse_decode_kernelILi128ELi16ELi0ELi4ELin1E", 3 * 1024),   # index-list launches (reference op sequence)
     ("sparse_decode_kernelILi128ELi16ELi0ELi8ELin1E", 5 * 1024),
+    ("layer_decode_kernelILi128ELi8ELi8E", 14 * 1024),             # the one-launch layer (8 x cfg 3; + 12.3 KiB dynamic at 2069 pages)
 ])
 def test_attention_kernels_fit_two_workgroups_per_cu(meta, fragment, max_lds):
     k = _one(meta, fragment)

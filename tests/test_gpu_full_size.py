@@ -137,12 +137,8 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     torch.testing.assert_close(o2[0].float(), o_ref, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(o2.float(), o.float(), rtol=2e-3, atol=2e-3)
     # the same step (the append is idempotent) through the whole-row front ends (round 4's launch: second generation, 24
-    # keys per thread): without and with the histogram pre-filter of the long-row front end
-    # (csrc/topk_bitmap.cuh; the default above is "with") and through the third generation (csrc/topk_prefilter.cuh,
-    # measured slower, not the default): same pages, same slots, same bits; and through the column-range form
-    # (csrc/topk_colrange.cuh, measured slower and therefore not the default): same page lists, outputs within the fp32
-    # merge-order bound (a different workgroup split)
-    for gen in (2, 3, 6, 4):
+    # keys per thread) without and with the histogram pre-filter (csrc/topk_bitmap.cuh): same pages, same slots, same bits
+    for gen in (2, 3):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl._decode_handler.set_front_end(gen)
         sel_i2 = torch.full_like(sel_i, -1)
@@ -151,12 +147,9 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
         o3 = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, qu.score_scratch(ctl).zero_(), tiles=False)
         ctl._decode_handler.set_selection_out(None, None)
         assert torch.equal(sel_i2, sel_i), f"front end {gen}: page lists differ"
-        assert ctl._decode_handler.last_launch_info()["front_end_variant"] == {2: 2, 3: 2, 6: 6, 4: 5}[gen]
-        if gen == 4:
-            torch.testing.assert_close(o3.float(), o2.float(), rtol=2e-3, atol=2e-3)
-            torch.testing.assert_close(o3[0].float(), o_ref, rtol=5e-3, atol=5e-3)
-        else:
-            assert torch.equal(o3, o2), f"front end {gen}"
+        info = ctl._decode_handler.last_launch_info()
+        assert (info["keys_per_thread"], info["front_end_variant"]) == (24, 2), info
+        assert torch.equal(o3, o2), f"front end {gen}"
     ctl._decode_handler.set_front_end(0)
     ctl.end_forward()
 
@@ -309,7 +302,7 @@ def test_cfg3_headline_on_the_timed_path(layout):
     st[2] -= 1
     ctl.begin_graph_decode()
     outs = {}
-    for gen in (0, 4, 1):
+    for gen in (0, 1):
         ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
         ctl._decode_handler.set_front_end(gen)
         sel_v = torch.zeros(1, H, B - 1, dtype=torch.float16, device=DEV)
@@ -320,9 +313,8 @@ def test_cfg3_headline_on_the_timed_path(layout):
         o = qu.decode_layer_dyn(q, k[-1:], v[-1:], ctl, 0, scores)
         ctl._decode_handler.set_selection_out(None, None)
         info = ctl._decode_handler.last_launch_info()
-        # 0 = the timed kernel: keys straight into registers, slot ownership; 4 = its column-range twin (measured slower,
-        # not the default); forced generation 1 = scalar-load staging in the generic kernel
-        assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": {0: 3, 4: 4, 1: 0}[gen],
+        # 0 = the timed kernel: keys straight into registers; forced generation 1 = scalar-load staging in the generic kernel
+        assert info == {"keys_per_thread": 8, "waves": 8, "front_end_variant": {0: 3, 1: 0}[gen],
                         "specialised": gen != 1, "workgroups_per_head": 16, "n_seqs": 1}, info
         assert ctl.step_state.cpu().tolist()[:4] == [L, n_pages, PAGE, kv_table[-1]]
         assert np.array_equal(U16(scores[:, : n_pages - 1].cpu().numpy()), U16(e_est)), "page scores"
@@ -333,7 +325,6 @@ def test_cfg3_headline_on_the_timed_path(layout):
         outs[gen] = o
     ctl._decode_handler.set_front_end(0)
     assert torch.equal(outs[0], o_eager) and torch.equal(outs[1], o_eager)  # same slot split: same bits
-    assert not torch.equal(outs[4], o_eager)  # column ranges: another split (within 2e-3, asserted above)
     mmax, mmin = entries(ctl.metadata_cache.buf_layer(0)[ctl.metadata_indices.long()])
     assert torch.equal(mmax[:n_pages], kp.amax(1)) and torch.equal(mmin[:n_pages], kp.amin(1))
     kk, vv = entries(ctl.kv_cache.buf_layer(0)[torch.tensor(kv_table[-1:], device=DEV)])

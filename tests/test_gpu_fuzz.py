@@ -65,6 +65,7 @@ def test_random_shape_chain_matches_oracle(case):
     o2 = qu.decode_topk_sparse_attn(qd, est, ctl, 0, write_topk=True)
     assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
     assert torch.equal(o, o2)
+    eager_waves = ctl._decode_handler.last_launch_info()["waves"]
     ctl.end_forward()
     # state-driven launches on the same cache: rewind one token on the device state and decode it again
     # (append of the same key/value is idempotent on the pools)
@@ -81,25 +82,22 @@ def test_random_shape_chain_matches_oracle(case):
         for gen, scores in ((2, qu.score_scratch(ctl).zero_()),
                             (3, qu.score_scratch(ctl).zero_()),  # second generation with its histogram pre-filter
                             (1, torch.zeros(Hq, ctl.max_pages | 1, dtype=torch.float16, device="cuda:0")),
-                            (4, qu.score_scratch(ctl).zero_()),  # column-range ownership (csrc/topk_colrange.cuh)
+                            ("tiles", qu.score_scratch(ctl).zero_()),  # tile maxima from the estimate (sparse_decode_tiles_body)
                             (0, qu.score_scratch(ctl).zero_())):
-            ctl._decode_handler.set_front_end(gen)
+            tiles = gen == "tiles" and page == 16 and budget - 1 <= 256
+            ctl._decode_handler.set_front_end(gen if isinstance(gen, int) else 0)
             ctl.step_state.copy_(torch.tensor(st, dtype=torch.int32))
             sel_i = torch.full((1, Hq, budget - 1), -1, dtype=torch.int32, device="cuda:0")
             sel_v = torch.zeros(1, Hq, budget - 1, dtype=torch.float16, device="cuda:0")
             ctl._decode_handler.set_selection_out(sel_v, sel_i)
             qu.step_advance_dyn(ctl)
-            o3 = qu.decode_layer_dyn(qd, cuda(k[L - 1:L]), cuda(v[L - 1:L]), ctl, 0, scores)
+            o3 = qu.decode_layer_dyn(qd, cuda(k[L - 1:L]), cuda(v[L - 1:L]), ctl, 0, scores, tiles=tiles)
             ctl._decode_handler.set_selection_out(None, None)
             assert np.array_equal(sel_i[0].cpu().numpy(), ei) and np.array_equal(U16(sel_v[0].cpu().numpy()), U16(ev))
             assert np.array_equal(U16(scores[:, :n_out].cpu().numpy()), U16(e_est))
             assert pools_match(ctl, kv_o, meta_o, L)
             np.testing.assert_allclose(o3.cpu().numpy().astype(np.float32), eo.astype(np.float32), rtol=2e-3, atol=2e-3)
             info = ctl._decode_handler.last_launch_info()
-            if gen == 4 and page == 16 and info["workgroups_per_head"] > 1:
-                # the forced column-range launch really ran (8-wave workgroups); its workgroups fold a head's pages in a
-                # different split than the slot-ownership launches, so only the oracle bound above applies to the output
-                assert info["front_end_variant"] == 4 and info["waves"] == 8 and info["specialised"]
-            else:
-                assert info["front_end_variant"] in (0, 1, 2, 3)
-                assert torch.equal(o3, o)  # same pages in the same order as the eager fused launch: same bits
+            assert info["front_end_variant"] == 8 if tiles else info["front_end_variant"] in (0, 1, 2, 3), info
+            if info["waves"] == eager_waves:  # same pages in the same order, dealt over the same waves: same bits as the
+                assert torch.equal(o3, o)      # eager fused launch (the tiles launch always runs 8-wave workgroups)

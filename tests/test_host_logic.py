@@ -398,7 +398,14 @@ def test_round3_entry_points_validate_arguments_without_gpu():
     assert lib.quest_decode_handler_create(ctypes.byref(h), 0) == 0
     assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, one, 10, 4, None, None, None, None) == -1
     assert lib.quest_decode_forward_fused_topk_strided(h, one, one, kv, 32, None, 10, 16, None, None, None, None) == -1
-    assert lib.quest_decode_set_front_end(h, 6) == 0 and lib.quest_decode_set_front_end(h, 7) == -1
+    assert lib.quest_decode_set_front_end(h, 3) == 0 and lib.quest_decode_set_front_end(h, 4) == -1  # (4-6: removed in round 5)
+    assert lib.quest_decode_set_front_end(h, 0) == 0
+    # round-5 entries: the tiles launches and the one-launch layer refuse malformed arguments before anything runs
+    assert lib.quest_append_estimate_tiles_dyn(one, one, kv, one, one, 32, 16, 10, 0, kv, one, None) == -1   # no offset
+    assert lib.quest_append_estimate_tiles_dyn(one, one, kv, one, one, 32, 16, 10, 16, kv, one, None) == -1  # stride has no room
+    assert lib.quest_decode_forward_fused_topk_tiles_dyn(h, one, one, kv, 32, one, 32, 10, 0, one, None, None) == -1
+    assert lib.quest_decode_layer_fused_batched(h, None, one, kv, one, one, kv, 32, 10, one, b1, None, 0, None, None) == -1
+    assert lib.quest_decode_layer_fused_batched(h, one, one, kv, one, one, kv, 32, 10, one, b1, None, 0, None, None) == -3  # no plan
     info = (ctypes.c_uint32 * 6)()
     assert lib.quest_decode_last_launch_info(h, info) == 0 and list(info) == [0] * 6  # nothing launched yet
     assert lib.quest_decode_last_launch_info(None, info) == -1
