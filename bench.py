@@ -622,7 +622,8 @@ def pmc_traffic(a, n_local, kernel_name=None):
 def add_traffic(roof, a, n_local):
     """roofline.traffic + its source + the fraction of the HBM peak the PMC bytes amount to (next to `frac`, which is
     algorithmic bytes / time)."""
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(a, n_local, roof.get("kernel_name"))
+    roof["traffic"], roof["traffic_source"] = (pmc_traffic(a, n_local, roof["kernel_name"]) if roof.get("kernel_name")
+                                               else (None, None))  # no named instantiation: nothing to look up
     roof["frac_hbm_pmc"] = (roof["traffic"] / (roof["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
                             if roof["traffic"] and roof.get("launch_us") else None)
     if roof["traffic"] and roof["traffic"] < 0.95 * roof.get("algorithmic_bytes_per_launch", 0):
@@ -642,16 +643,33 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
     n_local = a.seqs_per_gpu
     batched = (n_local > 1 and a.multi_seq_mode == "batched" and a.mode == "graph" and a.skip_layers == 0
                and not a.unfused)
-    if stub:
-        ws = [StubWorkload(a)]
-    elif batched and a.seq_groups > 1:
-        assert n_local % a.seq_groups == 0, "--seq-groups must divide the sequences per GPU"
-        per = n_local // a.seq_groups
-        ws = [BatchedWorkload(a, dev, per, seq_id0=i * per) for i in range(a.seq_groups)]
-    elif batched:
-        ws = [BatchedWorkload(a, dev, n_local)]
-    else:
-        ws = [Workload(a, dev, i) for i in range(n_local)]
+    build_error = None
+    try:
+        if stub:
+            if os.environ.get("QUEST_BENCH_STUB_BUILD_FAIL") == f"{rank}:{int(side)}":
+                raise MemoryError("stub: this rank cannot build its workload")  # tests/test_parallel_gloo.py
+            ws = [StubWorkload(a)]
+        elif batched and a.seq_groups > 1:
+            assert n_local % a.seq_groups == 0, "--seq-groups must divide the sequences per GPU"
+            per = n_local // a.seq_groups
+            ws = [BatchedWorkload(a, dev, per, seq_id0=i * per) for i in range(a.seq_groups)]
+        elif batched:
+            ws = [BatchedWorkload(a, dev, n_local)]
+        else:
+            ws = [Workload(a, dev, i) for i in range(n_local)]
+    except Exception as exc:  # most likely memory: the pools of a side configuration
+        if dist is None:
+            raise
+        build_error = exc
+    if dist is not None:
+        # every rank says whether it built its workload BEFORE any other collective of this measurement: a rank that failed
+        # would otherwise leave through its exception while its peers wait in the barrier / token gather below until the
+        # process-group timeout.  All ranks leave together, with the failing rank's message where it is known.
+        ok = torch.tensor([0 if build_error is not None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"rank {rank}: " + (f"{type(build_error).__name__}: {build_error}" if build_error is not None
+                                                    else "a peer rank failed to build its workload"))
     w = ws[0]
     streams = [torch.cuda.Stream() for _ in ws] if len(ws) > 1 else None
     sync()
@@ -779,10 +797,13 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
                 hd = ctl0._dense_handler
                 od = [w.q[l].clone() for l in range(a.layers)]
 
+                fused_append = [True]
+
                 def dense_launch(l):  # the timed step's launch: decode append folded into the group-shared attention
                     if not hd.append_forward_shared_dyn(w.k1[l], w.v1[l], ctl0.metadata_cache.buf_layer(l), ctl0.meta_table_full,
                                                         w.q[l], od[l], ctl0.kv_cache.buf_layer(l), ctl0.kv_table_full,
                                                         ctl0.step_state):
+                        fused_append[0] = False  # shapes outside the group-shared kernel: attention alone (the step appends separately)
                         hd.forward_shared_dyn(w.q[l], od[l], ctl0.kv_cache.buf_layer(l), ctl0.kv_table_full, ctl0.step_state)
 
                 t_op = time_kernel_loop(dense_launch, a.layers, 10)
@@ -790,11 +811,15 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
                 t_k = time_kernel_loop(dense_launch, a.layers, 10)
                 hd.set_skip_merge(False)
                 bpl_now = bytes_per_layer(argparse.Namespace(**{**vars(a), "seqlen": ctl0.kv_cache.seqlen}))
-                alg = bpl_now["dense"] + bpl_now["append"]
+                # what was launched decides the name and the bytes: with the append folded in, or (fallback) attention alone --
+                # then no instantiation of the group-shared kernel is claimed and no committed traffic figure is looked up
+                alg = bpl_now["dense"] + (bpl_now["append"] if fused_append[0] else 0)
                 ach = alg / (t_k * 1e-6) / 1e9
-                kname = f"shared_decode_kernel<{a.head_dim},{a.heads // a.kv_heads},4,true>"
-                out["roofline"] = {"bound": "hbm", "kernel": f"{kname} (full-KV decode with the decode append folded in, K/V read "
-                                   "once per kv head; the dominant kernel of the timed step, merge launch excluded)",
+                kname = f"shared_decode_kernel<{a.head_dim},{a.heads // a.kv_heads},4,true>" if fused_append[0] else None
+                out["roofline"] = {"bound": "hbm", "kernel": (f"{kname} (full-KV decode with the decode append folded in, K/V "
+                                   "read once per kv head; the dominant kernel of the timed step, merge launch excluded)"
+                                   if kname else "full-KV attention launch of the state-driven step (per-head-list kernel over "
+                                   "the one page table; the append is its own launch at this shape)"),
                                    "kernel_name": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
                                    "launch_us": t_k, "op_us_with_merge": t_op,
@@ -889,9 +914,17 @@ def main():
                            + (["--seqs-per-gpu", str(overrides["seqs_per_gpu"])] if "seqs_per_gpu" in overrides else []))
                 try:
                     full = measure(a2, dev, dist, world_seen, rank, stub, side=True)
-                except Exception as exc:  # the headline line must survive a side measurement that fails (e.g. memory)
+                except RuntimeError as exc:  # the headline line must survive a side measurement that fails (e.g. memory)
+                    # (under N > 1 a workload that cannot be built makes EVERY rank raise here, at the same point -- see
+                    # measure(): nobody is left inside a collective; any other exception leaves through the outer handler)
+                    if dist is not None and "failed to build its workload" not in str(exc) and not str(exc).startswith("rank "):
+                        raise
+                    if out is not None:
+                        out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    continue
+                except Exception as exc:
                     if dist is not None:
-                        raise  # the peers are inside collectives: leave through the outer handler
+                        raise  # the peers may be inside collectives: leave through the outer handler
                     out[name] = {"error": f"{type(exc).__name__}: {exc}"}
                     continue
                 if out is None:

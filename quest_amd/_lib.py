@@ -123,7 +123,13 @@ def verify_build(lib_path: str, src_root: str = None) -> None:
     with extra -D flags) skips the check -- the override is explicit."""
     from .build import library_hash, source_hash
 
-    have, want = library_hash(lib_path), source_hash(src_root)
+    try:
+        have, want = library_hash(lib_path), source_hash(src_root)
+    except OSError as exc:  # a deployment that ships the package + prebuilt library without csrc/ or include/
+        raise ImportError(
+            f"cannot check {lib_path} against its sources ({exc}): the check reads quest_amd/csrc/* and include/quest_hip.h "
+            "under the repository root (or under QUEST_SRC_ROOT).  Ship the sources with the package, point QUEST_SRC_ROOT at "
+            "them, or name the library explicitly with QUEST_HIP_LIB=<path> (which skips the check).") from exc
     if have != want:
         raise ImportError(
             f"{lib_path} is stale: it was built from sources with hash {have}, the tree has {want}. "

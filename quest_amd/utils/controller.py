@@ -262,7 +262,12 @@ class BatchedInferenceController:
         A sequence with fewer pages than its budget attends all of them."""
         if budgets is None:
             if self._graph_budget_ptr:
-                # a captured step reads the buffer: "no per-sequence budget" = the sentinel, in place
+                # a captured step reads the buffer: "no per-sequence budget" = the sentinel, in place.  The kernels clamp
+                # to the CAPTURED plan, so the constructor's budget can only be honoured if the plan covers it
+                if min(self._page_budget, self.max_pages) > self._graph_planned:
+                    raise RuntimeError(f"the constructor's budget ({self._page_budget} pages) exceeds the {self._graph_planned} "
+                                       "pages the captured plan was made for; call begin_graph_decode() (and re-capture) "
+                                       "after dropping the per-sequence budgets")
                 self._budget_buf.fill_(self.kNoBudget)
                 self._host_budgets = None
                 return

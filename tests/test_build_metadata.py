@@ -3,9 +3,15 @@ static LDS small enough for two 8-wave workgroups per CU next to the dynamic sta
 of regression round 4 hit while refactoring: a by-reference hand-over of the kernel parameters left a 32-byte slice of
 them in memory, the compiler "promoted" it to LDS (16 KiB per workgroup), one workgroup fit a CU instead of two and the
 headline launch took 24 us instead of 12 -- with every parity test green."""
+import os
+
 import pytest
 
 from quest_amd.build import LIB, kernel_metadata
+
+LLVM = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB) or not os.path.exists(os.path.join(LLVM, "llvm-readelf")),
+                                reason="needs the built library and the ROCm LLVM tools (llvm-objcopy / llvm-readelf)")
 
 
 @pytest.fixture(scope="module")
@@ -83,5 +89,10 @@ def test_import_refuses_a_library_built_from_other_sources(tmp_path):
     env.pop("QUEST_HIP_LIB", None)
     r = subprocess.run([sys.executable, "-c", "import quest_amd._lib"], env=env, capture_output=True, text=True, cwd=root)
     assert r.returncode != 0 and "stale" in r.stderr, r.stderr[-400:]
-    os.utime(os.path.join(root, "quest_amd", "csrc", "quest_common.cuh"))  # a newer file time alone is not a change
-    assert not build.needs_build()
+    # a newer file time alone is not a change (checked on a copy: the working tree is not touched)
+    shutil.copy(os.path.join(root, "quest_amd", "csrc", "decode_device.cuh"), tmp_path / "quest_amd" / "csrc" / "decode_device.cuh")
+    os.utime(tmp_path / "quest_amd" / "csrc" / "quest_common.cuh")
+    assert build.source_hash(str(tmp_path)) == build.source_hash() and not build.needs_build()
+    # a tree without its sources: an ImportError that says what to do, not a raw FileNotFoundError
+    with pytest.raises(ImportError, match="QUEST_SRC_ROOT"):
+        verify_build(LIB, str(tmp_path / "nowhere"))

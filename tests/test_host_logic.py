@@ -187,6 +187,20 @@ def test_batched_controller_budgets_and_graph_plan(monkeypatch):
     assert bc.topk_dout_buffer.shape == (3, 4, 4) and bc.topk_dindices_buffer.dtype == torch.int32
     assert bc._decode_handler.planned == [4]  # same budget: not re-planned
 
+    # a plan captured with per-sequence budgets BELOW the constructor's budget cannot serve "the constructor's
+    # budget for all" -- the kernels clamp to the captured plan: refused like a too-large list, until a re-plan
+    bc3 = ctl_mod.BatchedInferenceController(3, 1, 4, 128, 16, 5, 400, torch.float16, "cpu")
+    for c in bc3.seqs:
+        c.prepare_metadata(300)
+    bc3.enable_device_state()
+    bc3.set_page_budgets([3, 3, 3])
+    bc3.begin_graph_decode()
+    assert bc3._decode_handler.planned == [2]
+    with pytest.raises(RuntimeError, match="captured plan"):
+        bc3.set_page_budgets(None)
+    assert bc3.page_budgets.tolist() == [3, 3, 3]  # untouched: the captured graph keeps attending 3 pages, as reported
+    assert bc3.max_page_budget() == 3
+
     bc2 = ctl_mod.BatchedInferenceController(2, 1, 4, 128, 16, 5, 400, torch.float16, "cpu")
     for c in bc2.seqs:
         c.prepare_metadata(300)

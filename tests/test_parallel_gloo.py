@@ -116,6 +116,57 @@ def test_bench_default_headline_reports_configs4_side_measurement_under_n_ranks(
     assert "aggregate over all ranks" in side["note"]
 
 
+def test_bench_launcher_at_the_width_the_driver_uses_world_size_8():
+    """the launcher stub at world size 8 -- port handling, the poll loop over 8 children, the headline's
+    rendezvous and the side measurement's (every rank decodes configs[4]'s 8 sequences, 64 token ids gathered per step) at
+    the width of the driver's SCALE run.  CPU stub workload (gloo): no scaling figure, only the control flow."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["QUEST_BENCH_STUB"] = "1"
+    env["OMP_NUM_THREADS"] = "1"  # 8 ranks on the 8 cores of the build container
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--side-steps", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["world_size_seen"] == 8 and out["config"]["gpus_requested"] == 8
+    assert out["config"]["sequences_per_gpu"] == 1 and "side_error" not in out
+    assert abs(out["value"] - 8 * 1 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-6
+    side = out["cfg5_8seq_gqa"]
+    assert side["n_gpus"] == 8 and side["sequences_per_gpu"] == 8 and side["steps"] == 2
+    assert abs(side["tokens_per_s"] - 8 * 8 * 2 / (side["ms_per_step"] * 2e-3)) / side["tokens_per_s"] < 1e-6
+
+
+def test_bench_side_measurement_that_one_rank_cannot_build_leaves_every_rank_together():
+    """a rank that cannot build the side configuration's workload (memory) must not leave its peers inside the
+    side measurement's collectives: every rank learns it before the first collective, all skip the side object, the
+    headline line is printed with the error, exit code 0 -- promptly."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["QUEST_BENCH_STUB"] = "1"
+    env["QUEST_BENCH_STUB_BUILD_FAIL"] = "1:1"  # rank 1, in the side measurement
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--side-steps", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 60
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "error" in out["cfg5_8seq_gqa"] and "failed to build its workload" in out["cfg5_8seq_gqa"]["error"]
+
+
 def test_bench_launcher_returns_promptly_when_a_peer_dies_before_rendezvous():
     """Rank 1 exits (code 3) before init_process_group: the launcher must notice, terminate rank 0 (which would
     otherwise sit in the rendezvous until the process-group timeout), print one JSON error line and return non-zero
