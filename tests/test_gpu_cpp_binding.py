@@ -50,6 +50,11 @@ def test_every_op_of_the_binding_matches_the_python_shim(ext):
         ctl.prepare_metadata(L - 1)
         ctl.begin_forward(L - 1)
         mod.append_kv_cache_prefill(kc[:-1], vc[:-1], *args())
+        # prefill attention over the pages just written (bsk_ops.h:84-92): the whole prompt (causal), a 37-row chunk at the
+        # end of the cache (causal, masked) and one row (full attention) -- GQA, K/V not repeated
+        qp = cuda(inputs(21, L - 1, Hq, Hkv, D)[1][:, :1].repeat(Hq, axis=1))  # [L-1, Hq, D]
+        pre = [mod.prefill_with_paged_kv_cache(x, ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last, ctl.kv_cache.last_page_len,
+                                               True, ctl.layout, False, 1.0, 1e4) for x in (qp, qp[-37:], qp[-1:])]
         ctl.end_forward()
         ctl.prepare_metadata(1)
         ctl.begin_forward(1)
@@ -76,10 +81,22 @@ def test_every_op_of_the_binding_matches_the_python_shim(ext):
         table = torch.tensor(ctl.kv_cache.indicies, device=dev)
         mtable = torch.tensor(ctl.metadata_cache.indicies, device=dev)
         results.append(dict(rope_q=qr, rope_k=kr, kv=ctl.kv_cache.buf_layer(0)[table][:-1],
-                            meta=ctl.metadata_cache.buf_layer(0)[mtable][:-1], est=est, topk_v=dv, topk_i=di, o=o, rms=y))
+                            meta=ctl.metadata_cache.buf_layer(0)[mtable][:-1], est=est, topk_v=dv, topk_i=di, o=o, rms=y,
+                            prefill_whole=pre[0], prefill_chunk=pre[1], prefill_row=pre[2]))
     for key in results[0]:
         assert torch.equal(results[0][key], results[1][key]), f"C++ binding differs from quest_amd._kernels: {key}"
     assert torch.isfinite(results[1]["o"].float()).all() and results[1]["o"].abs().sum() > 0
+    # the prefill op itself against fp32 torch attention (causal over the cache of L - 1 tokens)
+    kf = cuda(k)[:L - 1].float().repeat_interleave(Hq // Hkv, dim=1)
+    vf = cuda(v)[:L - 1].float().repeat_interleave(Hq // Hkv, dim=1)
+    qf = cuda(inputs(21, L - 1, Hq, Hkv, D)[1][:, :1].repeat(Hq, axis=1)).float()
+    logits = torch.einsum("ihd,jhd->hij", qf, kf) / D ** 0.5
+    logits = logits.masked_fill(torch.triu(torch.ones(L - 1, L - 1, dtype=torch.bool, device=dev), 1), float("-inf"))
+    ref = torch.einsum("hij,jhd->ihd", torch.softmax(logits, -1), vf)
+    assert results[1]["prefill_whole"].shape == (L - 1, Hq, D)
+    torch.testing.assert_close(results[1]["prefill_whole"].float(), ref, rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(results[1]["prefill_chunk"].float(), ref[-37:], rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(results[1]["prefill_row"].float(), ref[-1:], rtol=5e-3, atol=5e-3)
 
 
 def test_binding_error_behaviour(ext):
