@@ -249,9 +249,26 @@ class BatchedInferenceController:
         self.topk_dout_buffer = self.topk_dindices_buffer = None
         self._planned = None
         self._graph_planned = 0       # budget begin_graph_decode planned for (0: no graph plan)
-        # decode_layer_batched: one launch per layer (csrc/layer_device.cuh) where the plan allows it.  With GQA the query
-        # heads of a group would each stream their kv head's metadata (re-reads the two-launch form does not have)
-        self.one_launch_layers = self.num_heads == self.num_kv_heads
+        # decode_layer_batched: one launch per layer (csrc/layer_device.cuh) where the plan allows it AND it pays: its grid
+        # is one workgroup per (sequence, head), each bound by what ONE CU moves, so it needs the chip filled in whole
+        # rounds -- measured at cfg-3 shapes, us per sequence-layer one / two launches: 5 sequences (160 workgroups on 256
+        # CUs) 13.27 / 13.01, 6: 12.03 / 12.47, 7: 11.64 / 11.96, 8: 11.15 / 11.60, 12 (1.5 per CU) 12.10 / 11.86, 16: 11.02 /
+        # 11.16 (profiles/r05_sweep_sequences_per_gpu_one_vs_two_launches.txt).  With GQA the query heads of a group would
+        # each stream their kv head's metadata (cfg 5: 68.9 vs 58.8 us per layer): two launches.
+        self.one_launch_layers = self.num_heads == self.num_kv_heads and self._fills_the_chip(n_seqs * num_heads, device)
+
+    @staticmethod
+    def _fills_the_chip(workgroups: int, device) -> bool:
+        """Does a grid of `workgroups` one-per-CU-sized workgroups use the chip's CUs in (nearly) whole rounds?"""
+        cus = 256  # MI355X
+        try:
+            dev = torch.device(device)
+            if dev.type == "cuda" and torch.cuda.is_available():
+                cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        except Exception:  # noqa: BLE001  (CPU-only host logic tests)
+            pass
+        rounds = -(-workgroups // cus)
+        return workgroups / (rounds * cus) >= (0.75 if rounds == 1 else 0.8)
 
     # ---- per-sequence page budgets + eager (host-planned) batched steps.  The reference keeps one controller and one
     # page budget per request and loops over requests in Python (controller.py:39-41, :80-129: five list -> tensor

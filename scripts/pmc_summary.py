@@ -19,7 +19,7 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("estimate_kernel", "sparse_decode_kernel", "shared_decode_kernel", "merge_states", "topk_kernel",
+    for key in ("layer_decode_kernel", "estimate_kernel", "sparse_decode_kernel", "shared_decode_kernel", "merge_states", "topk_kernel",
                 "append_decode", "append_prefill", "step_state_advance", "rope_kernel"):
         if key in name:
             i = name.find(key)
