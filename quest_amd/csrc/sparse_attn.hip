@@ -39,18 +39,21 @@ template <int D, int S_T, int FC, int NW, int VF = -1>
 __global__ __launch_bounds__(NW* kWave, (D >= 256 && NW >= 8) ? NW / 4 : NW / 2) void sparse_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
     QUEST_DECODE_HEAD_TAKE(p);
     uint32_t hq = blockIdx.y;
-    const uint32_t period = p.xcd_period & 255u, slow = p.xcd_period >> 8;
+    const uint32_t period = p.xcd_period & 255u, slow = (p.xcd_period >> 8) & 15u, group_l2 = p.xcd_period >> 12;
     if (period > 1) {
         hq = (hq % period) * (a_num_qo_heads / period) + hq / period;
     } else if (slow) {
-        // slow-class heads first (plan_decode): rows [0, Hq/4) serve the heads = slow - 1 mod 4, the rest follow in order
-        const uint32_t sr = slow - 1u, quarter = a_num_qo_heads >> 2;
-        if (hq < quarter) {
-            hq = 4u * hq + sr;
+        // slow-class kv heads first (plan_decode): the first quarter of the rows serves the kv heads = slow - 1 mod 4 (with
+        // all query heads of their groups), the rest follow in order
+        const uint32_t sr = slow - 1u, unit = hq >> group_l2, quarter = a_num_qo_heads >> (2u + group_l2);
+        uint32_t hk;
+        if (unit < quarter) {
+            hk = 4u * unit + sr;
         } else {
-            const uint32_t r = hq - quarter;
-            hq = 4u * (r / 3u) + ((sr + 1u + r % 3u) & 3u);
+            const uint32_t r = unit - quarter;
+            hk = 4u * (r / 3u) + ((sr + 1u + r % 3u) & 3u);
         }
+        hq = (hk << group_l2) + (hq & ((1u << group_l2) - 1u));
     }
     p.xcd_period = period;
     if constexpr (VF == 8) sparse_decode_tiles_body<D, NW>(p, blockIdx.x, hq, blockIdx.z, a_num_qo_heads);
@@ -727,10 +730,10 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         // Measured at cfg 3, same box, us per launch: 12.04 -> 11.82 (profiles/r05_ab_slow_class_heads_first.txt);
         // QUEST_SLOW_FIRST=0 keeps the plain order (A/B).  Same work per head, same bits.
         static const int slow_env = [] { const char* e = quest_tuning_env("QUEST_SLOW_FIRST"); return e ? atoi(e) : 1; }();
-        if (slow_env && p.xcd_period == 1 && p.group == 1 && kv.layout == QUEST_LAYOUT_NHD && kv.head_dim == 128 &&
-            num_qo_heads % 4u == 0 && batch.n_seqs == 1) {
-            const uint32_t c0 = (uint32_t)(((uintptr_t)kv.data >> 8) & 3u);  // class of head 0
-            p.xcd_period |= (1u + ((1u - c0) & 3u)) << 8;
+        if (slow_env && p.xcd_period == 1 && (p.group & (p.group - 1u)) == 0 && kv.layout == QUEST_LAYOUT_NHD &&
+            kv.head_dim == 128 && kv.num_heads % 4u == 0 && batch.n_seqs == 1) {
+            const uint32_t c0 = (uint32_t)(((uintptr_t)kv.data >> 8) & 3u);  // class of kv head 0
+            p.xcd_period |= (1u + ((1u - c0) & 3u)) << 8 | (uint32_t)__builtin_ctz(p.group) << 12;
         }
     }
     // fc > 0: capacity (keys per thread) of the fused top-k front end; 0 = page ids come from an index tensor
