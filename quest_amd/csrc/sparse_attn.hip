@@ -84,6 +84,10 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void layer_decode_kernel(QUEST_L
 // (append_decode_body's arithmetic, same bits); nobody else reads or writes those bytes during the launch.
 template <int D, int GS, int NW, bool APPEND = false>
 __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_DECODE_HEAD_PARAMS, DecodeParams p) {
+    // MHA (one query head per kv head: registers to spare): the next page's rows are requested before the current page is
+    // folded.  cfg 2: 14.35 -> 14.11 us per launch, 16.40 -> 16.20 per layer; the 32K dense launch 85.0 -> 84.4 us
+    // (profiles/r05_ab_dense_kernel_prefetch.txt).
+    constexpr bool PREFETCH = GS == 1;
     QUEST_DECODE_HEAD_TAKE(p);
     constexpr int LPR = D / kVec, R = kWave / LPR, S_T = 16, T = (S_T + R - 1) / R;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -144,16 +148,19 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
         }
     }
 
-    for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += NW) {
+    // request the K/V rows of slot s0
+    auto issue = [&](uint32_t s0, half8 (&k)[T], half8 (&v)[T]) {
         const int32_t pg = __builtin_amdgcn_readfirstlane(s0 < p.n_sel ? sv.indices[s0] : p.last_page_idx);
-        const int len = s0 < p.n_sel ? S_T : (int)p.last_page_len;
         const half_t* b0 = head_base + (size_t)pg * p.st.page;
-        half8 k[T], v[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             k[t] = ld8_stream(b0 + lane_off + t * step);
             v[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
         }
+    };
+    // fold the rows of slot s0 into the GS states
+    auto fold = [&](uint32_t s0, half8 (&k)[T], half8 (&v)[T]) {
+        const int len = s0 < p.n_sel ? S_T : (int)p.last_page_len;
         if constexpr (APPEND) {
             if (s0 >= p.n_sel) {  // wave-uniform: the current page -- its newest row is the token being decoded, which is
                                   // not in the pool yet (written after this loop): it comes from the inputs
@@ -199,6 +206,38 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
                 for (int i = 0; i < kVec; ++i) st[g].acc[i] = __builtin_fmaf(pr, vf[t][i], st[g].acc[i]);
             }
             st[g].m = m_new;
+        }
+    };
+    if constexpr (PREFETCH) {
+        // the next page's rows are requested before the current page is folded (two register sets, 16 loads in flight per
+        // lane); same pages in the same order per wave, hence the same bits.  Straight-line issue -> fold segments: a load
+        // under a branch would be waited for at the join
+        uint32_t s0 = slot_begin + wave;
+        if (s0 < slot_end) {
+            half8 k0[T], v0[T], k1[T], v1[T];
+            issue(s0, k0, v0);
+            while (true) {
+                uint32_t s1 = s0 + NW;
+                if (s1 >= slot_end) {
+                    fold(s0, k0, v0);
+                    break;
+                }
+                issue(s1, k1, v1);
+                fold(s0, k0, v0);
+                s0 = s1 + NW;
+                if (s0 >= slot_end) {
+                    fold(s1, k1, v1);
+                    break;
+                }
+                issue(s0, k0, v0);
+                fold(s1, k1, v1);
+            }
+        }
+    } else {
+        for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += NW) {
+            half8 k[T], v[T];
+            issue(s0, k, v);
+            fold(s0, k, v);
         }
     }
 
