@@ -174,8 +174,10 @@ int quest_decode_forward_fused_topk(quest_decode_handler_t* h, const void* q, vo
 /* The same with a row stride for `scores` (elements; 0 = n_scores).  The reference's score tensor is a contiguous
  * [num_qo_heads][pages - 1] (quest/utils/__init__.py:171-205), whose rows are only 2-byte aligned; rows padded to a
  * multiple of 8 columns (16 bytes: quest_append_estimate_strided writes them) let the front end fetch a thread's
- * scores with one vector load and are REQUIRED beyond 4096 pages (QUEST_EUNSUPPORTED otherwise: callers then issue
- * quest_topk_filtering + quest_decode_forward). */
+ * scores with one vector load.  Both layouts are served in ONE launch (since round 5 also the reference's layout beyond 4096
+ * pages: every workgroup reads the 8-byte aligned stream below its row and skips the 0-3 leading columns of the previous
+ * row; up to QUEST_TOPK_MAX_ROW - 3 pages -- QUEST_EUNSUPPORTED beyond: callers then issue quest_topk_filtering +
+ * quest_decode_forward). */
 int quest_decode_forward_fused_topk_strided(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t paged_kv,
                                             uint32_t num_qo_heads, const void* scores, uint32_t n_scores,
                                             uint32_t score_stride, void* topk_val_out, int32_t* topk_idx_out, float* lse,

@@ -36,6 +36,8 @@ struct DecodeParams {
     uint32_t score_stride;  // row stride of `scores`
     uint32_t table_stride;  // batched launches (blockIdx.z = sequence): entries between page tables
     uint32_t stage_ids;     // fused front end: page ids staged in LDS next to the keys
+    uint32_t row_lead;      // second generation on score rows that are only 2-byte aligned: every workgroup rounds its row
+                            // pointer down to 8 bytes and skips the 0-3 leading columns that belong to the previous row
     uint32_t vec_front;     // fused front end: 0 = first generation (topk_select.cuh); 1 = the same, staging arrays fed by
                             // 8/16-byte granule loads; 3 = the same, each thread loads its OWN cpt (4 or 8) columns and
                             // page ids straight into registers (no LDS staging); 2 = second generation
@@ -74,19 +76,20 @@ struct DecodeParams {
 };
 
 // leading scalar kernel arguments (preloaded into SGPRs at wave launch) and their hand-over to the struct; a_pack =
-// vec_front | cpt << 4 | stage_ids << 12 | xcd_period << 16 (one dword, so that the query-head count fits as well:
+// vec_front | cpt << 4 | stage_ids << 12 | row_lead << 13 | xcd_period << 16 (one dword, so that the query-head count fits as well:
 // gridDim.y would be an s_load of the hidden arguments in front of the score-row address)
 #define QUEST_DECODE_HEAD_PARAMS                                                                                        \
     const half_t *a_q, const int32_t *a_indices, const uint16_t *a_scores, const quest_step_state_t *a_state,           \
         uint32_t a_n_scores, uint32_t a_score_stride, uint32_t a_table_stride, uint32_t a_pack, uint32_t a_num_qo_heads
 #define QUEST_DECODE_HEAD_ARGS(p, num_qo_heads)                                                  \
     (p).q, (p).indices, (p).scores, (p).state, (p).n_scores, (p).score_stride, (p).table_stride, \
-        ((p).vec_front | (p).cpt << 4 | ((p).stage_ids ? 1u : 0u) << 12 | (p).xcd_period << 16), (uint32_t)(num_qo_heads)
+        ((p).vec_front | (p).cpt << 4 | ((p).stage_ids ? 1u : 0u) << 12 | ((p).row_lead ? 1u : 0u) << 13 | (p).xcd_period << 16), (uint32_t)(num_qo_heads)
 #define QUEST_DECODE_HEAD_TAKE(p)                                                                                    \
     do {                                                                                                             \
         (p).q = a_q, (p).indices = a_indices, (p).scores = a_scores, (p).state = a_state, (p).n_scores = a_n_scores; \
         (p).score_stride = a_score_stride, (p).table_stride = a_table_stride;                                        \
         (p).vec_front = a_pack & 15u, (p).cpt = (a_pack >> 4) & 255u, (p).stage_ids = (a_pack >> 12) & 1u;           \
+        (p).row_lead = (a_pack >> 13) & 1u;                                                                          \
         (p).xcd_period = a_pack >> 16;                                                                               \
     } while (0)
 
@@ -491,6 +494,8 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
         __shared__ uint32_t s_bm[2][kBmWords];
         extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
         const uint16_t* srow = sv.scores + (size_t)hq * p.score_stride;
+        // (second generation on 2-byte aligned rows: the aligned stream below the row, see topk_bitmap.cuh)
+        const uint32_t lead = p.row_lead ? (uint32_t)((reinterpret_cast<uintptr_t>(srow) >> 1) & 3u) : 0u;
         Fe2Raw<fe2_has_ids(FC)> raw[FC / 4];
         // live lengths of a state-driven launch: ONE scalar load (n_pages, last page's length and id are adjacent),
         // issued before the vector loads below and consumed after them
@@ -531,7 +536,7 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             }
             fe2_clear<NT>(sm);
         } else if (vec_front) {  // loads first: their addresses depend on the capacity only, not on the state below
-            fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap, raw);
+            fe2_issue<NT, FC / 4, fe2_has_ids(FC)>(srow - lead, sv.indices, n_cap + 1u, p.stage_ids != 0, n_cap + lead, raw);
             fe2_clear<NT>(sm);
         }
         // the per-sequence budget of a batched launch (from q's first bytes when there is none): requested here, after the
@@ -554,13 +559,14 @@ __device__ __forceinline__ void sparse_decode_body(DecodeParams p, const uint32_
             const bool ids_staged = p.stage_ids && fe2_has_ids(FC) && vec_front == 2;
             uint16_t* val_row = p.sel_val_out ? p.sel_val_out + out_row : nullptr;
             int32_t* idx_row_out = p.sel_idx_out ? p.sel_idx_out + out_row : nullptr;
-            fe2_select<NT, FC>(sm, s_bm, raw, srow, sv.indices,
-                               ids_staged ? reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset) : nullptr, n_cap, n,
-                               p.n_sel, slot_begin, slot_end, s_sel, val_row, idx_row_out, p.fe2_prefilter != 0, QUEST_TL_SUB);
+            fe2_select<NT, FC>(sm, s_bm, raw, srow - lead, sv.indices - lead,
+                               ids_staged ? reinterpret_cast<int32_t*>(fe_dyn + p.ids_lds_offset) : nullptr, n_cap + lead, n,
+                               p.n_sel, slot_begin, slot_end, s_sel, val_row, idx_row_out, p.fe2_prefilter != 0, QUEST_TL_SUB,
+                               lead);
             QUEST_STAMP(4);
             __syncthreads();
-            if (!ids_staged) {  // block-uniform: columns -> pages, one parallel round trip
-                fe2_resolve_pages(srow, sv.indices, slot_begin, slot_end, p.n_sel, s_sel, val_row, idx_row_out);
+            if (!ids_staged) {  // block-uniform: columns (positions of the aligned stream) -> pages, one parallel round trip
+                fe2_resolve_pages(srow - lead, sv.indices - lead, slot_begin, slot_end, p.n_sel, s_sel, val_row, idx_row_out);
                 __syncthreads();
             }
             QUEST_STAMP(5);

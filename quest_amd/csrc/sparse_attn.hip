@@ -720,14 +720,22 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         table_vec = table_aligned;
         rows_aligned = aligned;
         int gen = 1;
+        bool lead_rows = false;
         if (aligned) {
             if (forced == 2 || forced == 3 || (forced == 0 && n_scores > 4096u)) gen = 2;
+        } else if (n_scores > 4096u && n_scores + 3u <= QUEST_TOPK_MAX_ROW && forced != 1) {  // (the bitmaps cover positions)
+            // the reference's own score layout beyond 4096 pages (contiguous [Hq][pages - 1] rows: 2-byte aligned,
+            // quest/utils/__init__.py:194): the second generation on the aligned stream BELOW each row (row_lead) -- one
+            // fused launch where rounds 2-4 needed topk_filtering + forward
+            gen = 2;
+            lead_rows = true;
         }
         if (gen != 1) {
             p.vec_front = 2;
             p.ids_lds_offset = 0;  // no key staging
-            // page ids are staged with 16-byte loads: the table(s) must be 16-byte aligned
-            if (!table_aligned) p.stage_ids = 0;
+            p.row_lead = lead_rows ? 1u : 0u;
+            // page ids are staged with 16-byte loads: the table(s) must be 16-byte aligned (and columns = positions)
+            if (!table_aligned || lead_rows) p.stage_ids = 0;
             // (gen 2 stages ids only in the instantiations with <= 16 keys per thread: rows <= 4096 columns)
             // pre-filter of the histogram: pays where a thread holds many keys (rows beyond 4096 columns); QUEST_FE2_PREFILTER=0
             // turns it off, =2 turns it on for every second-generation launch (tuning, tests)
@@ -790,7 +798,7 @@ static int plan_decode(quest_decode_handler_t* h, const void* q, void* o, quest_
         // attention part runs the same with 4 or 8 waves.  Measured at cfg 3: 15.2 vs 15.8 us.
         if (kv.page_size == 16 && n_scores > 4u * 4u * kWave) waves = 8;
         const uint32_t nt = (kv.page_size == 16 ? waves : 4u) * kWave;
-        const uint32_t per_thread = (n_scores + nt - 1) / nt;
+        const uint32_t per_thread = (n_scores + (p.row_lead ? 3u : 0u) + nt - 1) / nt;  // (+ the skipped leading columns)
         // (24: rows of 8193-12288 columns at 512 threads -- cfg 4's capacity of ~8320 pages needs 17 keys per thread; the
         // 32-key instantiation carries two more dead load / histogram / bitmap rounds in every unrolled phase.
         // QUEST_FC24=0 takes the 32-key instantiation instead: A/B)

@@ -13,8 +13,10 @@
 //     this workgroup's chunk are ever materialised.
 //
 // Barriers in the common case (row spans < 2048 key values): range, histogram, bitmaps, page list = 4 (the first
-// generation: 7).  Requires score rows whose base and stride are 8-byte aligned and readable up to the next
-// multiple of 4 columns; callers fall back to topk_select.cuh otherwise.
+// generation: 7).  Wants score rows whose base and stride are 8-byte aligned and readable up to the next multiple of 4
+// columns.  Rows that are only 2-byte aligned (the reference's contiguous [Hq][pages - 1] score tensor) are served through
+// `lead`: the caller passes the row pointer rounded DOWN to 8 bytes and the number of columns it skipped (0-3); position p
+// of that aligned stream is column p - lead, positions below `lead` belong to the previous row and are never live.
 #pragma once
 #include "topk_select.cuh"
 
@@ -160,7 +162,9 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
                                            const uint16_t* srow, const int32_t* table, int32_t* ids_s, uint32_t n_cap,
                                            uint32_t n, uint32_t k, uint32_t slot_begin, uint32_t slot_end, int32_t* s_sel,
                                            uint16_t* sel_val_row, int32_t* sel_idx_row, bool prefilter,
-                                           long long* sub = nullptr) {
+                                           long long* sub = nullptr, const uint32_t lead = 0) {
+    // srow / table / n_cap are those of the ALIGNED stream when lead > 0 (srow and table moved down by `lead` entries,
+    // n_cap grown by it); n stays the live COLUMN count: position c is live iff c - lead < n (unsigned: c < lead wraps)
     constexpr int RMAX = FC / 4, NWV = NT / kWave;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,13 +180,13 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
             const uint32_t c0 = 4u * (tid + (uint32_t)r * NT);
             key2[2 * r] = half_key2(raw[r].k.x);
             key2[2 * r + 1] = half_key2(raw[r].k.y);
-            if (c0 + 3u < n) {  // whole granule inside the row (all but one granule of the row)
+            if (c0 >= lead && c0 + 3u - lead < n) {  // whole granule inside the row (all but one or two granules of the row)
                 pmax = pk_max_u16(pmax, pk_max_u16(key2[2 * r], key2[2 * r + 1]));
                 pmin = pk_min_u16(pmin, pk_min_u16(key2[2 * r], key2[2 * r + 1]));
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (c0 + i < n) {
+                    if (c0 + i - lead < n) {
                         const uint32_t kk = key_at(key2, 4 * r + i);
                         pmax = pk_max_u16(pmax, kk);                   // low half only
                         pmin = pk_min_u16(pmin, kk | 0xffff0000u);
@@ -243,7 +247,7 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t kk = key_at(key2, 4 * r + i);
-                if (c0 + i < n && kk >= kmin) atomicAdd(&sm.hist1[(kk - kmin) >> shift], 1u);
+                if (c0 + i - lead < n && kk >= kmin) atomicAdd(&sm.hist1[(kk - kmin) >> shift], 1u);
             }
         }
     QUEST_SUBSTAMP(2);
@@ -305,7 +309,7 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const uint32_t kk = key_at(key2, 4 * r + i);
-                        if (c0 + i < n && kk >= kmin && ((kk - kmin) >> shift) == thr_bin)
+                        if (c0 + i - lead < n && kk >= kmin && ((kk - kmin) >> shift) == thr_bin)
                             atomicAdd(&sm.hist2[(kk - kmin) & low_mask], 1u);
                     }
                 }
@@ -329,7 +333,7 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
             uint32_t ng = 0, ne = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool in = c0 + i < n;
+                const bool in = c0 + i - lead < n;
                 const uint32_t kk = key_at(key2, 4 * r + i);
                 ng |= (uint32_t)(in && kk > T) << i;
                 ne |= (uint32_t)(in && kk == T) << i;
@@ -347,7 +351,7 @@ __device__ __forceinline__ void fe2_select(TopkSmem<NT>& sm, uint32_t (&bm)[2][k
     // ---- ranks: a wave scans the whole bitmap (a few words per lane) and extracts the slots of this workgroup's
     // chunk from the lanes it is responsible for (redundant form: lane % waves == wave; solo form: wave 0, all lanes)
     if (kFe2Solo && wave != 0) return;
-    const uint32_t W = (n + 31u) >> 5, wpl = (W + 63u) >> 6;  // words per lane, <= 8
+    const uint32_t W = (n + lead + 31u) >> 5, wpl = (W + 63u) >> 6;  // words per lane, <= 8
     uint32_t sel[8], eqc = 0;
     uint32_t eqw[8];
 #pragma unroll

@@ -76,8 +76,8 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     ctl.begin_forward(1)
     assert ctl.need_estimate() and ctl.inference_page_budget == B
     # ---- eager route through the drop-in API: fused append+estimate into 16-byte aligned score rows, then top-k +
-    # attention in ONE launch (the second-generation front end serves the 8191-column rows; the reference's contiguous
-    # [Hq, 8191] layout -- odd row stride -- takes two launches, checked below)
+    # attention in ONE launch (the second-generation front end serves the 8191-column rows; so it does, since round 5, on
+    # the reference's contiguous [Hq, 8191] layout -- odd row stride, 2-byte aligned rows --, checked below)
     est = qu.decode_append_estimate(q, k[-1:], v[-1:], ctl, 0)
     assert est.shape == (Hq, n_pages - 1) and est.stride(0) % 8 == 0
     kp = k.view(n_pages, PAGE, Hkv, D)
@@ -97,11 +97,24 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
                                                   ctl.kv_cache.last_page_len, ctl.kv_last_page_idx), "fused launch refused"
     assert torch.equal(o_chk, o)
     est_ref_layout = est.contiguous()  # the reference's layout: rows of 8191 fp16, 2-byte aligned
-    assert not ctl._decode_handler.forward_fused_topk(q, o_chk, ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last,
+    assert est_ref_layout.stride(0) == n_pages - 1 and est_ref_layout.stride(0) % 4 != 0
+    # round 5: also ONE fused launch (second generation on the aligned stream below each row): same slots, same bits
+    o_ref_layout = torch.empty_like(q)
+    tv = torch.zeros(Hq, B - 1, dtype=torch.float16, device=DEV)
+    ti = torch.full((Hq, B - 1), -1, dtype=torch.int32, device=DEV)
+    assert ctl._decode_handler.forward_fused_topk(q, o_ref_layout, ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last,
+                                                  est_ref_layout, tv, ti, ctl.kv_cache.last_page_len, ctl.kv_last_page_idx)
+    info = ctl._decode_handler.last_launch_info()
+    assert (info["front_end_variant"], info["waves"]) == (2, 8), info
+    assert np.array_equal(ti.cpu().numpy(), ei) and np.array_equal(U16(tv.cpu().numpy()), U16(ev))
+    assert torch.equal(o_ref_layout, o)
+    ctl.topk_dindices_buffer.fill_(-1)
+    ctl._decode_handler.set_front_end(1)  # first generation only: refuses rows beyond 4096 pages -> the reference's own op
+    assert not ctl._decode_handler.forward_fused_topk(q, o_chk, ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last,  # sequence
                                                       est_ref_layout, None, None, ctl.kv_cache.last_page_len,
                                                       ctl.kv_last_page_idx)
-    ctl.topk_dindices_buffer.fill_(-1)
     o_two = qu.decode_topk_sparse_attn(q, est_ref_layout, ctl, 0)  # stand-alone top-k + index-list attention
+    ctl._decode_handler.set_front_end(0)
     assert np.array_equal(ctl.topk_dindices_buffer.cpu().numpy(), ei)
     torch.testing.assert_close(o_two.float(), o.float(), rtol=2e-3, atol=2e-3)
     ctl.end_forward()

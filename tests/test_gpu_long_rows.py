@@ -77,7 +77,14 @@ def test_long_score_rows_select_the_oracles_pages(n_pages, k, kind):
     kv_o, _ = oracle_pools(ctl, kc.cpu().numpy(), vc.cpu().numpy())
     eo, _ = oracle.sparse_attn(q.cpu().numpy(), kv_o, ei, k, int(table[-1]), kv_o.last_page_len)
     h = ctl._decode_handler
-    for gen, want in ((0, 2), (2, 2), (3, 2)):
+    # rows padded to 16 bytes (what decode_append_estimate writes), then the reference's own layout: contiguous [Hq, n]
+    # rows, 2-byte aligned (round 5: the second generation reads the aligned stream below each row)
+    layouts = [("padded", scores)]
+    if n % 4 and n + 3 <= 16384:  # (the row + its up to 3 skipped leading columns must fit the 16384-position bitmaps)
+        ref_layout = scores.contiguous()
+        assert any((ref_layout[hh].data_ptr() % 8) != 0 for hh in range(Hq))
+        layouts.append(("reference", ref_layout))
+    for (lname, scores), (gen, want) in [(lay, gw) for lay in layouts for gw in ((0, 2), (2, 2), (3, 2))]:
         h.set_front_end(gen)
         val = torch.zeros(Hq, k, dtype=torch.float16, device=dev)
         idx = torch.full((Hq, k), -1, dtype=torch.int32, device=dev)
@@ -86,8 +93,8 @@ def test_long_score_rows_select_the_oracles_pages(n_pages, k, kind):
                                     ctl.kv_cache.last_page_len, ctl.kv_last_page_idx)
         info = h.last_launch_info()
         assert info["front_end_variant"] == want and info["waves"] == 8 and info["specialised"], (gen, info)
-        assert np.array_equal(idx.cpu().numpy(), ei), f"front end {gen}: page ids"
-        assert np.array_equal(U16(val.cpu().numpy()), U16(ev)), f"front end {gen}: values"
+        assert np.array_equal(idx.cpu().numpy(), ei), f"{lname} rows, front end {gen}: page ids"
+        assert np.array_equal(U16(val.cpu().numpy()), U16(ev)), f"{lname} rows, front end {gen}: values"
         np.testing.assert_allclose(o.cpu().numpy().astype(np.float32), eo.astype(np.float32), rtol=2e-3, atol=2e-3)
     h.set_front_end(0)
     ctl.end_forward()
