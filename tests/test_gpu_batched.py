@@ -420,7 +420,7 @@ def test_one_launch_layer_equals_two_launches(Hq, Hkv, layout, D, B, lens, budge
     import quest_amd.utils as qu
 
     dev = torch.device("cuda:0")
-    layers, steps, n = 2, 40, len(lens)
+    layers, steps, n = 2, int(os.environ.get("QUEST_SOAK_STEPS", "40")), len(lens)  # soak: QUEST_SOAK_STEPS=400
     # a capacity beyond 1024 pages: the two-launch form then gathers with 8-wave workgroups like the one-launch kernel (a
     # head's pages are dealt over the waves, so another wave count is another fp32 fold order)
     cap = 16 * 1040
