@@ -418,6 +418,21 @@ int quest_rms_norm_forward(const void* input, const void* weight, void* output, 
                            uint32_t cols, float epsilon, quest_stream_t stream);
 
 /*
+ * prefill_with_paged_kv_cache (bsk_ops.h:78-86, batch_prefill.cu:27-117 -> BatchPrefillWithPagedKVCache,
+ * kernels/include/prefill/prefill.cuh:1008-1119, kernel :688-882).  q, o: [n_q][num_qo_heads][head_dim] fp16; the
+ * sequence's K/V (the n_q new tokens included: append_kv_cache_prefill ran before, utils/__init__.py:127-170) are the
+ * n_pages_host pages kv.indices lists, the last one holding kv.last_page_len tokens.  Row i attends the keys
+ * 0 .. kv_len - n_q + i when `causal`, every key otherwise; no rotary (RotaryMode::kNone, batch_prefill.cu:101),
+ * softmax scale 1/sqrt(head_dim).  GQA: num_qo_heads a multiple of kv.num_heads, query head h reads kv head
+ * h / (num_qo_heads / kv.num_heads).  head_dim 128, any page_size, both layouts; QUEST_EUNSUPPORTED otherwise;
+ * n_q > kv_len is QUEST_EINVAL (the reference assumes kv_len >= qo_len, test_prefill_attention.py:53-54).
+ * MFMA flash kernel (csrc/prefill.hip): 128 query rows per workgroup, 64-key tiles, nothing but o is written.
+ */
+int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_t n_q, uint32_t num_qo_heads,
+                                      quest_paged_kv_t kv, uint32_t n_pages_host, int causal,
+                                      quest_stream_t stream);
+
+/*
  * Decode-token projections of a Llama decoder layer around the attention path, fused (EXTENSION; csrc/decode_layer.hip).
  * The reference leaves them to cuBLAS + PyTorch kernels: RMSNorm (quest/ops/csrc/rms_norm.cu:82-213 via
  * quest/models/llama.py:72), q/k/v projections + RoPE (QuestAttention.py:64-70, decode_page.cuh:644-728), o_proj (:118),

@@ -6,6 +6,9 @@ against fixtures produced by the reference's own functions:
 * ``page_scores``      <- quest/tests/test_estimate.py:17-75 (``_ref_cpu_estimate``)
 * ``sparse_decode``    <- quest/tests/test_approx_attention.py:17-110 (``_ref_self_approx_attention``)
 * ``dense_decode``     <- quest/tests/test_decode_attention.py:17-44 (``_ref_self_attention``)
+* ``prefill_attention`` <- quest/tests/test_prefill_attention.py:17-44 (``_ref_self_attention``: bottom-right causal mask
+  ``tril(diagonal=kv_len - qo_len)``), in fp32 or fp64 so that it can serve as the checker at a tighter bar than the
+  reference's own fp16 arithmetic; pinned against fixtures of the reference function (tests/golden/prefill_ref_golden.npz)
 
 Like the reference's eager path it materialises the full ``[H, 1, L]`` logits and
 masks them, so its cost does not shrink with the page budget.  Layout of all
@@ -83,3 +86,22 @@ def sparse_decode(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, page_size: 
     probs = torch.softmax(logits, dim=-1, dtype=torch.float32).to(q.dtype)
     o = torch.matmul(probs, vh).transpose(0, 1)
     return o, sel.to(torch.int32)
+
+
+def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = True,
+                      dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Attention of ``qo_len`` query rows ``[qo_len, Hq, D]`` over ``kv_len >= qo_len`` cached tokens ``[kv_len, Hkv, D]``;
+    row i sees keys ``0 .. kv_len - qo_len + i`` when ``causal`` (test_prefill_attention.py:35-36).  GQA: query head h
+    reads kv head ``h // (Hq // Hkv)`` (evaluation/quest_attention.py:139-184's repeat_kv).  Returns ``[qo_len, Hq, D]``
+    in ``dtype``."""
+    qo_len, Hq, D = q.shape
+    kv_len, Hkv, _ = k.shape
+    assert kv_len >= qo_len and Hq % Hkv == 0
+    qh = q.to(dtype).transpose(0, 1)
+    kh = k.to(dtype).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)
+    vh = v.to(dtype).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)
+    logits = torch.matmul(qh, kh.transpose(1, 2)) / math.sqrt(D)  # [Hq, qo_len, kv_len]
+    if causal:
+        keep = torch.ones(qo_len, kv_len, dtype=torch.bool, device=q.device).tril(diagonal=kv_len - qo_len)
+        logits = logits.masked_fill(~keep, float("-inf"))
+    return torch.matmul(torch.softmax(logits, dim=-1), vh).transpose(0, 1)

@@ -606,46 +606,27 @@ def apply_rope_in_place_batched(q, k, rope_scale: float, rope_theta: float, stat
 
 def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, causal: bool, layout: int,
                                 allow_fp16_qk_reduction: bool, rope_scale: float, rope_theta: float):
-    """batch_prefill.cu:27-117 -- NOT on the sparse-decode path ("prefill via torch SDPA"): torch's fused
-    attention over the gathered pages.  Whole prompt (n == kv_len): ``is_causal`` -> the flash backend (0.5 ms for 32 heads
-    x 4096 x 128 on MI355X, 4.5 ms at 16K; the math backend this used to fall into: 6.3 ms at 4096 and heads x n x kv
-    scores in memory).  Chunked prefill (n < kv_len; query i sees keys 0 .. kv_len - n + i): a boolean mask through the
-    memory-efficient backend, in blocks of query rows that bound the mask.  GQA: ``enable_gqa`` (K/V are not repeated)."""
+    """batch_prefill.cu:27-117 -> BatchPrefillWithPagedKVCache (prefill.cuh:1008-1119): attention of the ``n`` new rows
+    of ``q`` over the sequence's pages, the new tokens included (row i sees keys 0 .. kv_len - n + i when ``causal``).
+    One launch of the MFMA flash kernel of csrc/prefill.hip straight over the page table: no gathered K/V copy, no mask
+    tensor, whole prompt and chunked prefill alike, GQA by head index.  ``allow_fp16_qk_reduction`` asks the reference
+    for fp16 score accumulation on RTX 4090 (utils/__init__.py:165); scores accumulate in fp32 here either way.  The
+    rotary arguments are unused, as in the reference (RotaryMode::kNone, batch_prefill.cu:101).  Returns a new tensor
+    (batch_prefill.cu:73)."""
     _check_input(q, "q")
     _check_input(kv_data, "kv_data")
     _check_input(kv_indices, "kv_indices")
     _check_dim(3, q, "q")
     _check_dim(5, kv_data, "kv_data")
-    page_size, num_kv_heads, head_dim = _pool_dims(kv_data, layout)
-    pages = kv_data.index_select(0, kv_indices.long())  # [n, 2, ...]
-    if layout == _NHD:
-        k = pages[:, 0].reshape(-1, num_kv_heads, head_dim)
-        v = pages[:, 1].reshape(-1, num_kv_heads, head_dim)
-    else:
-        k = pages[:, 0].transpose(1, 2).reshape(-1, num_kv_heads, head_dim)
-        v = pages[:, 1].transpose(1, 2).reshape(-1, num_kv_heads, head_dim)
-    kv_len = (kv_indices.size(0) - 1) * page_size + int(kv_last_page_len)
-    k, v = k[:kv_len], v[:kv_len]
-    n, hq = q.size(0), q.size(1)
-    gqa = hq != num_kv_heads
-    sdpa = torch.nn.functional.scaled_dot_product_attention
-    qh, kh, vh = q.transpose(0, 1).unsqueeze(0), k.transpose(0, 1).unsqueeze(0), v.transpose(0, 1).unsqueeze(0)
-    scale = 1.0 / math.sqrt(head_dim)
-    if not causal or n == 1:
-        o = sdpa(qh, kh, vh, scale=scale, enable_gqa=gqa)
-    elif n == kv_len:
-        o = sdpa(qh, kh, vh, is_causal=True, scale=scale, enable_gqa=gqa)
-    else:
-        o = torch.empty_like(qh)
-        blk = max(1, min(n, (1 << 28) // max(kv_len, 1)))  # <= 256 Mi mask elements per block
-        cols = torch.arange(kv_len, device=q.device)
-        for r0 in range(0, n, blk):
-            r1 = min(n, r0 + blk)
-            hi = kv_len - n + r1  # keys beyond the block's last row are masked for every row of it
-            limit = (kv_len - n + torch.arange(r0, r1, device=q.device)).unsqueeze(1)
-            o[:, :, r0:r1] = sdpa(qh[:, :, r0:r1], kh[:, :, :hi], vh[:, :, :hi], attn_mask=cols[:hi].unsqueeze(0) <= limit,
-                                  scale=scale, enable_gqa=gqa)
-    return o.squeeze(0).transpose(0, 1).contiguous()
+    _check_dim(1, kv_indices, "kv_indices")
+    _check_eq(kv_indices.dtype, torch.int32, "kv_indices.scalar_type(), torch::kInt32")
+    _check_eq(q.size(2), kv_data.size(4), "q.size(2), kv_data.size(4)")
+    _check_half(q, "BatchPrefillWithPagedKVCache")
+    o = torch.empty_like(q)
+    kv = _paged(kv_data, kv_indices, None, kv_last_page_len, 0, layout)
+    check(lib.quest_prefill_with_paged_kv_cache(q.data_ptr(), o.data_ptr(), q.size(0), q.size(1), kv, kv_indices.size(0),
+                                                1 if causal else 0, _stream(q)), "BatchPrefillWithPagedKVCache")
+    return o
 
 
 # ---------------------------------------------------------------- handler class

@@ -113,6 +113,7 @@ SIGNATURES = {
                                                       c_u32, c_u32, c_f32, c_f32, c_vp, c_u32, c_vp]),
     "quest_decode_batched_plan": (ctypes.c_int, [c_u32, c_u32, c_u32, ctypes.c_int, c_vp]),
     "quest_rms_norm_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_f32, c_vp]),
+    "quest_prefill_with_paged_kv_cache": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, c_u32, ctypes.c_int, c_vp]),
 }
 
 

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libquest_hip.so")
-SOURCES = ["append.hip", "estimate.hip", "topk.hip", "sparse_attn.hip", "rope_norm.hip", "decode_layer.hip"]
+SOURCES = ["append.hip", "estimate.hip", "topk.hip", "sparse_attn.hip", "rope_norm.hip", "decode_layer.hip", "prefill.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          # first 16 kernarg dwords in SGPRs at wave launch (the kernels keep their pointers first): the first

@@ -220,3 +220,24 @@ def test_rope_and_rmsnorm_oracle_vs_torch():
     ref = xx.astype(np.float32)
     ref = ref / np.sqrt((ref ** 2).mean(-1, keepdims=True) + 1e-5) * w.astype(np.float32)
     _close(oracle.rms_norm(xx, w, 1e-5), ref)
+
+
+def test_prefill_oracle_matches_reference_oracle():
+    """torch_ref.prefill_attention (fp32 restatement) vs the outputs of the reference's own `_ref_self_attention`
+    (test_prefill_attention.py:17-44; tests/golden/make_prefill_golden.py) on pairs of the reference's sweep, at the
+    reference's tolerance; the fp64 form agrees with the fp32 one far inside it."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "prefill_ref_golden.npz"))
+    for seed, qo, kv, H in g["cases"]:
+        q, k, v = (torch.from_numpy(synth.normal_f16(int(seed) * 3 + i, (n, int(H), 128)))
+                   for i, n in ((0, int(qo)), (1, int(kv)), (2, int(kv))))
+        o = torch_ref.prefill_attention(q, k, v)
+        _close(o.numpy(), g[f"o_{qo}_{kv}"])
+        o64 = torch_ref.prefill_attention(q, k, v, dtype=torch.float64)
+        assert float((o64 - o.double()).abs().max()) < 1e-5
+    # non-causal = every key for every row; one row over the whole cache = dense decode
+    q, k, v = (torch.from_numpy(synth.normal_f16(900 + i, (n, 2, 128))) for i, n in ((0, 5), (1, 70), (2, 70)))
+    full = torch_ref.prefill_attention(q, k, v, causal=False)
+    last = torch_ref.prefill_attention(q[-1:], k, v, causal=True)
+    torch.testing.assert_close(full[-1:], last, rtol=1e-6, atol=1e-6)
