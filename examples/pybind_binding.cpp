@@ -2,9 +2,8 @@
 // reference's op signatures (quest/ops/csrc/bsk_ops.h:23-117) and module definition (bsk_ops.cu:4-20) whose
 // bodies only build a quest_paged_kv_t view and call the C ABI of libquest_hip.so -- this is what a maintainer
 // puts in place of the bodies of quest/ops/csrc/{page,estimate,topk,approx_attn,rms_norm}.cu.
-// prefill_with_paged_kv_cache (bsk_ops.h:84-92, batch_prefill.cu:27-117) is outside the sparse-decode path (SURVEY 8f-4:
-// "prefill via torch SDPA"): bound here over at::scaled_dot_product_attention on the gathered pages, the semantics of
-// quest_amd/_kernels.py, so that the module carries the reference's WHOLE surface (quest.utils.prefill_forward works).
+// prefill_with_paged_kv_cache (bsk_ops.h:78-86, batch_prefill.cu:27-117) is bound the same way since round 5's MFMA flash
+// kernel (csrc/prefill.hip), so the module carries the reference's WHOLE surface over the C ABI.
 // Built by __graft_entry__.build() / scripts/check_cpp_binding.py, checked against quest_amd._kernels on the GPU
 // by tests/test_gpu_cpp_binding.py.
 #include <ATen/hip/HIPContext.h>
@@ -13,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
+#include <string>
 
 #include "quest_hip.h"
 
@@ -98,48 +98,26 @@ void append_kv_cache_decode(torch::Tensor k, torch::Tensor v, torch::Tensor kv_d
     TORCH_CHECK(rc == 0, "Append_kv_cache_decode failed with error code ", quest_error_string(rc));
 }
 
-// bsk_ops.h:84-92 (batch_prefill.cu:27-117): q [n][Hq][D] against the sequence's pages, query i sees keys 0 .. kv_len - n + i
-// when causal.  Whole prompt -> is_causal (flash backend); a chunk at the end of a longer cache -> boolean mask (memory-
-// efficient backend) in blocks of query rows that bound the mask; GQA without repeating K/V.  rope_* unused: the
-// reference prefills with RotaryMode::kNone on this path (QuestAttention.py rotates q / k beforehand).
+// bsk_ops.h:78-86 (batch_prefill.cu:27-117): q [n][Hq][D] against the sequence's pages, query i sees keys 0 .. kv_len - n + i
+// when causal.  One launch of the MFMA flash kernel straight over the page table (quest_prefill_with_paged_kv_cache).
+// rope_* unused: the reference prefills with RotaryMode::kNone on this path (QuestAttention.py rotates q / k beforehand).
 torch::Tensor prefill_with_paged_kv_cache(torch::Tensor q, torch::Tensor kv_data, torch::Tensor kv_indices,
                                           unsigned int kv_last_page_len, bool causal, unsigned int layout,
                                           bool /*allow_fp16_qk_reduction*/, float /*rope_scale*/, float /*rope_theta*/) {
     TORCH_CHECK(q.is_cuda() && kv_data.is_cuda() && kv_indices.is_cuda(), "prefill_with_paged_kv_cache: tensors must be on the GPU");
-    TORCH_CHECK(q.dim() == 3 && kv_data.dim() == 5, "prefill_with_paged_kv_cache: q must be 3-D, kv_data 5-D");
-    const bool hnd = layout == QUEST_LAYOUT_HND;
-    const int64_t page_size = kv_data.size(hnd ? 3 : 2), num_kv_heads = kv_data.size(hnd ? 2 : 3), head_dim = kv_data.size(4);
-    const torch::Tensor pages = kv_data.index_select(0, kv_indices.to(torch::kLong));  // [n_pages][2][...]
-    torch::Tensor k = pages.select(1, 0), v = pages.select(1, 1);
-    if (hnd) {
-        k = k.transpose(1, 2);
-        v = v.transpose(1, 2);
-    }
-    const int64_t kv_len = (kv_indices.size(0) - 1) * page_size + (int64_t)kv_last_page_len;
-    k = k.reshape({-1, num_kv_heads, head_dim}).slice(0, 0, kv_len);
-    v = v.reshape({-1, num_kv_heads, head_dim}).slice(0, 0, kv_len);
-    const int64_t n = q.size(0), hq = q.size(1);
-    const bool gqa = hq != num_kv_heads;
-    const torch::Tensor qh = q.transpose(0, 1).unsqueeze(0), kh = k.transpose(0, 1).unsqueeze(0), vh = v.transpose(0, 1).unsqueeze(0);
-    const double scale = 1.0 / std::sqrt((double)head_dim);
-    torch::Tensor o;
-    if (!causal || n == 1) {
-        o = at::scaled_dot_product_attention(qh, kh, vh, {}, 0.0, false, scale, gqa);
-    } else if (n == kv_len) {
-        o = at::scaled_dot_product_attention(qh, kh, vh, {}, 0.0, true, scale, gqa);
-    } else {
-        o = torch::empty_like(qh);
-        const int64_t blk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t(1) << 28) / std::max<int64_t>(kv_len, 1)));
-        const torch::Tensor cols = torch::arange(kv_len, torch::TensorOptions().device(q.device()).dtype(torch::kLong));
-        for (int64_t r0 = 0; r0 < n; r0 += blk) {
-            const int64_t r1 = std::min(n, r0 + blk), hi = kv_len - n + r1;  // keys beyond the block's last row: masked for all
-            const torch::Tensor limit = (torch::arange(r0, r1, cols.options()) + (kv_len - n)).unsqueeze(1);
-            const torch::Tensor mask = cols.slice(0, 0, hi).unsqueeze(0) <= limit;
-            o.slice(2, r0, r1).copy_(at::scaled_dot_product_attention(qh.slice(2, r0, r1), kh.slice(2, 0, hi), vh.slice(2, 0, hi),
-                                                                      mask, 0.0, false, scale, gqa));
-        }
-    }
-    return o.squeeze(0).transpose(0, 1).contiguous();
+    TORCH_CHECK(q.is_contiguous() && kv_data.is_contiguous() && kv_indices.is_contiguous(), "prefill_with_paged_kv_cache: tensors must be contiguous");
+    TORCH_CHECK(q.dim() == 3 && kv_data.dim() == 5 && kv_indices.dim() == 1, "prefill_with_paged_kv_cache: q must be 3-D, kv_data 5-D, kv_indices 1-D");
+    TORCH_CHECK(kv_indices.scalar_type() == torch::kInt32, "prefill_with_paged_kv_cache: kv_indices must be int32");
+    TORCH_CHECK(q.size(2) == kv_data.size(4), "prefill_with_paged_kv_cache: head_dim of q and kv_data differ");
+    TORCH_CHECK(q.scalar_type() == torch::kHalf, "BatchPrefillWithPagedKVCache failed to dispatch with dtype ", q.scalar_type());
+    torch::Tensor o = torch::empty_like(q);
+    quest_paged_kv_t kv = view(kv_data, kv_indices, kv_indices, kv_last_page_len, 0, layout);
+    kv.indptr = nullptr;  // one sequence: the page count travels as a host integer (batch_prefill.cu:41 builds {0, n})
+    const int rc = quest_prefill_with_paged_kv_cache(q.data_ptr(), o.data_ptr(), q.size(0), q.size(1), kv, kv_indices.size(0),
+                                                     causal ? 1 : 0, stream());
+    if (rc == QUEST_EINVAL) throw std::invalid_argument(std::string("BatchPrefillWithPagedKVCache: ") + quest_error_string(rc));
+    TORCH_CHECK(rc == 0, "BatchPrefillWithPagedKVCache failed with error code ", quest_error_string(rc));
+    return o;
 }
 
 // bsk_ops.h:94-116: the handler class over quest_decode_handler_t
@@ -196,7 +174,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {  // bsk_ops.cu:4-20 (the reference na
     m.def("estimate_attn_score", &estimate_attn_score, "page criticality scores from (max, min) metadata (HIP)");
     m.def("append_kv_cache_prefill", &append_kv_cache_prefill, "append many tokens + fold page metadata (HIP)");
     m.def("append_kv_cache_decode", &append_kv_cache_decode, "append one token + fold page metadata (HIP)");
-    m.def("prefill_with_paged_kv_cache", &prefill_with_paged_kv_cache, "prefill attention over the paged cache (ATen SDPA)");
+    m.def("prefill_with_paged_kv_cache", &prefill_with_paged_kv_cache, "prefill attention over the paged cache");
     py::class_<BatchDecodeWithPagedKVCachePyTorchWrapper>(m, "BatchDecodeWithPagedKVCachePyTorchWrapper")
         .def(py::init(&BatchDecodeWithPagedKVCachePyTorchWrapper::Create))
         .def("begin_forward", &BatchDecodeWithPagedKVCachePyTorchWrapper::BeginForward)

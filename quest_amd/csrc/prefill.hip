@@ -14,7 +14,14 @@
 // register for register, the B operand of O^T += V^T P^T (guide: "an accumulator tile as the next MFMA's operand") --
 // no LDS round trip for P.  V^T fragments come out of the row-major V tile with ds_read_b64_tr_b16.  K and V tiles are
 // staged global -> registers -> LDS one tile ahead (two LDS buffers, one barrier per tile) in the guide's dual-use
-// image (256-byte rows, 16-byte chunks XOR-swizzled by the row), conflict-free for both kinds of read.
+// image (256-byte rows, 16-byte chunks XOR-swizzled by the row), conflict-free for both kinds of read
+// (SQ_LDS_BANK_CONFLICT = 0 measured).  The tile loop is unrolled by the two buffers so that every LDS address is a
+// loop-invariant register plus an immediate, and the softmax keeps a deferred reference maximum (guide T13): in the
+// steady state a tile costs a wave 32 MFMAs, 48 LDS reads and ~150 vector instructions (32 v_exp, 32 v_fma, 32 v_add,
+// 16 v_max3, 16 v_cvt_pk) -- the first version's 220 bought 7 %.
+// Measured (profiles/r05_prefill_*): 0.74-0.98 PFLOP/s at 4K-32K tokens, 32 query heads (1.7-2.6x torch's fused
+// attention on contiguous K/V, 3.0-4.3x its masked path on a chunk, 20x with GQA); MFMA pipe busy 48 % of the cycles at
+// the ~1.6 GHz the chip holds under this load, LDS port active 38 %, no bank conflicts.
 #include "quest_common.cuh"
 
 namespace quest {
@@ -22,8 +29,8 @@ namespace quest {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
-constexpr int kPfRows = 128;  // query rows per workgroup
-constexpr int kPfKeys = 64;   // keys per tile
+constexpr uint32_t kPfRows = 128;  // query rows per workgroup
+constexpr int kPfKeys = 64;        // keys per tile
 
 struct PrefillParams {
     const half_t* q;
@@ -40,74 +47,116 @@ __device__ __forceinline__ uint32_t img_off(uint32_t row, uint32_t ch) {
     return 256u * row + 16u * (ch ^ (((row & 3u) << 2) | ((row >> 2) & 3u)));
 }
 
+#define QUEST_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ half8 lds_read16(uint32_t addr) {
+    return *reinterpret_cast<const QUEST_LDS half8*>((uintptr_t)addr);
+}
+__device__ __forceinline__ void lds_write16(uint32_t addr, half8 v) {
+    *reinterpret_cast<QUEST_LDS half8*>((uintptr_t)addr) = v;
+}
+// ds_read_b64_tr_b16: the 16 lanes of a group read a 4-row x 16-column block and each receives one COLUMN of it
+__device__ __forceinline__ half4 lds_read_tr(uint32_t addr) {
+    return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                         reinterpret_cast<QUEST_LDS short4v*>((uintptr_t)addr)));
+}
+
+constexpr uint32_t kPfBufBytes = 2 * kPfKeys * 256;  // one buffer: K image then V image
+constexpr float kPfDefer = 8.0f;  // log2 units a row maximum may run ahead of the exponent's reference before a rescale
+
+// Two 32-row blocks per wave (256-row workgroups, one wave per SIMD, each K / V fragment feeding two MFMAs) was built and
+// measured: 0.65-0.69 against 0.84-0.91 PFLOP/s -- hipcc keeps the second set of accumulators in AGPRs and copies them to
+// and from VGPRs around every vector instruction (1250 v_accvgpr moves per two tiles).
 template <bool S16>
 __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) {
     constexpr int D = 128;
-    __shared__ __attribute__((aligned(16))) unsigned char s_img[2][2][kPfKeys * 256];  // [buffer][K, V]
+    __shared__ __attribute__((aligned(16))) unsigned char s_img[2 * kPfBufBytes];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
 
     // workgroup -> (head, query block): the heads of an XCD are neighbours (a GQA group shares its K/V through one L2),
     // and the query blocks with the most keys under the causal mask are dispatched first
-    uint32_t head, qb;
+    uint32_t head, qblk;
     {
         const uint32_t id = blockIdx.x;
         if ((p.num_qo_heads & 7u) == 0) {
             const uint32_t hpx = p.num_qo_heads >> 3, slot = id >> 3;
             head = (id & 7u) * hpx + slot % hpx;
-            qb = slot / hpx;
+            qblk = slot / hpx;
         } else {
             head = id % p.num_qo_heads;
-            qb = id / p.num_qo_heads;
+            qblk = id / p.num_qo_heads;
         }
-        qb = p.q_blocks - 1 - qb;
+        qblk = p.q_blocks - 1 - qblk;
     }
     const uint32_t kv_head = head / p.group;
-    const uint32_t q0 = qb * kPfRows, q0w = q0 + wave * 32;
+    const uint32_t q0 = qblk * kPfRows, q0w = q0 + wave * 32;
     const uint32_t last_q = p.n_q - 1, last_key = p.kv_len - 1;
     const uint32_t shift = p.kv_len - p.n_q;  // query i sees keys <= shift + i
-    const uint32_t qi = min(q0w + r, last_q);
-    const uint32_t limit = p.causal ? shift + qi : last_key;                                   // this lane's query
-    const uint32_t limit_lo = p.causal ? shift + min(q0w, last_q) : last_key;                  // first query of the wave
-    const uint32_t limit_hi = p.causal ? shift + min(q0w + 31, last_q) : last_key;             // last query of the wave
+    const uint32_t limit = p.causal ? shift + min(q0w + r, last_q) : last_key;        // this lane's query
+    const uint32_t limit_lo = p.causal ? shift + min(q0w, last_q) : last_key;         // first query of the wave (uniform)
+    const uint32_t limit_hi = p.causal ? shift + min(q0w + 31, last_q) : last_key;    // last query of the wave
     const uint32_t limit_wg = p.causal ? shift + min(q0 + kPfRows - 1, last_q) : last_key;
     const uint32_t n_tiles = limit_wg / kPfKeys + 1;
     const bool wave_live = q0w < p.n_q;
 
-    // Q^T fragments (B operand): lane (r, h) holds q[row r][16 s + 8 h ..] of k-step s
+    // Q^T fragments (B operand): lane (r, h) holds q[row r][16 s + 8 h ..] of k-step s.  Unscaled: the reference folds
+    // log2(e) / sqrt(D) into q in fp16 (prefill.cuh:744), which rounds every score by up to 2^-11 of its terms -- 4e-3 of
+    // an output once |score| reaches ~100; here the factor multiplies the fp32 score on its way into the exponent.
+    // Rows past the end of q repeat the last row (computed, never stored).
     half8 qf[D / 16];
     {
-        const half_t* qrow = p.q + ((size_t)qi * p.num_qo_heads + head) * D + 8 * h;
+        const half_t* qrow = p.q + ((size_t)min(q0w + r, last_q) * p.num_qo_heads + head) * D + 8 * h;
 #pragma unroll
         for (int s = 0; s < D / 16; ++s) qf[s] = ld8(qrow + 16 * s);
     }
 
-    const uint32_t srow = tid >> 4, sch = tid & 15;  // staging: row srow + 16 i, chunk sch
-    const half_t* kv_head_base = p.kv + (size_t)kv_head * p.st.head + sch * 8;
+    // LDS addresses, loop-invariant up to immediates (buffer, key block, 16-key step): every read below is
+    // `register + constant`, no address arithmetic in the loop
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(QUEST_LDS unsigned char*)s_img;
+    uint32_t ka[D / 16];  // K row read of k-step s: row 32 kb + r, chunk 2 s + h
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) ka[s] = lds0 + img_off(r, 2 * s + h);
+    // V transposed read of d-block db, half u of a 16-key step: 16-lane group (tg = its d half), lane 4 tq + tp of it
+    const uint32_t tg = (lane >> 4) & 1u, tq = (lane & 15u) >> 2, tp = lane & 3u;
+    uint32_t va[D / 32][2];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            va[db][u] = lds0 + kPfKeys * 256 + img_off(8 * u + 4 * h + tq, 4 * db + 2 * tg + (tp >> 1)) + 8 * (tp & 1u);
+
+    // staging: thread -> row srow + 16 i, chunk sch of a tile
+    const uint32_t srow = tid >> 4, sch = tid & 15;
+    const uint32_t wa = lds0 + img_off(srow, sch);
+    const unsigned char* kv_head_base = reinterpret_cast<const unsigned char*>(p.kv + (size_t)kv_head * p.st.head);
+    const uint32_t v_bytes = p.st.v_off * 2u;
+    const uint32_t lane_bytes = (srow * p.st.entry + sch * 8u) * 2u;  // S16: slot = srow in every tile
     auto issue = [&](uint32_t t, half8(&kr)[4], half8(&vr)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t key = min(t * kPfKeys + srow + 16 * i, last_key);
-            uint32_t pg, slot;
             if constexpr (S16) {
-                pg = (uint32_t)ld_uniform_i32(p.table + min(t * 4 + i, last_key >> 4));
-                slot = key & 15u;
+                // one page per 16-row group, its id a scalar load; rows past the end of the sequence read stale slots
+                // of the last page (inside the pool): their scores are masked, their V rows zeroed below
+                const uint32_t pg = (uint32_t)ld_uniform_i32(p.table + min(t * 4 + i, last_key >> 4));
+                const unsigned char* src = kv_head_base + (size_t)pg * p.st.page * 2u;
+                kr[i] = *reinterpret_cast<const half8*>(src + lane_bytes);
+                vr[i] = *reinterpret_cast<const half8*>(src + v_bytes + lane_bytes);
             } else {
+                const uint32_t key = min(t * kPfKeys + srow + 16 * i, last_key);
                 const uint32_t pi = key / p.page_size;
-                pg = (uint32_t)p.table[pi];
-                slot = key - pi * p.page_size;
+                const uint32_t pg = (uint32_t)p.table[pi], slot = key - pi * p.page_size;
+                const unsigned char* src = kv_head_base + ((size_t)pg * p.st.page + (size_t)slot * p.st.entry + sch * 8u) * 2u;
+                kr[i] = *reinterpret_cast<const half8*>(src);
+                vr[i] = *reinterpret_cast<const half8*>(src + v_bytes);
             }
-            const half_t* src = kv_head_base + (size_t)pg * p.st.page + (size_t)slot * p.st.entry;
-            kr[i] = ld8(src);
-            vr[i] = ld8(src + p.st.v_off);
         }
-    };
-    auto stash = [&](uint32_t buf, const half8(&kr)[4], const half8(&vr)[4]) {
+        if constexpr (S16) {
+            if (t * kPfKeys + kPfKeys - 1 > last_key) {  // 0 x stale bits must stay 0
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t off = img_off(srow + 16 * i, sch);
-            *reinterpret_cast<half8*>(&s_img[buf][0][off]) = kr[i];
-            *reinterpret_cast<half8*>(&s_img[buf][1][off]) = vr[i];
+                for (int i = 0; i < 4; ++i)
+                    if (t * kPfKeys + srow + 16 * i > last_key) vr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     };
 
@@ -116,24 +165,19 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
     for (int db = 0; db < D / 32; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[db][e] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    const float c = p.scale_log2;
-
-    // per-lane pieces of the transposed-read address: 16-lane group g, lane 4 q + pp of it
-    const uint32_t tg = (lane >> 4) & 1u, tq = (lane & 15u) >> 2, tp = lane & 3u;
+    // online softmax with a deferred maximum (guide T13): m_ref, the reference the exponents are taken against, follows a
+    // row's maximum only when that runs ahead by more than kPfDefer (so p <= 2^8: exact range for fp16 and fp32 sums), and
+    // then everything still at the old reference (O and l) is moved exactly once, before the tile's exponents are taken
+    float m_ref = 0.f, l = 0.f;
+    const float c = p.scale_log2, defer = kPfDefer / c;  // scores are in raw units, the exponent in log2 units
 
     half8 kr[4], vr[4];
-    issue(0, kr, vr);
-    stash(0, kr, vr);
-    __syncthreads();
-    if (n_tiles > 1) issue(1, kr, vr);
 
-    for (uint32_t t = 0; t < n_tiles; ++t) {
-        const uint32_t buf = t & 1u;
+    auto tile = [&](auto buf_c, uint32_t t) {
+        constexpr uint32_t BUF = decltype(buf_c)::value;
+        constexpr uint32_t base = BUF * kPfBufBytes;
         const uint32_t key0 = t * kPfKeys;
         if (wave_live && key0 <= limit_hi) {
-            const unsigned char* img_k = s_img[buf][0];
-            const unsigned char* img_v = s_img[buf][1];
             f32x16 sacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -141,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
                 for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
                 for (int s = 0; s < D / 16; ++s) {
-                    const half8 kf = *reinterpret_cast<const half8*>(img_k + img_off(32 * kb + r, 2 * s + h));
+                    const half8 kf = lds_read16(ka[s] + base + kb * 32 * 256);
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
                 }
             }
@@ -155,17 +199,24 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
                         sacc[kb][e] = key <= limit ? sacc[kb][e] : -INFINITY;
                     }
             }
-            float smax = sacc[0][0];
+            float g = sacc[0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) smax = __builtin_fmaxf(smax, sacc[kb][e]);
-            smax = __builtin_fmaxf(smax, lane_xor<32>(smax, lane));
-            // key 0 is visible to every query, so from tile 0 on m_new is finite (a NaN score: NaN in, NaN out)
-            const float m_new = __builtin_fmaxf(m, smax);
-            const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
-            m = m_new;
-            const float mc = m_new * c;
+                for (int e = 0; e < 16; ++e) g = __builtin_fmaxf(g, sacc[kb][e]);
+            g = __builtin_fmaxf(g, lane_xor<32>(g, lane));  // the row's maximum in this tile
+            // key 0 is visible to every query, so tile 0 gives every row a finite reference (NaN in, NaN out)
+            if (t == 0 || __builtin_amdgcn_ballot_w64(g - m_ref > defer)) {
+                const float m_new = t == 0 ? g : __builtin_fmaxf(m_ref, g);
+                const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * c);
+                m_ref = m_new;
+                l *= alpha;
+#pragma unroll
+                for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+            }
+            const float mc = m_ref * c;
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -175,13 +226,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
                     sacc[kb][e] = pe;
                     psum += pe;
                 }
-            l = __builtin_fmaf(l, alpha, psum);
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
-#pragma unroll
-                for (int db = 0; db < D / 32; ++db)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
-            }
+            l += psum;
             // O^T += V^T P^T over the tile's four 16-key steps
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -190,27 +235,35 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
                 for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[s >> 1][8 * (s & 1) + j];
 #pragma unroll
                 for (int db = 0; db < D / 32; ++db) {
-                    half8 vf;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const uint32_t row = 16 * s + 8 * u + 4 * h + tq;
-                        const uint32_t off = img_off(row, 4 * db + 2 * tg + (tp >> 1)) + 8 * (tp & 1u);
-                        const short4v tv = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) short4v*)(uintptr_t)(
-                                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)img_v + off));
-                        const half4 hv = __builtin_bit_cast(half4, tv);
-                        vf[4 * u + 0] = hv[0];
-                        vf[4 * u + 1] = hv[1];
-                        vf[4 * u + 2] = hv[2];
-                        vf[4 * u + 3] = hv[3];
-                    }
+                    const half4 lo = lds_read_tr(va[db][0] + base + s * 16 * 256);
+                    const half4 hi = lds_read_tr(va[db][1] + base + s * 16 * 256);
+                    const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
                 }
             }
         }
-        if (t + 1 < n_tiles) stash(buf ^ 1u, kr, vr);
+        if (t + 1 < n_tiles) {  // tile t + 1 into the other buffer: its last readers passed the previous barrier
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lds_write16(wa + (base ^ kPfBufBytes) + i * 16 * 256, kr[i]);
+                lds_write16(wa + (base ^ kPfBufBytes) + kPfKeys * 256 + i * 16 * 256, vr[i]);
+            }
+        }
         __syncthreads();
         if (t + 2 < n_tiles) issue(t + 2, kr, vr);
+    };
+
+    issue(0, kr, vr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lds_write16(wa + i * 16 * 256, kr[i]);
+        lds_write16(wa + kPfKeys * 256 + i * 16 * 256, vr[i]);
+    }
+    __syncthreads();
+    if (n_tiles > 1) issue(1, kr, vr);
+    for (uint32_t t = 0; t < n_tiles; t += 2) {
+        tile(std::integral_constant<uint32_t, 0>{}, t);
+        if (t + 1 < n_tiles) tile(std::integral_constant<uint32_t, 1>{}, t + 1);
     }
 
     if (wave_live && q0w + r < p.n_q) {
@@ -253,10 +306,10 @@ extern "C" int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_
     p.num_qo_heads = num_qo_heads;
     p.group = num_qo_heads / kv.num_heads;
     p.page_size = kv.page_size;
-    p.q_blocks = (n_q + kPfRows - 1) / kPfRows;
     p.causal = causal ? 1u : 0u;
     p.st = pool_strides(kv);
     p.scale_log2 = 1.4426950408889634f / sqrtf((float)kv.head_dim);
+    p.q_blocks = (n_q + kPfRows - 1) / kPfRows;
     const uint64_t grid = (uint64_t)p.q_blocks * num_qo_heads;
     if (grid > 0x7fffffffull) return QUEST_ETOOLARGE;
     hipStream_t s = static_cast<hipStream_t>(stream);

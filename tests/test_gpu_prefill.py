@@ -98,6 +98,34 @@ def test_prefill_scale_of_scores_and_masked_keys_never_leak():
     torch.testing.assert_close(o[:40].cpu().float(), ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("pattern", ["ramp", "jump", "late_one_hot"])
+def test_prefill_row_maximum_that_keeps_growing(pattern):
+    """The kernel defers the softmax's reference maximum (it follows a row's maximum only when that runs ahead by more
+    than 8 log2 units) -- a branch that bounded random data almost never takes after the first tiles.  Crafted keys take
+    it on purpose: `ramp` grows every row's maximum a little per tile (deferred: probabilities above 1 for a while, then a
+    rescale), `jump` plants keys ten times larger late in the sequence (a rescale by 2^-100 and more in the middle of a
+    row's life, for some rows of a wave only -- the causal mask hides the jump from the others), `late_one_hot` makes the
+    very last visible key of each row dominate."""
+    qo, kv, H = 300, 1500, 2
+    q, k, v = _randn(21, qo, H, 128), _randn(22, kv, H, 128), _randn(23, kv, H, 128)
+    if pattern == "ramp":
+        k = (k.float() * torch.linspace(0.2, 3.0, kv, device=DEV).view(kv, 1, 1)).half()
+        k = (k.float().abs() * q[-1:].float().sign()).half()  # aligned with the last query: scores grow along the keys
+    elif pattern == "jump":
+        k = (k.float() * 0.3).half()
+        for j in (1210, 1290, 1377, 1499):
+            k[j] = (q[j - (kv - qo)].float() * 3.0).half()  # key j is the diagonal of row j - shift: score ~ 3 |q|^2 / sqrt(D)
+    else:
+        k = (k.float() * 0.2).half()
+        rows = torch.arange(qo, device=DEV)
+        k[kv - qo + rows] = (q.float() * 2.0).half()
+    ctl = _cache(k, v, H)
+    o = _prefill(q, ctl)
+    ctl.end_forward()
+    ref = torch_ref.prefill_attention(q.cpu(), k.cpu(), v.cpu())
+    torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_prefill_full_size_properties():
     """Llama-2-7B head shapes at 4096 and a 2048-row chunk after a 6144-token prefix: (i) chunked == whole on the same
     rows (different tile counts per row block, different dispatch order); (ii) spot rows against the fp32 oracle;
