@@ -420,6 +420,16 @@ def test_round3_entry_points_validate_arguments_without_gpu():
     assert lib.quest_decode_forward_fused_topk_tiles_dyn(h, one, one, kv, 32, one, 32, 10, 0, one, None, None) == -1
     assert lib.quest_decode_layer_fused_batched(h, None, one, kv, one, one, kv, 32, 10, one, b1, None, 0, None, None) == -1
     assert lib.quest_decode_layer_fused_batched(h, one, one, kv, one, one, kv, 32, 10, one, b1, None, 0, None, None) == -3  # no plan
+    # the prefill kernel's entry: null tensors, no pages, more query rows than cached tokens, a group that does not divide,
+    # a head_dim the MFMA kernel is not built for
+    pf = lib.quest_prefill_with_paged_kv_cache
+    assert pf(None, one, 8, 32, kv, 4, 1, None) == -1 and pf(one, one, 0, 32, kv, 4, 1, None) == -1
+    assert pf(one, one, 8, 32, kv, 0, 1, None) == -1
+    assert pf(one, one, 50, 32, kv, 4, 1, None) == -1          # 3 * 16 + 1 = 49 cached tokens < 50 rows
+    assert pf(one, one, 8, 48, kv, 4, 1, None) == -1           # 48 query heads over 32 kv heads
+    kv64 = PagedKV(data=16, indices=16, indptr=16, num_heads=32, page_size=16, head_dim=64, page_budget=0,
+                   last_page_len=1, last_page_idx=0, layout=0)
+    assert pf(one, one, 8, 32, kv64, 4, 1, None) == -2
     info = (ctypes.c_uint32 * 6)()
     assert lib.quest_decode_last_launch_info(h, info) == 0 and list(info) == [0] * 6  # nothing launched yet
     assert lib.quest_decode_last_launch_info(None, info) == -1
