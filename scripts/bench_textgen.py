@@ -3,7 +3,8 @@
 (the shape of the reference's scripts/bench_textgen.py:75-97 and README Fig. 10).
 
 Random weights (no checkpoints offline) of Llama-2-7B shape by default; the KV cache of `--ctx` tokens is
-filled with synthetic keys/values through append_kv (a real prefill at 32K is outside this path), then one
+filled with synthetic keys/values through append_kv -- or, with --real-prefill, by the reference harness's own prefill: one
+model forward over `--ctx` random hidden states, timed (attention on the MFMA kernel of csrc/prefill.hip) --, then one
 decode token -- RMSNorm, QKV GEMV, RoPE, [append+estimate | top-k+sparse attention | merge], o_proj, MLP,
 lm_head -- is captured in a hipGraph and replayed.  First `skip` = 2 layers run dense like the reference
 (quest/models/llama.py:428-439).
@@ -114,6 +115,10 @@ def main():
     ap.add_argument("--generate", type=int, default=0,
                     help="also generate this many tokens greedily by graph replay from the synthetic cache and report "
                          "ms/token over the whole run (host loop included)")
+    ap.add_argument("--real-prefill", action="store_true",
+                    help="fill the cache the way the reference's harness does (scripts/bench_textgen.py:77-84): ONE model "
+                         "forward over --ctx random hidden states -- projections, RoPE, append with page metadata, the MFMA "
+                         "prefill attention kernel, MLP in every layer -- and report its latency (time to first token)")
     a = ap.parse_args()
     from quest_amd.models.llama import LlamaConfig, LlamaForCausalLM
     import quest_amd.utils as qu
@@ -158,6 +163,7 @@ def main():
         return
     results = {}
     gen_ms = {}
+    prefill_s = {}
     for name, budget in (("quest", a.token_budget), ("dense", 1 << 24)):
         if a.checkpoint:
             import time
@@ -176,16 +182,30 @@ def main():
         ctl = model.model.iController
         g = torch.Generator(device=dev).manual_seed(1)
         D = a.hidden // a.heads
-        ctl.prepare_metadata(a.ctx)
-        ctl.begin_forward(a.ctx)
-        k = torch.empty(a.ctx, a.kv_heads, D, dtype=torch.float16, device=dev)
-        v = torch.empty_like(k)
-        for l in range(a.layers):
-            k.normal_(generator=g)
-            v.normal_(generator=g)
-            qu.append_kv(k, v, ctl, l)
-        ctl.end_forward()
-        del k, v
+        if a.real_prefill:
+            import time
+            x = torch.randn(1, a.ctx, a.hidden, generator=g, device=dev, dtype=torch.float16)
+            with torch.inference_mode():
+                model(inputs_embeds=x[:, :256])  # warm the libraries' kernels on a short request, then start over
+                model.quest_clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                first = model(inputs_embeds=x)
+                torch.cuda.synchronize()
+            prefill_s[name] = time.perf_counter() - t0
+            assert torch.isfinite(first.float()).all() and ctl.kv_cache.seqlen == a.ctx
+            del x, first
+        else:
+            ctl.prepare_metadata(a.ctx)
+            ctl.begin_forward(a.ctx)
+            k = torch.empty(a.ctx, a.kv_heads, D, dtype=torch.float16, device=dev)
+            v = torch.empty_like(k)
+            for l in range(a.layers):
+                k.normal_(generator=g)
+                v.normal_(generator=g)
+                qu.append_kv(k, v, ctl, l)
+            ctl.end_forward()
+            del k, v
         emb = torch.randn(1, 1, a.hidden, generator=g, device=dev, dtype=torch.float16) * 0.1
         results[name] = time_decode(model, ctl, emb, a.reps)
         if a.generate:
@@ -215,6 +235,11 @@ def main():
         out["generated_tokens"] = a.generate
         out["ms_per_generated_token_quest"] = gen_ms["quest"]
         out["ms_per_generated_token_full_kv"] = gen_ms["dense"]
+    if prefill_s:
+        out["prefill_s_quest"] = prefill_s["quest"]  # the same work in both runs (prefill is dense): two samples
+        out["prefill_s_full_kv"] = prefill_s["dense"]
+        out["prefill"] = ("one model forward over ctx random hidden states, as the reference harness "
+                          "(scripts/bench_textgen.py:77-84); attention = csrc/prefill.hip")
     if ckpt_info:
         out["checkpoint"] = ckpt_info
         out["bench"] = "e2e decode latency, Llama checkpoint in Hugging Face layout loaded with from_pretrained"
