@@ -105,6 +105,8 @@ def parse(argv=None):
                     help="skip the side configurations (8 sequences per GPU) the default headline run measures after its "
                          "timed region")
     ap.add_argument("--side-steps", type=int, default=100, help="timed steps of each side configuration")
+    ap.add_argument("--side-warmup", type=int, default=None,
+                    help="untimed steps before each side configuration's timed steps (default: max(--warmup, 20))")
     ap.add_argument("--cpu-sample-s", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic K/V/q (SURVEY 8d: seeds 0, 1, 2)")
     a = ap.parse_args(argv)
@@ -908,7 +910,8 @@ def main():
                 gc.collect()
                 if not stub:
                     torch.cuda.empty_cache()
-                a2 = parse(["--config", str(overrides["config"]), "--steps", str(a.side_steps), "--warmup", str(a.warmup),
+                side_warmup = a.side_warmup if a.side_warmup is not None else max(a.warmup, 20)
+                a2 = parse(["--config", str(overrides["config"]), "--steps", str(a.side_steps), "--warmup", str(side_warmup),
                             "--seed", str(a.seed), "--no-cpu-baseline", "--gpus", str(a.gpus),
                             "--layer-launches", a.layer_launches]
                            + (["--seqs-per-gpu", str(overrides["seqs_per_gpu"])] if "seqs_per_gpu" in overrides else []))

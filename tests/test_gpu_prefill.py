@@ -82,6 +82,27 @@ def test_prefill_vs_oracle(qo, kv, Hq, Hkv, page, layout, causal):
     torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3)
 
 
+def test_prefill_fuzz_vs_oracle():
+    """60 seeded random shapes: query rows 1..700, cached tokens up to 2500, 1-9 kv heads x groups 1/2/4, page sizes
+    1..33, both layouts, causal or not -- every combination of ragged query blocks, ragged key tiles and page walks."""
+    rng = np.random.default_rng(20250705)
+    for case in range(60):
+        kv = int(rng.integers(1, 2500))
+        qo = int(rng.integers(1, min(kv, 700) + 1))
+        Hkv, group = int(rng.integers(1, 10)), int(rng.choice([1, 1, 2, 4]))
+        page = int(rng.choice([16, 16, 16, 1, 2, 5, 8, 24, 33]))
+        layout, causal = int(rng.integers(0, 2)), bool(rng.integers(0, 4))
+        q = _randn(3 * case, qo, Hkv * group, 128)
+        k, v = _randn(3 * case + 1, kv, Hkv, 128), _randn(3 * case + 2, kv, Hkv, 128)
+        ctl = _cache(k, v, Hkv * group, page, layout, seed=case)
+        o = _prefill(q, ctl, causal)
+        ctl.end_forward()
+        ref = torch_ref.prefill_attention(q.cpu(), k.cpu(), v.cpu(), causal)
+        torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3,
+                                   msg=lambda m: f"case {case}: qo={qo} kv={kv} Hkv={Hkv} group={group} page={page} "
+                                                 f"layout={layout} causal={causal}: {m}")
+
+
 def test_prefill_scale_of_scores_and_masked_keys_never_leak():
     """Large scores (|s| ~ 100: softmax close to one-hot) and garbage in the masked future: keys a row must not see hold
     NaN / inf K and huge V; the visible result is untouched (a masked score is replaced, never multiplied)."""
