@@ -425,7 +425,7 @@ int quest_rms_norm_forward(const void* input, const void* weight, void* output, 
  * 0 .. kv_len - n_q + i when `causal`, every key otherwise; no rotary (RotaryMode::kNone, batch_prefill.cu:101),
  * softmax scale 1/sqrt(head_dim).  GQA: num_qo_heads a multiple of kv.num_heads, query head h reads kv head
  * h / (num_qo_heads / kv.num_heads).  head_dim 128, any page_size, both layouts; QUEST_EUNSUPPORTED otherwise;
- * n_q > kv_len is QUEST_EINVAL (the reference assumes kv_len >= qo_len, test_prefill_attention.py:53-54).
+ * causal with n_q > kv_len is QUEST_EINVAL (the reference assumes kv_len >= qo_len, test_prefill_attention.py:53-54).
  * MFMA flash kernel (csrc/prefill.hip): 128 query rows per workgroup, 64-key tiles, nothing but o is written.
  */
 int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_t n_q, uint32_t num_qo_heads,

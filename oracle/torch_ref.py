@@ -96,7 +96,7 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal:
     in ``dtype``."""
     qo_len, Hq, D = q.shape
     kv_len, Hkv, _ = k.shape
-    assert kv_len >= qo_len and Hq % Hkv == 0
+    assert (kv_len >= qo_len or not causal) and Hq % Hkv == 0
     qh = q.to(dtype).transpose(0, 1)
     kh = k.to(dtype).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)
     vh = v.to(dtype).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)

@@ -11,11 +11,9 @@ symbol exists so ``quest.utils`` imports unchanged, and is served by torch SDPA 
 from __future__ import annotations
 
 import ctypes
-import math
 
 import torch
 
-from . import _lib
 from ._lib import Batch, PagedKV, check, lib
 
 _NHD, _HND = 0, 1

@@ -295,7 +295,8 @@ extern "C" int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_
     if (num_qo_heads % kv.num_heads != 0) return QUEST_EINVAL;
     if (kv.head_dim != 128) return QUEST_EUNSUPPORTED;
     const uint64_t kv_len = (uint64_t)(n_pages_host - 1) * kv.page_size + kv.last_page_len;
-    if (kv_len > 0x7fffffffull || n_q > kv_len) return QUEST_EINVAL;  // the reference assumes kv_len >= qo_len
+    // causal rows are the LAST n_q tokens of the sequence: the reference assumes kv_len >= qo_len (test_prefill_attention.py:53)
+    if (kv_len > 0x7fffffffull || (causal && n_q > kv_len)) return QUEST_EINVAL;
     PrefillParams p;
     p.q = static_cast<const half_t*>(q);
     p.o = static_cast<half_t*>(o);

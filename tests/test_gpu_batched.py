@@ -3,7 +3,6 @@ the single-sequence state-driven path computes: states, pool bytes, estimates an
 attention outputs bit for bit when the work split is the same and within the attention tolerance otherwise."""
 import os
 
-import numpy as np
 import pytest
 import torch
 

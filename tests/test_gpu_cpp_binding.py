@@ -6,7 +6,6 @@ rebuilt here if stale and a host compiler is present, and the test skips cleanly
 import os
 import sys
 
-import numpy as np
 import pytest
 import torch
 

@@ -1,7 +1,6 @@
 """Fused decode-token projections of a Llama decoder layer (csrc/decode_layer.hip; EXTENSION for SURVEY 8f-4): each launch
 against a plain PyTorch fp32 reference of the same op, and the whole graph-replayed model step against the unfused
 module path (nn.Linear + rms_norm_forward + apply_rope_in_place + PyTorch SiLU / adds)."""
-import numpy as np
 import pytest
 import torch
 

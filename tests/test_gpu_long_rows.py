@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import oracle
-from _harness import cuda, inputs, make_controller, oracle_pools
+from _harness import make_controller, oracle_pools
 
 pytestmark = pytest.mark.gpu
 PAGE = 16

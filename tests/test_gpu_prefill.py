@@ -178,8 +178,11 @@ def test_prefill_argument_errors():
 
     q, k, v = _randn(1, 40, 2, 128), _randn(2, 30, 2, 128), _randn(3, 30, 2, 128)
     ctl = _cache(k, v, 2)
-    with pytest.raises(ValueError):  # more query rows than cached tokens (test_prefill_attention.py:53-54)
+    with pytest.raises(ValueError):  # more causal query rows than cached tokens (test_prefill_attention.py:53-54)
         _prefill(q, ctl)
+    o = _prefill(q, ctl, causal=False)  # without the mask any number of rows may look at the cache
+    torch.testing.assert_close(o.cpu().float(), torch_ref.prefill_attention(q.cpu(), k.cpu(), v.cpu(), causal=False),
+                               rtol=2e-3, atol=2e-3)
     with pytest.raises(RuntimeError):  # head_dim mismatch (batch_prefill.cu:58)
         _kernels.prefill_with_paged_kv_cache(q[:10, :, :64].contiguous(), ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last,
                                              ctl.kv_cache.last_page_len, True, ctl.layout, False, 1.0, 1e4)

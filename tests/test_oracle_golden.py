@@ -5,7 +5,6 @@ Tolerances are the reference's own: rtol = atol = 5e-3 for fp16
 (quest/tests/test_estimate.py:10-15, test_approx_attention.py:10-15).
 """
 import numpy as np
-import pytest
 import torch
 
 import oracle
