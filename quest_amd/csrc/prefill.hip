@@ -6,7 +6,8 @@
 // j <= kv_len - n + i (causal; every key otherwise) of the sequence whose pages `indices` lists; the new tokens' K/V are
 // already in the cache (utils/__init__.py:127-170), no rotary (RotaryMode::kNone, batch_prefill.cu:101), fp16 in/out.
 //
-// Shape of the kernel (gfx950): a workgroup = 4 waves = 128 query rows of one query head; a wave owns 32 of them.  Per
+// Shape of the kernel (gfx950; head_dim 64 / 128 / 256 as in the reference's SWITCH_HEAD_DIM, the text below is for 128): a
+// workgroup = 4 waves = 128 query rows of one query head; a wave owns 32 of them.  Per
 // 64-key tile a wave computes the TRANSPOSED scores S^T = K Q^T with v_mfma_f32_32x32x16_f16 (K rows from LDS as the A
 // operand, its Q rows -- loaded once, 32 registers -- as B): a 32x32 result has its column, i.e. the QUERY, on the lane
 // and 16 keys in the lane's registers, so the row maximum and sum of the online softmax are per-lane loops plus one
@@ -14,14 +15,15 @@
 // register for register, the B operand of O^T += V^T P^T (guide: "an accumulator tile as the next MFMA's operand") --
 // no LDS round trip for P.  V^T fragments come out of the row-major V tile with ds_read_b64_tr_b16.  K and V tiles are
 // staged global -> registers -> LDS one tile ahead (two LDS buffers, one barrier per tile) in the guide's dual-use
-// image (256-byte rows, 16-byte chunks XOR-swizzled by the row), conflict-free for both kinds of read
-// (SQ_LDS_BANK_CONFLICT = 0 measured).  The tile loop is unrolled by the two buffers so that every LDS address is a
+// image (8-row x 32-column subtiles, the chunks of a subtile row XOR-swizzled by the row), conflict-free for both kinds
+// of read and for the staging writes (SQ_LDS_BANK_CONFLICT = 0 measured).  The tile loop is unrolled by the two buffers so that every LDS address is a
 // loop-invariant register plus an immediate, and the softmax keeps a deferred reference maximum (guide T13): in the
 // steady state a tile costs a wave 32 MFMAs, 48 LDS reads and ~150 vector instructions (32 v_exp, 32 v_fma, 32 v_add,
 // 16 v_max3, 16 v_cvt_pk) -- the first version's 220 bought 7 %.
 // Measured (profiles/r05_prefill_*): 0.74-0.98 PFLOP/s at 4K-32K tokens, 32 query heads (1.7-2.6x torch's fused
 // attention on contiguous K/V, 3.0-4.3x its masked path on a chunk, 20x with GQA); MFMA pipe busy 48 % of the cycles at
-// the ~1.6 GHz the chip holds under this load, LDS port active 38 %, no bank conflicts.
+// the ~1.6 GHz the chip holds under this load, LDS port active 38 %, no bank conflicts.  head_dim 64: 0.56-0.82, head_dim
+// 256: 0.58-0.73 PFLOP/s (1.2-2.5x torch's).
 #include "quest_common.cuh"
 
 namespace quest {
@@ -42,9 +44,13 @@ struct PrefillParams {
     float scale_log2;  // log2(e) / sqrt(D)
 };
 
-// Byte offset of 16-byte chunk `ch` of row `row` in a [rows][128 halves] tile image (guide T10, image (b)).
-__device__ __forceinline__ uint32_t img_off(uint32_t row, uint32_t ch) {
-    return 256u * row + 16u * (ch ^ (((row & 3u) << 2) | ((row >> 2) & 3u)));
+// Byte offset of 16-byte chunk `ch` of row `row` in a [rows][D halves] tile image: the guide's dual-use image (a) (T10) --
+// 8-row x 32-column subtiles of 512 B, the four chunks of a subtile row XOR-swizzled by the row -- which serves the K row
+// reads (ds_read_b128) and the V transposed reads (ds_read_b64_tr_b16) of the 32x32x16 operands without bank conflicts and
+// with two address registers each for any D (every other term is an immediate).
+template <int D>
+__device__ __forceinline__ constexpr uint32_t img_off(uint32_t row, uint32_t ch) {
+    return 16u * D * (row >> 3) + 512u * (ch >> 2) + 64u * (row & 7u) + 16u * ((ch & 3u) ^ ((row >> 2) & 3u));
 }
 
 #define QUEST_LDS __attribute__((address_space(3)))
@@ -61,16 +67,23 @@ __device__ __forceinline__ half4 lds_read_tr(uint32_t addr) {
                                          reinterpret_cast<QUEST_LDS short4v*>((uintptr_t)addr)));
 }
 
-constexpr uint32_t kPfBufBytes = 2 * kPfKeys * 256;  // one buffer: K image then V image
 constexpr float kPfDefer = 8.0f;  // log2 units a row maximum may run ahead of the exponent's reference before a rescale
 
 // Two 32-row blocks per wave (256-row workgroups, one wave per SIMD, each K / V fragment feeding two MFMAs) was built and
 // measured: 0.65-0.69 against 0.84-0.91 PFLOP/s -- hipcc keeps the second set of accumulators in AGPRs and copies them to
 // and from VGPRs around every vector instruction (1250 v_accvgpr moves per two tiles).
-template <bool S16>
-__global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) {
-    constexpr int D = 128;
-    __shared__ __attribute__((aligned(16))) unsigned char s_img[2 * kPfBufBytes];
+//
+// D = 64 / 128: two LDS buffers (32 / 64 KiB), two workgroups per CU.  D = 256: the output accumulators alone are 128
+// registers, so one wave per SIMD and ONE 64 KiB buffer (a second barrier per tile instead of the second buffer).
+template <int D, bool S16>
+__global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_kernel(const PrefillParams p) {
+    constexpr uint32_t IMG = kPfKeys * 2 * D;        // bytes of one K (or V) tile image
+    constexpr uint32_t BUFB = 2 * IMG;               // one buffer: K image then V image
+    constexpr int NBUF = D <= 128 ? 2 : 1;
+    constexpr uint32_t CPR = D / 8;                  // 16-byte chunks per row
+    constexpr uint32_t RP = 256 / CPR;               // rows staged per pass of the 256 threads
+    constexpr int NP = kPfKeys / RP;                 // passes per tile
+    __shared__ __attribute__((aligned(16))) unsigned char s_img[NBUF * BUFB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
 
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
     const uint32_t kv_head = head / p.group;
     const uint32_t q0 = qblk * kPfRows, q0w = q0 + wave * 32;
     const uint32_t last_q = p.n_q - 1, last_key = p.kv_len - 1;
-    const uint32_t shift = p.kv_len - p.n_q;  // query i sees keys <= shift + i
+    const uint32_t shift = p.kv_len - p.n_q;  // query i sees keys <= shift + i (causal)
     const uint32_t limit = p.causal ? shift + min(q0w + r, last_q) : last_key;        // this lane's query
     const uint32_t limit_lo = p.causal ? shift + min(q0w, last_q) : last_key;         // first query of the wave (uniform)
     const uint32_t limit_hi = p.causal ? shift + min(q0w + 31, last_q) : last_key;    // last query of the wave
@@ -111,39 +124,43 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
         for (int s = 0; s < D / 16; ++s) qf[s] = ld8(qrow + 16 * s);
     }
 
-    // LDS addresses, loop-invariant up to immediates (buffer, key block, 16-key step): every read below is
-    // `register + constant`, no address arithmetic in the loop
+    // LDS addresses, loop-invariant up to immediates (buffer, key block, k-step pair, 16-key step, d-block): every read
+    // below is `register + constant`, no address arithmetic in the loop
     const uint32_t lds0 = (uint32_t)(uintptr_t)(QUEST_LDS unsigned char*)s_img;
-    uint32_t ka[D / 16];  // K row read of k-step s: row 32 kb + r, chunk 2 s + h
-#pragma unroll
-    for (int s = 0; s < D / 16; ++s) ka[s] = lds0 + img_off(r, 2 * s + h);
-    // V transposed read of d-block db, half u of a 16-key step: 16-lane group (tg = its d half), lane 4 tq + tp of it
+    // K row read of k-step s: row 32 kb + r, chunk 2 s + h = subtile s >> 1, chunk 2 (s & 1) + h of it
+    const uint32_t ka[2] = {lds0 + img_off<D>(r, h), lds0 + img_off<D>(r, 2 + h)};
+    // V transposed read of d-block db, half u of 16-key step s: rows 16 s + 8 u + 4 h + tq, 16-lane group tg = the d half,
+    // lane 4 tq + tp of the group supplies row tq, columns 4 tp .. 4 tp + 3 of the block
     const uint32_t tg = (lane >> 4) & 1u, tq = (lane & 15u) >> 2, tp = lane & 3u;
-    uint32_t va[D / 32][2];
-#pragma unroll
-    for (int db = 0; db < D / 32; ++db)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            va[db][u] = lds0 + kPfKeys * 256 + img_off(8 * u + 4 * h + tq, 4 * db + 2 * tg + (tp >> 1)) + 8 * (tp & 1u);
+    const uint32_t va[2] = {lds0 + IMG + img_off<D>(4 * h + tq, 2 * tg + (tp >> 1)) + 8 * (tp & 1u),
+                            lds0 + IMG + img_off<D>(8 + 4 * h + tq, 2 * tg + (tp >> 1)) + 8 * (tp & 1u)};
 
-    // staging: thread -> row srow + 16 i, chunk sch of a tile
-    const uint32_t srow = tid >> 4, sch = tid & 15;
-    const uint32_t wa = lds0 + img_off(srow, sch);
+    // staging: thread -> chunk sch of rows srow + RP i of a tile.  Four lanes take the four chunks of a subtile row, the
+    // next lanes the next ROW of the same subtile: a wave writes whole 512-byte subtiles (no bank conflict on the
+    // ds_write_b128) and still reads 128 contiguous bytes of each of its 8 rows from memory.
+    constexpr uint32_t SUB = CPR / 4;  // subtiles per 8-row group
+    const uint32_t srow = 8u * (tid / (32u * SUB)) + ((tid >> 2) & 7u), sch = 4u * ((tid >> 5) % SUB) + (tid & 3u);
+    uint32_t wa[NP];  // (for RP = 16 / 32 the passes differ by a constant)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) wa[i] = lds0 + img_off<D>(srow + RP * i, sch);
     const unsigned char* kv_head_base = reinterpret_cast<const unsigned char*>(p.kv + (size_t)kv_head * p.st.head);
     const uint32_t v_bytes = p.st.v_off * 2u;
-    const uint32_t lane_bytes = (srow * p.st.entry + sch * 8u) * 2u;  // S16: slot = srow in every tile
-    auto issue = [&](uint32_t t, half8(&kr)[4], half8(&vr)[4]) {
+    auto issue = [&](uint32_t t, half8(&kr)[NP], half8(&vr)[NP]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
+            const uint32_t row = srow + RP * i;
             if constexpr (S16) {
-                // one page per 16-row group, its id a scalar load; rows past the end of the sequence read stale slots
-                // of the last page (inside the pool): their scores are masked, their V rows zeroed below
-                const uint32_t pg = (uint32_t)ld_uniform_i32(p.table + min(t * 4 + i, last_key >> 4));
+                // one page per 16-row group -- the same one for every lane of a wave --, its id a scalar load; rows past the
+                // end of the sequence read stale slots of the last page (inside the pool): their scores are masked, their
+                // V rows zeroed below
+                const uint32_t pi = t * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 4));
+                const uint32_t pg = (uint32_t)ld_uniform_i32(p.table + min(pi, last_key >> 4));
                 const unsigned char* src = kv_head_base + (size_t)pg * p.st.page * 2u;
+                const uint32_t lane_bytes = ((row & 15u) * p.st.entry + sch * 8u) * 2u;
                 kr[i] = *reinterpret_cast<const half8*>(src + lane_bytes);
                 vr[i] = *reinterpret_cast<const half8*>(src + v_bytes + lane_bytes);
             } else {
-                const uint32_t key = min(t * kPfKeys + srow + 16 * i, last_key);
+                const uint32_t key = min(t * kPfKeys + row, last_key);
                 const uint32_t pi = key / p.page_size;
                 const uint32_t pg = (uint32_t)p.table[pi], slot = key - pi * p.page_size;
                 const unsigned char* src = kv_head_base + ((size_t)pg * p.st.page + (size_t)slot * p.st.entry + sch * 8u) * 2u;
@@ -154,9 +171,16 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
         if constexpr (S16) {
             if (t * kPfKeys + kPfKeys - 1 > last_key) {  // 0 x stale bits must stay 0
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (t * kPfKeys + srow + 16 * i > last_key) vr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < NP; ++i)
+                    if (t * kPfKeys + srow + RP * i > last_key) vr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             }
+        }
+    };
+    auto stash = [&](uint32_t base, const half8(&kr)[NP], const half8(&vr)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            lds_write16(wa[i] + base, kr[i]);
+            lds_write16(wa[i] + base + IMG, vr[i]);
         }
     };
 
@@ -171,11 +195,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
     float m_ref = 0.f, l = 0.f;
     const float c = p.scale_log2, defer = kPfDefer / c;  // scores are in raw units, the exponent in log2 units
 
-    half8 kr[4], vr[4];
+    half8 kr[NP], vr[NP];
 
     auto tile = [&](auto buf_c, uint32_t t) {
-        constexpr uint32_t BUF = decltype(buf_c)::value;
-        constexpr uint32_t base = BUF * kPfBufBytes;
+        constexpr uint32_t base = decltype(buf_c)::value * BUFB;
         const uint32_t key0 = t * kPfKeys;
         if (wave_live && key0 <= limit_hi) {
             f32x16 sacc[2];
@@ -185,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
                 for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
                 for (int s = 0; s < D / 16; ++s) {
-                    const half8 kf = lds_read16(ka[s] + base + kb * 32 * 256);
+                    const half8 kf = lds_read16(ka[s & 1] + base + kb * (64 * D) + 512 * (s >> 1));
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
                 }
             }
@@ -235,35 +258,36 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
                 for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[s >> 1][8 * (s & 1) + j];
 #pragma unroll
                 for (int db = 0; db < D / 32; ++db) {
-                    const half4 lo = lds_read_tr(va[db][0] + base + s * 16 * 256);
-                    const half4 hi = lds_read_tr(va[db][1] + base + s * 16 * 256);
+                    const half4 lo = lds_read_tr(va[0] + base + s * (32 * D) + 512 * db);
+                    const half4 hi = lds_read_tr(va[1] + base + s * (32 * D) + 512 * db);
                     const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
                 }
             }
         }
-        if (t + 1 < n_tiles) {  // tile t + 1 into the other buffer: its last readers passed the previous barrier
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lds_write16(wa + (base ^ kPfBufBytes) + i * 16 * 256, kr[i]);
-                lds_write16(wa + (base ^ kPfBufBytes) + kPfKeys * 256 + i * 16 * 256, vr[i]);
-            }
+        if constexpr (NBUF == 2) {
+            // tile t + 1 into the other buffer: its last readers passed the previous barrier
+            if (t + 1 < n_tiles) stash(base ^ BUFB, kr, vr);
+            __syncthreads();
+        } else {
+            __syncthreads();  // every wave is done reading tile t
+            if (t + 1 < n_tiles) stash(0, kr, vr);
+            __syncthreads();
         }
-        __syncthreads();
         if (t + 2 < n_tiles) issue(t + 2, kr, vr);
     };
 
     issue(0, kr, vr);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lds_write16(wa + i * 16 * 256, kr[i]);
-        lds_write16(wa + kPfKeys * 256 + i * 16 * 256, vr[i]);
-    }
+    stash(0, kr, vr);
     __syncthreads();
     if (n_tiles > 1) issue(1, kr, vr);
-    for (uint32_t t = 0; t < n_tiles; t += 2) {
-        tile(std::integral_constant<uint32_t, 0>{}, t);
-        if (t + 1 < n_tiles) tile(std::integral_constant<uint32_t, 1>{}, t + 1);
+    if constexpr (NBUF == 2) {
+        for (uint32_t t = 0; t < n_tiles; t += 2) {
+            tile(std::integral_constant<uint32_t, 0>{}, t);
+            if (t + 1 < n_tiles) tile(std::integral_constant<uint32_t, 1>{}, t + 1);
+        }
+    } else {
+        for (uint32_t t = 0; t < n_tiles; ++t) tile(std::integral_constant<uint32_t, 0>{}, t);
     }
 
     if (wave_live && q0w + r < p.n_q) {
@@ -281,6 +305,14 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(const PrefillParams p) 
     }
 }
 
+template <int D>
+static void launch_prefill(const PrefillParams& p, uint32_t grid, bool s16, hipStream_t s) {
+    if (s16)
+        hipLaunchKernelGGL((prefill_kernel<D, true>), dim3(grid), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((prefill_kernel<D, false>), dim3(grid), dim3(256), 0, s, p);
+}
+
 }  // namespace quest
 
 using namespace quest;
@@ -293,7 +325,7 @@ extern "C" int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_
     if (kv.layout != QUEST_LAYOUT_NHD && kv.layout != QUEST_LAYOUT_HND) return QUEST_EINVAL;
     if (kv.last_page_len == 0 || kv.last_page_len > kv.page_size) return QUEST_EINVAL;
     if (num_qo_heads % kv.num_heads != 0) return QUEST_EINVAL;
-    if (kv.head_dim != 128) return QUEST_EUNSUPPORTED;
+    if (kv.head_dim != 64 && kv.head_dim != 128 && kv.head_dim != 256) return QUEST_EUNSUPPORTED;
     const uint64_t kv_len = (uint64_t)(n_pages_host - 1) * kv.page_size + kv.last_page_len;
     // causal rows are the LAST n_q tokens of the sequence: the reference assumes kv_len >= qo_len (test_prefill_attention.py:53)
     if (kv_len > 0x7fffffffull || (causal && n_q > kv_len)) return QUEST_EINVAL;
@@ -314,10 +346,11 @@ extern "C" int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_
     const uint64_t grid = (uint64_t)p.q_blocks * num_qo_heads;
     if (grid > 0x7fffffffull) return QUEST_ETOOLARGE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (kv.page_size == 16)
-        hipLaunchKernelGGL(prefill_kernel<true>, dim3((uint32_t)grid), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(prefill_kernel<false>, dim3((uint32_t)grid), dim3(256), 0, s, p);
+    switch (kv.head_dim) {
+        case 64: launch_prefill<64>(p, (uint32_t)grid, kv.page_size == 16, s); break;
+        case 128: launch_prefill<128>(p, (uint32_t)grid, kv.page_size == 16, s); break;
+        default: launch_prefill<256>(p, (uint32_t)grid, kv.page_size == 16, s); break;
+    }
     QUEST_LAUNCH_CHECK();
     return 0;
 }

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Time of the prefill attention op (quest.utils.prefill_forward -> csrc/prefill.hip, the MFMA flash kernel over the paged
 cache) for a whole prompt and for a 2048-token chunk at the end of it, Llama-2-7B head shapes (and Llama-3.1-8B GQA with
---gqa); beside it torch's fused attention on CONTIGUOUS K/V (is_causal flash backend for the whole prompt; the masked
+--gqa; --head-dim 64 / 256 for the other two built head sizes); beside it torch's fused attention on CONTIGUOUS K/V (is_causal flash backend for the whole prompt; the masked
 memory-efficient backend for the chunk -- what the op was built on until round 5), which does not pay for gathering the
-pages.      python scripts/prefill_bench.py [--gqa] [--lens 4096,16384,32768]"""
+pages.      python scripts/prefill_bench.py [--gqa] [--head-dim D] [--lens 4096,16384,32768]"""
 import math
 import os
 import sys
@@ -15,6 +15,8 @@ import quest_amd.utils as qu  # noqa: E402
 
 dev = torch.device("cuda", 0)
 Hq, D = 32, 128
+if "--head-dim" in sys.argv:
+    D = int(sys.argv[sys.argv.index("--head-dim") + 1])
 Hkv = 8 if "--gqa" in sys.argv else 32
 lens = [4096, 16384, 32768]
 if "--lens" in sys.argv:
@@ -60,7 +62,7 @@ for L in lens:
             mask = torch.arange(L, device=dev).unsqueeze(0) <= (L - n + torch.arange(n, device=dev)).unsqueeze(1)
             ms_t = timed(lambda: sdpa(qh, kh, vh, attn_mask=mask, scale=1 / math.sqrt(D), enable_gqa=Hkv != Hq))
         fl = flops(n, L)
-        print(f"L={L} Hkv={Hkv} {name}: {ms:.3f} ms = {fl / ms / 1e9:.0f} TFLOP/s   (torch SDPA on contiguous K/V: "
+        print(f"L={L} Hkv={Hkv} D={D} {name}: {ms:.3f} ms = {fl / ms / 1e9:.0f} TFLOP/s   (torch SDPA on contiguous K/V: "
               f"{ms_t:.3f} ms = {fl / ms_t / 1e9:.0f} TFLOP/s)", flush=True)
     ctl.end_forward()
     del ctl, k, v, q, kh, vh

@@ -52,13 +52,16 @@ def test_no_d128_attention_instantiation_spills(meta):
 
 
 def test_prefill_kernel_fits_two_workgroups_per_cu(meta):
-    """csrc/prefill.hip is designed around two 4-wave workgroups per CU (two waves of DIFFERENT workgroups per SIMD, whose
-    MFMA and softmax phases overlap): at most 256 VGPRs, no spill, at most half of the CU's 160 KiB of LDS."""
-    hits = {k: v for k, v in meta.items() if "14prefill_kernelILb" in k}
-    assert len(hits) == 2, list(hits)  # 16-token pages; the generic page walk
+    """csrc/prefill.hip is designed around two 4-wave workgroups per CU for head_dim 64 / 128 (two waves of DIFFERENT
+    workgroups per SIMD, whose MFMA and softmax phases overlap): at most 256 VGPRs, at most half of the CU's 160 KiB of
+    LDS; head_dim 256 runs one wave per SIMD.  No instantiation spills."""
+    hits = {k: v for k, v in meta.items() if "14prefill_kernelILi" in k}
+    assert len(hits) == 6, list(hits)  # head_dim 64 / 128 / 256 x (16-token pages, the generic page walk)
     for k, v in hits.items():
         assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
-        assert v["vgpr"] <= 256 and v["lds"] <= 80 * 1024, (k, v)
+        assert v["lds"] <= 80 * 1024, (k, v)
+        if "ILi256E" not in k:
+            assert v["vgpr"] <= 256, (k, v)
 
 
 def test_streaming_kernels_have_no_scratch(meta):

@@ -82,9 +82,30 @@ def test_prefill_vs_oracle(qo, kv, Hq, Hkv, page, layout, causal):
     torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("D", [64, 256])
+@pytest.mark.parametrize("qo,kv,Hq,Hkv,page,layout,causal", [
+    (1, 1, 2, 2, 16, 0, True),
+    (65, 65, 2, 2, 16, 1, True),
+    (200, 1000, 8, 2, 16, 0, True),
+    (333, 333, 3, 3, 16, 0, True),
+    (300, 515, 4, 4, 16, 1, False),
+    (150, 411, 4, 2, 7, 0, True),
+    (257, 640, 4, 1, 31, 1, True),
+])
+def test_prefill_other_head_dims_vs_oracle(D, qo, kv, Hq, Hkv, page, layout, causal):
+    """head_dim 64 (two LDS buffers of 32 KiB, 32-row staging passes) and 256 (one wave per SIMD, ONE buffer and a second
+    barrier per tile, 8-row staging passes): the reference's prefill dispatches 64 / 128 / 256 too (prefill.cuh SWITCH_HEAD_DIM)."""
+    q, k, v = _randn(qo * 7 + kv + D, qo, Hq, D), _randn(kv + 1 + D, kv, Hkv, D), _randn(kv + 2 + D, kv, Hkv, D)
+    ctl = _cache(k, v, Hq, page, layout, seed=qo)
+    o = _prefill(q, ctl, causal)
+    ctl.end_forward()
+    ref = torch_ref.prefill_attention(q.cpu(), k.cpu(), v.cpu(), causal)
+    torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_prefill_fuzz_vs_oracle():
-    """60 seeded random shapes: query rows 1..700, cached tokens up to 2500, 1-9 kv heads x groups 1/2/4, page sizes
-    1..33, both layouts, causal or not -- every combination of ragged query blocks, ragged key tiles and page walks."""
+    """60 seeded random shapes: head_dim 64 / 128 / 256, query rows 1..700, cached tokens up to 2500, 1-9 kv heads x groups
+    1/2/4, page sizes 1..33, both layouts, causal or not -- every combination of ragged query blocks, ragged key tiles and page walks."""
     rng = np.random.default_rng(20250705)
     for case in range(60):
         kv = int(rng.integers(1, 2500))
@@ -92,14 +113,15 @@ def test_prefill_fuzz_vs_oracle():
         Hkv, group = int(rng.integers(1, 10)), int(rng.choice([1, 1, 2, 4]))
         page = int(rng.choice([16, 16, 16, 1, 2, 5, 8, 24, 33]))
         layout, causal = int(rng.integers(0, 2)), bool(rng.integers(0, 4))
-        q = _randn(3 * case, qo, Hkv * group, 128)
-        k, v = _randn(3 * case + 1, kv, Hkv, 128), _randn(3 * case + 2, kv, Hkv, 128)
+        D = int(rng.choice([128, 128, 64, 256]))
+        q = _randn(3 * case, qo, Hkv * group, D)
+        k, v = _randn(3 * case + 1, kv, Hkv, D), _randn(3 * case + 2, kv, Hkv, D)
         ctl = _cache(k, v, Hkv * group, page, layout, seed=case)
         o = _prefill(q, ctl, causal)
         ctl.end_forward()
         ref = torch_ref.prefill_attention(q.cpu(), k.cpu(), v.cpu(), causal)
         torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3,
-                                   msg=lambda m: f"case {case}: qo={qo} kv={kv} Hkv={Hkv} group={group} page={page} "
+                                   msg=lambda m: f"case {case}: D={D} qo={qo} kv={kv} Hkv={Hkv} group={group} page={page} "
                                                  f"layout={layout} causal={causal}: {m}")
 
 

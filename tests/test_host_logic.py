@@ -427,9 +427,9 @@ def test_round3_entry_points_validate_arguments_without_gpu():
     assert pf(one, one, 8, 32, kv, 0, 1, None) == -1
     assert pf(one, one, 50, 32, kv, 4, 1, None) == -1          # 3 * 16 + 1 = 49 cached tokens < 50 rows
     assert pf(one, one, 8, 48, kv, 4, 1, None) == -1           # 48 query heads over 32 kv heads
-    kv64 = PagedKV(data=16, indices=16, indptr=16, num_heads=32, page_size=16, head_dim=64, page_budget=0,
+    kv96 = PagedKV(data=16, indices=16, indptr=16, num_heads=32, page_size=16, head_dim=96, page_budget=0,
                    last_page_len=1, last_page_idx=0, layout=0)
-    assert pf(one, one, 8, 32, kv64, 4, 1, None) == -2
+    assert pf(one, one, 8, 32, kv96, 4, 1, None) == -2         # 64 / 128 / 256 are built
     info = (ctypes.c_uint32 * 6)()
     assert lib.quest_decode_last_launch_info(h, info) == 0 and list(info) == [0] * 6  # nothing launched yet
     assert lib.quest_decode_last_launch_info(None, info) == -1
