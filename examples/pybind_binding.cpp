@@ -111,6 +111,7 @@ torch::Tensor prefill_with_paged_kv_cache(torch::Tensor q, torch::Tensor kv_data
     TORCH_CHECK(q.size(2) == kv_data.size(4), "prefill_with_paged_kv_cache: head_dim of q and kv_data differ");
     TORCH_CHECK(q.scalar_type() == torch::kHalf, "BatchPrefillWithPagedKVCache failed to dispatch with dtype ", q.scalar_type());
     torch::Tensor o = torch::empty_like(q);
+    if (q.size(0) == 0) return o;  // nothing to attend from
     quest_paged_kv_t kv = view(kv_data, kv_indices, kv_indices, kv_last_page_len, 0, layout);
     kv.indptr = nullptr;  // one sequence: the page count travels as a host integer (batch_prefill.cu:41 builds {0, n})
     const int rc = quest_prefill_with_paged_kv_cache(q.data_ptr(), o.data_ptr(), q.size(0), q.size(1), kv, kv_indices.size(0),

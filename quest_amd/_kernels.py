@@ -621,6 +621,8 @@ def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, c
     _check_eq(q.size(2), kv_data.size(4), "q.size(2), kv_data.size(4)")
     _check_half(q, "BatchPrefillWithPagedKVCache")
     o = torch.empty_like(q)
+    if q.size(0) == 0:  # nothing to attend from (the reference launches an empty grid)
+        return o
     kv = _paged(kv_data, kv_indices, None, kv_last_page_len, 0, layout)
     check(lib.quest_prefill_with_paged_kv_cache(q.data_ptr(), o.data_ptr(), q.size(0), q.size(1), kv, kv_indices.size(0),
                                                 1 if causal else 0, _stream(q)), "BatchPrefillWithPagedKVCache")

@@ -202,6 +202,7 @@ def test_prefill_argument_errors():
     ctl = _cache(k, v, 2)
     with pytest.raises(ValueError):  # more causal query rows than cached tokens (test_prefill_attention.py:53-54)
         _prefill(q, ctl)
+    assert _prefill(q[:0], ctl).shape == (0, 2, 128)  # no query rows: an empty result, nothing launched
     o = _prefill(q, ctl, causal=False)  # without the mask any number of rows may look at the cache
     torch.testing.assert_close(o.cpu().float(), torch_ref.prefill_attention(q.cpu(), k.cpu(), v.cpu(), causal=False),
                                rtol=2e-3, atol=2e-3)
