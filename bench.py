@@ -842,6 +842,9 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
     return out
 
 
+_LINE_OUT = None  # the process's real stdout once main() has parked it (see there)
+
+
 def main():
     a = parse()
     if a.kernel_sweep:
@@ -855,6 +858,14 @@ def main():
         return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a.gpus))
+
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner from C
+    # when the first communicator is created): park the real stdout for that line and point fd 1 at stderr for the rest
+    # of the run.
+    global _LINE_OUT
+    sys.stdout.flush()
+    line_out = _LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
 
@@ -968,7 +979,7 @@ def main():
             raise
     finally:
         if out is not None:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=line_out, flush=True)
 
 
 if __name__ == "__main__":
@@ -976,5 +987,5 @@ if __name__ == "__main__":
         main()
     except Exception as exc:  # one machine-readable line for whoever parses stdout, then the traceback as usual
         if os.environ.get("RANK", "0") == "0":
-            print(json.dumps({"error": f"{type(exc).__name__}: {exc}", "rank": 0}), flush=True)
+            print(json.dumps({"error": f"{type(exc).__name__}: {exc}", "rank": 0}), file=_LINE_OUT or sys.stdout, flush=True)
         raise
