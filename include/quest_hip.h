@@ -424,8 +424,8 @@ int quest_rms_norm_forward(const void* input, const void* weight, void* output, 
  * n_pages_host pages kv.indices lists, the last one holding kv.last_page_len tokens.  Row i attends the keys
  * 0 .. kv_len - n_q + i when `causal`, every key otherwise; no rotary (RotaryMode::kNone, batch_prefill.cu:101),
  * softmax scale 1/sqrt(head_dim).  GQA: num_qo_heads a multiple of kv.num_heads, query head h reads kv head
- * h / (num_qo_heads / kv.num_heads).  head_dim 64 / 128 / 256 (the reference's SWITCH_HEAD_DIM set), any page_size, both
- * layouts; QUEST_EUNSUPPORTED otherwise;
+ * h / (num_qo_heads / kv.num_heads).  head_dim 64 / 128 / 256 (the set of the reference's SWITCH_HEAD_DIM_PREFILL,
+ * prefill.cuh:1073), any page_size, both layouts; QUEST_EUNSUPPORTED otherwise;
  * causal with n_q > kv_len is QUEST_EINVAL (the reference assumes kv_len >= qo_len, test_prefill_attention.py:53-54).
  * MFMA flash kernel (csrc/prefill.hip): 128 query rows per workgroup, 64-key tiles, nothing but o is written.
  */

@@ -6,7 +6,8 @@
 // j <= kv_len - n + i (causal; every key otherwise) of the sequence whose pages `indices` lists; the new tokens' K/V are
 // already in the cache (utils/__init__.py:127-170), no rotary (RotaryMode::kNone, batch_prefill.cu:101), fp16 in/out.
 //
-// Shape of the kernel (gfx950; head_dim 64 / 128 / 256 as in the reference's SWITCH_HEAD_DIM, the text below is for 128): a
+// Shape of the kernel (gfx950; head_dim 64 / 128 / 256, the set of the reference's SWITCH_HEAD_DIM_PREFILL,
+// prefill.cuh:1073 -- the macro itself lives in the absent flashinfer submodule; the text below is for 128): a
 // workgroup = 4 waves = 128 query rows of one query head; a wave owns 32 of them.  Per
 // 64-key tile a wave computes the TRANSPOSED scores S^T = K Q^T with v_mfma_f32_32x32x16_f16 (K rows from LDS as the A
 // operand, its Q rows -- loaded once, 32 registers -- as B): a 32x32 result has its column, i.e. the QUERY, on the lane
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_kernel(const Pr
     const bool wave_live = q0w < p.n_q;
 
     // Q^T fragments (B operand): lane (r, h) holds q[row r][16 s + 8 h ..] of k-step s.  Unscaled: the reference folds
-    // log2(e) / sqrt(D) into q in fp16 (prefill.cuh:744), which rounds every score by up to 2^-11 of its terms -- 4e-3 of
+    // log2(e) / sqrt(D) into q in fp16 (prefill.cuh:758), which rounds every score by up to 2^-11 of its terms -- 4e-3 of
     // an output once |score| reaches ~100; here the factor multiplies the fp32 score on its way into the exponent.
     // Rows past the end of q repeat the last row (computed, never stored).
     half8 qf[D / 16];

@@ -94,7 +94,7 @@ def test_prefill_vs_oracle(qo, kv, Hq, Hkv, page, layout, causal):
 ])
 def test_prefill_other_head_dims_vs_oracle(D, qo, kv, Hq, Hkv, page, layout, causal):
     """head_dim 64 (two LDS buffers of 32 KiB, 32-row staging passes) and 256 (one wave per SIMD, ONE buffer and a second
-    barrier per tile, 8-row staging passes): the reference's prefill dispatches 64 / 128 / 256 too (prefill.cuh SWITCH_HEAD_DIM)."""
+    barrier per tile, 8-row staging passes): the reference's prefill dispatches 64 / 128 / 256 too (prefill.cuh:1073 SWITCH_HEAD_DIM_PREFILL)."""
     q, k, v = _randn(qo * 7 + kv + D, qo, Hq, D), _randn(kv + 1 + D, kv, Hkv, D), _randn(kv + 2 + D, kv, Hkv, D)
     ctl = _cache(k, v, Hq, page, layout, seed=qo)
     o = _prefill(q, ctl, causal)
