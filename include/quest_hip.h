@@ -422,11 +422,11 @@ int quest_rms_norm_forward(const void* input, const void* weight, void* output, 
  * kernels/include/prefill/prefill.cuh:1008-1119, kernel :688-882).  q, o: [n_q][num_qo_heads][head_dim] fp16; the
  * sequence's K/V (the n_q new tokens included: append_kv_cache_prefill ran before, utils/__init__.py:127-170) are the
  * n_pages_host pages kv.indices lists, the last one holding kv.last_page_len tokens.  Row i attends the keys
- * 0 .. kv_len - n_q + i when `causal`, every key otherwise; no rotary (RotaryMode::kNone, batch_prefill.cu:101),
+ * 0 .. kv_len - n_q + i when `causal`, every key otherwise; no rotary (RotaryMode::kNone, batch_prefill.cu:102),
  * softmax scale 1/sqrt(head_dim).  GQA: num_qo_heads a multiple of kv.num_heads, query head h reads kv head
  * h / (num_qo_heads / kv.num_heads).  head_dim 64 / 128 / 256 (the set of the reference's SWITCH_HEAD_DIM_PREFILL,
  * prefill.cuh:1073), any page_size, both layouts; QUEST_EUNSUPPORTED otherwise;
- * causal with n_q > kv_len is QUEST_EINVAL (the reference assumes kv_len >= qo_len, test_prefill_attention.py:53-54).
+ * causal with n_q > kv_len is QUEST_EINVAL (the reference assumes kv_len >= qo_len, test_prefill_attention.py:50-51).
  * MFMA flash kernel (csrc/prefill.hip): 128 query rows per workgroup, 64-key tiles, nothing but o is written.
  */
 int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_t n_q, uint32_t num_qo_heads,

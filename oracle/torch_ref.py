@@ -91,7 +91,7 @@ def sparse_decode(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, page_size: 
 def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = True,
                       dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """Attention of ``qo_len`` query rows ``[qo_len, Hq, D]`` over ``kv_len >= qo_len`` cached tokens ``[kv_len, Hkv, D]``;
-    row i sees keys ``0 .. kv_len - qo_len + i`` when ``causal`` (test_prefill_attention.py:35-36).  GQA: query head h
+    row i sees keys ``0 .. kv_len - qo_len + i`` when ``causal`` (test_prefill_attention.py:38-39).  GQA: query head h
     reads kv head ``h // (Hq // Hkv)`` (evaluation/quest_attention.py:139-184's repeat_kv).  Returns ``[qo_len, Hq, D]``
     in ``dtype``."""
     qo_len, Hq, D = q.shape

@@ -609,7 +609,7 @@ def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, c
     One launch of the MFMA flash kernel of csrc/prefill.hip straight over the page table: no gathered K/V copy, no mask
     tensor, whole prompt and chunked prefill alike, GQA by head index.  ``allow_fp16_qk_reduction`` asks the reference
     for fp16 score accumulation on RTX 4090 (utils/__init__.py:165); scores accumulate in fp32 here either way.  The
-    rotary arguments are unused, as in the reference (RotaryMode::kNone, batch_prefill.cu:101).  Returns a new tensor
+    rotary arguments are unused, as in the reference (RotaryMode::kNone, batch_prefill.cu:102).  Returns a new tensor
     (batch_prefill.cu:73)."""
     _check_input(q, "q")
     _check_input(kv_data, "kv_data")

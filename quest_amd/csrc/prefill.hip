@@ -4,7 +4,7 @@
 //
 // What the reference computes (restated, not translated): o[i] = softmax_j(q[i] . k[j] / sqrt(D)) v[j] over the keys
 // j <= kv_len - n + i (causal; every key otherwise) of the sequence whose pages `indices` lists; the new tokens' K/V are
-// already in the cache (utils/__init__.py:127-170), no rotary (RotaryMode::kNone, batch_prefill.cu:101), fp16 in/out.
+// already in the cache (utils/__init__.py:127-170), no rotary (RotaryMode::kNone, batch_prefill.cu:102), fp16 in/out.
 //
 // Shape of the kernel (gfx950; head_dim 64 / 128 / 256, the set of the reference's SWITCH_HEAD_DIM_PREFILL,
 // prefill.cuh:1073 -- the macro itself lives in the absent flashinfer submodule; the text below is for 128): a
@@ -328,7 +328,7 @@ extern "C" int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_
     if (num_qo_heads % kv.num_heads != 0) return QUEST_EINVAL;
     if (kv.head_dim != 64 && kv.head_dim != 128 && kv.head_dim != 256) return QUEST_EUNSUPPORTED;
     const uint64_t kv_len = (uint64_t)(n_pages_host - 1) * kv.page_size + kv.last_page_len;
-    // causal rows are the LAST n_q tokens of the sequence: the reference assumes kv_len >= qo_len (test_prefill_attention.py:53)
+    // causal rows are the LAST n_q tokens of the sequence: the reference assumes kv_len >= qo_len (test_prefill_attention.py:50)
     if (kv_len > 0x7fffffffull || (causal && n_q > kv_len)) return QUEST_EINVAL;
     PrefillParams p;
     p.q = static_cast<const half_t*>(q);

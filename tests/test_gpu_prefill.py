@@ -200,7 +200,7 @@ def test_prefill_argument_errors():
 
     q, k, v = _randn(1, 40, 2, 128), _randn(2, 30, 2, 128), _randn(3, 30, 2, 128)
     ctl = _cache(k, v, 2)
-    with pytest.raises(ValueError):  # more causal query rows than cached tokens (test_prefill_attention.py:53-54)
+    with pytest.raises(ValueError):  # more causal query rows than cached tokens (test_prefill_attention.py:50-51)
         _prefill(q, ctl)
     assert _prefill(q[:0], ctl).shape == (0, 2, 128)  # no query rows: an empty result, nothing launched
     o = _prefill(q, ctl, causal=False)  # without the mask any number of rows may look at the cache
