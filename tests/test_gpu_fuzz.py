@@ -1,6 +1,8 @@
 """Seeded random sweep of shapes through the whole chain -- unfused ops, fused launches and the state-driven
 (graph-replayable) launches -- against the CPU oracle: pools / estimates / selections bit-exact, attention
 within the attention tolerance.  Complements the hand-picked cases of test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -29,7 +31,8 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(48, 2025), ids=lambda c: "Hq%d_Hkv%d_D%d_S%d_L%d_B%d_lay%d" % c[:7])
+# soak: QUEST_FUZZ_CASES=600 QUEST_FUZZ_SEED=7 pytest tests/test_gpu_fuzz.py
+@pytest.mark.parametrize("case", _cases(int(os.environ.get("QUEST_FUZZ_CASES", "48")), int(os.environ.get("QUEST_FUZZ_SEED", "2025"))), ids=lambda c: "Hq%d_Hkv%d_D%d_S%d_L%d_B%d_lay%d" % c[:7])
 def test_random_shape_chain_matches_oracle(case):
     import quest_amd.utils as qu
 

@@ -106,8 +106,8 @@ def test_prefill_other_head_dims_vs_oracle(D, qo, kv, Hq, Hkv, page, layout, cau
 def test_prefill_fuzz_vs_oracle():
     """60 seeded random shapes: head_dim 64 / 128 / 256, query rows 1..700, cached tokens up to 2500, 1-9 kv heads x groups
     1/2/4, page sizes 1..33, both layouts, causal or not -- every combination of ragged query blocks, ragged key tiles and page walks."""
-    rng = np.random.default_rng(20250705)
-    for case in range(60):
+    rng = np.random.default_rng(int(os.environ.get("QUEST_FUZZ_SEED", "20250705")))  # soak: QUEST_FUZZ_CASES=600 QUEST_FUZZ_SEED=7
+    for case in range(int(os.environ.get("QUEST_FUZZ_CASES", "60"))):
         kv = int(rng.integers(1, 2500))
         qo = int(rng.integers(1, min(kv, 700) + 1))
         Hkv, group = int(rng.integers(1, 10)), int(rng.choice([1, 1, 2, 4]))
