@@ -21,7 +21,9 @@ tried and is slower, +16 % -- the RCCL kernel then runs beside the step's kernel
 
 One JSON line on stdout (rank 0).  Extra objects: "roofline" (the dominant kernel OF THE TIMED STEP:
 sparse_decode_kernel with its top-k front end; algorithmic bytes / HIP-event launch time) and
-"cpu_baseline" (oracle/torch_ref eager port timed on the host cores, bounded sample).
+"cpu_baseline" (oracle/torch_ref eager port timed on the host cores, bounded sample).  Side objects of the default N = 1 run,
+measured after the headline and outside `value`: "batched_8seq", "cfg5_8seq_gqa" (8 sequences per GPU) and
+"prefill_attention" (the prefill operator on the headline shapes: the MFMA kernel's TFLOP/s against the dense fp16 peak).
 """
 import argparse
 import datetime
@@ -842,6 +844,45 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
     return out
 
 
+def prefill_side(a, dev):
+    """Side object of the default N = 1 run: the prefill attention operator (prefill_with_paged_kv_cache -> the MFMA flash
+    kernel of csrc/prefill.hip) on the headline's shapes -- the whole seqlen-token prompt of one layer, causal, straight
+    over the paged cache -- timed with events on the launch stream.  MFMA-bound: flops = 4 D per visible (query, key) pair
+    and head; peak = the dense fp16 matrix peak of MI355X_MICROARCH.md.  Not part of `value`."""
+    import torch
+
+    import quest_amd.utils as qu
+
+    L, Hq, Hkv, D = a.seqlen, a.heads, a.kv_heads, a.head_dim
+    ctl = qu.InferenceController(1, Hq, D, a.page_size, 128, L + 4 * a.page_size, torch.float16, dev, num_kv_heads=Hkv)
+    g = torch.Generator(device=dev).manual_seed(a.seed)
+    k = torch.randn(L, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    v = torch.randn(L, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    q = torch.randn(L, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    ctl.prepare_metadata(L)
+    ctl.begin_forward(L)
+    qu.append_kv(k, v, ctl, 0)
+    del k, v
+    o = qu.prefill_forward(q, ctl, 0)
+    torch.cuda.synchronize()
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        o = qu.prefill_forward(q, ctl, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    ctl.end_forward()
+    ms = e0.elapsed_time(e1) / reps
+    assert torch.isfinite(o[-1].float()).all()
+    flops = 4.0 * D * Hq * (L * L - (L * (L - 1)) // 2)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"workload": f"prefill attention of one layer, causal, {L} tokens x {Hq} heads x {D} (kv heads {Hkv}), paged cache",
+            "kernel": f"prefill_kernel<{D},{'true' if a.page_size == 16 else 'false'}>", "launches": reps, "ms": ms,
+            "flops": flops, "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0},
+            "note": "measured after the headline timing in the same process; not part of `value`"}
+
+
 _LINE_OUT = None  # the process's real stdout once main() has parked it (see there)
 
 
@@ -969,6 +1010,12 @@ def main():
                                 "tokens_per_s is the aggregate over all ranks, the fractions are per GPU (rank 0's)"
                                 if dist is not None else "")),
                 }
+        if (dist is None and out is not None and not stub and not a.no_side and a.config == 3
+                and "custom" not in a.workload_label):
+            try:
+                out["prefill_attention"] = prefill_side(a, dev)
+            except Exception as exc:  # never at the cost of the headline line
+                out["prefill_attention"] = {"error": f"{type(exc).__name__}: {exc}"}
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
