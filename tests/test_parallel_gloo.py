@@ -80,6 +80,9 @@ def test_bench_launcher_starts_n_ranks_and_reports_world_size():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # ... and nothing else: whatever libraries print (RCCL writes a version banner to the process's stdout from C when
+    # its first communicator is created) is sent to stderr, the driver parses stdout
+    assert r.stdout.strip() == lines[0], r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["world_size_seen"] == 2 and out["config"]["gpus_requested"] == 2
     assert out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak" and out["data"] == "stub"
