@@ -233,7 +233,9 @@ int quest_decode_forward_fused_topk_dyn(quest_decode_handler_t* h, const void* q
  * selection, same outputs as quest_append_estimate_dyn + quest_decode_forward_fused_topk_dyn.
  * tile_max_offset must be max_n rounded up to 8 columns; rows 16-byte aligned with
  * stride >= tile_max_offset + ceil(max_n / 8) rounded up to 4.  Plans with at most 256 selected pages, page_size 16, rows
- * up to 16384 pages; QUEST_EUNSUPPORTED otherwise.
+ * up to 16384 pages; QUEST_EUNSUPPORTED otherwise.  The estimate side needs its workgroup tile to be a multiple of 8 pages
+ * wide (head_dim 256: the tile covers 4 kv heads instead of 8); a shape for which no such tile exists returns
+ * QUEST_EUNSUPPORTED before anything is launched, and the caller takes quest_append_estimate_dyn instead.
  */
 int quest_append_estimate_tiles_dyn(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
                                     uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out, uint32_t tile_max_offset,

@@ -425,7 +425,9 @@ def append_estimate_dyn(k, v, kv_data, kv_table, q, o, metadata_data, meta_table
     """append_estimate whose lengths / last-page ids / n_out come from ``state``; ``o`` is ``[Hq, stride]``.
     ``tiles``: also store the rows' tile maxima (per 8 pages the largest score, as a 16-bit key) at column
     ``tile_max_offset(max_n_out)`` -- ``o`` must be ``[Hq, >= tiles_row_stride(max_n_out)]``; returns False (nothing
-    launched) where the estimate's tile is not 8 pages wide."""
+    launched) for QUEST_EUNSUPPORTED: no estimate tile of this shape is a multiple of 8 pages wide (checked before the
+    launch, ``csrc/estimate.hip`` ``launch_estimate``), or the group size / head_dim has no instantiation at all -- the
+    caller's whole-row launch (``tiles=False``) then raises for the latter."""
     for t, n in ((k, "k"), (v, "v"), (kv_data, "kv_data"), (kv_table, "kv_table"), (q, "q"), (o, "o"),
                  (metadata_data, "metadata_data"), (meta_table, "meta_table"), (state, "state")):
         _check_input(t, n)

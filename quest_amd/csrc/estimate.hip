@@ -72,7 +72,14 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     constexpr uint32_t ROWS = kEstWaves * est_iter<G>() * R;
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
     if (!tail.state && tail.o_stride == 0) tail.o_stride = n_out;  // contiguous rows unless the caller pads them
-    const uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec), ew = ROWS / hw;
+    uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec);
+    // Tile maxima are one key per run of 8 consecutive columns of ONE query head, taken from 8 consecutive lanes of the
+    // score store loop: a tile must be a multiple of 8 entries wide.  head_dim 256 has 32-row tiles, so 8 heads per tile
+    // would leave 4 entries (two heads' scores in one 8-lane run): narrow the tile's head range instead, and refuse
+    // what still does not fit -- before anything is launched (the callers then take the whole-row launches).
+    while (tail.tile_off && hw > 1 && (ROWS / hw) % 8u != 0) hw >>= 1;
+    const uint32_t ew = ROWS / hw;
+    if (tail.tile_off && ew % 8u != 0) return QUEST_EUNSUPPORTED;
     tail.tile_heads = hw;
     tail.tile_log2 = (uint32_t)__builtin_ctz(hw);
     tail.est_blocks = ((n_out + ew - 1) / ew) * (meta.num_heads / hw);

@@ -122,8 +122,10 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     uint16_t* keys_s = reinterpret_cast<uint16_t*>(layer_dyn);
     int32_t* ids_s = reinterpret_cast<int32_t*>(layer_dyn + p.ids_lds_offset);
 
-    // the sequence's page table -> LDS (n_cap + 1 entries; addresses depend on the capacity only: clamped, unconditional)
-    const uint32_t n_cap = a_n_cap, table_len = n_cap + 1u;
+    // the sequence's page table -> LDS: the n_cap entries a selected COLUMN can name (columns < n <= n_cap; the current page,
+    // table entry n, comes from the step state, never from LDS) -- n_cap <= FC * NT by the host's check, so FC rounds cover
+    // it; addresses depend on the capacity only: clamped, unconditional
+    const uint32_t n_cap = a_n_cap, table_len = n_cap;
     int32_t iraw[FC];
     const uint32_t id_rounds = (table_len + NT - 1) / NT;
 #pragma unroll

@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_kernel(const Pr
             // key 0 is visible to every query, so tile 0 gives every row a finite reference (NaN in, NaN out)
             if (t == 0 || __builtin_amdgcn_ballot_w64(g - m_ref > defer)) {
                 const float m_new = t == 0 ? g : __builtin_fmaxf(m_ref, g);
-                const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * c);
+                // tile 0 has nothing to move (l and O are still zero): alpha = 1 -- exp2((0 - g) c) overflows to +inf for a row
+                // whose first-tile maximum is below about -128 log2 units, and 0 x inf would turn the whole row into NaN
+                const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f((m_ref - m_new) * c);
                 m_ref = m_new;
                 l *= alpha;
 #pragma unroll

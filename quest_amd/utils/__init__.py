@@ -284,7 +284,12 @@ def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bCon
     append+estimate | top-k+attention; True / False force one of them (True raises where the one-launch form does not
     apply).  Both produce the same pool bytes, selections and outputs.
     ``write_scores``: the one-launch form also writes its page scores to ``scores`` (inspection; they otherwise never
-    leave the CU)."""
+    leave the CU).
+
+    NOTE -- ``scores`` after the call: only the TWO-launch form fills it.  Where the one-launch form runs (the default for
+    MHA batches that fill the chip) ``scores`` keeps whatever it held before unless ``write_scores=True``; code that reads
+    the scratch after this call must pass ``write_scores=True`` or ``one_launch=False``.  Which form ran is left in
+    ``bController.last_layer_launches`` (1 or 2)."""
     b = bController
     _need_state(b)
     if apply_rope:
@@ -296,6 +301,7 @@ def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bCon
         if b._decode_handler.layer_fused_batched(k, v, b.metadata_layer(layer_idx), b.meta_tables, q, o, b.kv_layer(layer_idx),
                                                  b.kv_tables, b.step_states, max_n, b.page_budgets,
                                                  scores if write_scores else None):
+            b.last_layer_launches = 1
             return o
         if one_launch:
             raise RuntimeError("the one-launch layer does not serve this plan / shape (needs one workgroup per head, "
@@ -305,6 +311,7 @@ def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bCon
     o = torch.empty_like(q) if out is None else out
     b._decode_handler.forward_fused_topk_batched(q, o, b.kv_layer(layer_idx), b.kv_tables, scores, b.step_states, max_n,
                                                  b.page_budgets)
+    b.last_layer_launches = 2
     return o
 
 

@@ -170,7 +170,10 @@ def test_tiles_front_end_selects_the_oracles_pages(n_pages, k, kind):
         assert torch.equal(o, o2)
 
 
-@pytest.mark.parametrize("Hq,Hkv,D,L0,B", [(8, 2, 128, 16 * 300 + 9, 20), (4, 4, 128, 16 * 130 + 16, 33), (8, 8, 64, 16 * 75 + 1, 9)])
+@pytest.mark.parametrize("Hq,Hkv,D,L0,B", [(8, 2, 128, 16 * 300 + 9, 20), (4, 4, 128, 16 * 130 + 16, 33), (8, 8, 64, 16 * 75 + 1, 9),
+                                           # head_dim 256 with kv heads in multiples of 8: the estimate's 32-row tile
+                                           # used to be 8 heads x 4 pages there and the tile maxima mixed two heads' scores
+                                           (8, 8, 256, 16 * 90 + 5, 17), (16, 8, 256, 16 * 70 + 16, 12), (16, 16, 256, 16 * 40 + 3, 7)])
 def test_tiles_launches_equal_the_whole_row_launches_while_the_sequence_grows(Hq, Hkv, D, L0, B):
     """decode_layer_dyn with the tiles launches forced (the estimate writes the tile maxima, the attention launch selects
     from them) against the same step through the whole-row launches, token after token across KV-page and metadata-page

@@ -169,6 +169,34 @@ def test_prefill_row_maximum_that_keeps_growing(pattern):
     torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3)
 
 
+def test_prefill_first_tile_with_strongly_negative_scores():
+    """the first key tile used to rescale from the initial reference 0 to the tile's maximum g with
+    alpha = exp2((0 - g) c); a row whose largest first-tile score is below about -128 log2 units (head_dim 128: q.k < -1004)
+    overflowed alpha to +inf and 0 x inf made the whole row NaN.  Every query here is anti-aligned with the first 64+ keys
+    (q.k ~ -2000 ... -4000); causal row 0 sees key 0 only."""
+    qo = kv = 200
+    H = 2
+    b = _randn(31, 1, H, 128).float() * 4
+    q = (b + _randn(32, qo, H, 128).float() * 0.2).half()
+    k = _randn(33, kv, H, 128)
+    k[:100] = (-b * torch.linspace(1.0, 2.0, 100, device=DEV).view(100, 1, 1)).half()
+    v = _randn(34, kv, H, 128)
+    for causal in (True, False):
+        ctl = _cache(k, v, H)
+        o = _prefill(q, ctl, causal)
+        ctl.end_forward()
+        assert torch.isfinite(o.float()).all(), f"causal={causal}: non-finite output rows"
+        ref = torch_ref.prefill_attention(q.cpu(), k.cpu(), v.cpu(), causal)
+        torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3)
+    # a chunk whose rows all see ONLY strongly negative keys (the whole sequence is anti-aligned)
+    k2 = (-b * torch.linspace(1.0, 1.5, kv, device=DEV).view(kv, 1, 1)).half()
+    ctl = _cache(k2, v, H)
+    o = _prefill(q[-70:], ctl)
+    ctl.end_forward()
+    ref = torch_ref.prefill_attention(q[-70:].cpu(), k2.cpu(), v.cpu())
+    torch.testing.assert_close(o.cpu().float(), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_prefill_full_size_properties():
     """Llama-2-7B head shapes at 4096 and a 2048-row chunk after a 6144-token prefix: (i) chunked == whole on the same
     rows (different tile counts per row block, different dispatch order); (ii) spot rows against the fp32 oracle;
