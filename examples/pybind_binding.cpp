@@ -35,7 +35,7 @@ static quest_paged_kv_t view(const torch::Tensor& data, const torch::Tensor& ind
 
 static quest_stream_t stream() { return (quest_stream_t)at::hip::getCurrentHIPStream().stream(); }
 
-// bsk_ops.h:25-29
+// bsk_ops.h:23-27
 void apply_rope_in_place(torch::Tensor q, torch::Tensor k, unsigned int past_kv_len, float rope_scale,
                          float rope_theta) {
     int rc = quest_apply_rope_in_place(q.data_ptr(), k.data_ptr(), q.size(0), past_kv_len, q.size(1), k.size(1),
@@ -43,7 +43,7 @@ void apply_rope_in_place(torch::Tensor q, torch::Tensor k, unsigned int past_kv_
     TORCH_CHECK(rc == 0, "apply_rope_in_place failed with error code ", quest_error_string(rc));
 }
 
-// bsk_ops.h:31-34; input [1][rows][cols]
+// bsk_ops.h:29-32; input [1][rows][cols]
 void rms_norm_forward(torch::Tensor input, torch::Tensor weight, torch::Tensor output, float epsilon) {
     const auto cols = input.size(-1);
     int rc = quest_rms_norm_forward(input.data_ptr(), weight.data_ptr(), output.data_ptr(), input.numel() / cols, cols,
@@ -51,7 +51,7 @@ void rms_norm_forward(torch::Tensor input, torch::Tensor weight, torch::Tensor o
     TORCH_CHECK(rc == 0, "rms_norm_forward failed with error code ", quest_error_string(rc));
 }
 
-// bsk_ops.h:38-43
+// bsk_ops.h:34-39
 void topk_filtering(torch::Tensor estimated_value, torch::Tensor estimated_indices, torch::Tensor d_out,
                     torch::Tensor indices_out, torch::Tensor buf, unsigned int page_budget) {
     int rc = quest_topk_filtering(estimated_value.data_ptr(), static_cast<const int32_t*>(estimated_indices.data_ptr()),
@@ -60,7 +60,7 @@ void topk_filtering(torch::Tensor estimated_value, torch::Tensor estimated_indic
     TORCH_CHECK(rc == 0, "topk_filtering failed with error code ", quest_error_string(rc));
 }
 
-// bsk_ops.h:45-52
+// bsk_ops.h:41-48
 void estimate_attn_score(torch::Tensor q, torch::Tensor o, torch::Tensor metadata_data, torch::Tensor metadata_indices,
                          torch::Tensor metadata_indptr, unsigned int metadata_last_page_len,
                          unsigned int metadata_last_page_idx, unsigned int layout) {
@@ -71,7 +71,7 @@ void estimate_attn_score(torch::Tensor q, torch::Tensor o, torch::Tensor metadat
     TORCH_CHECK(rc == 0, "Estimate_attn_score failed with error code ", quest_error_string(rc));
 }
 
-// bsk_ops.h:56-68
+// bsk_ops.h:50-62
 void append_kv_cache_prefill(torch::Tensor k, torch::Tensor v, torch::Tensor kv_data, torch::Tensor kv_indices,
                              torch::Tensor kv_indptr, unsigned int kv_last_page_len, unsigned int kv_last_page_idx,
                              torch::Tensor metadata_data, torch::Tensor metadata_indices, torch::Tensor metadata_indptr,
@@ -85,7 +85,7 @@ void append_kv_cache_prefill(torch::Tensor k, torch::Tensor v, torch::Tensor kv_
     TORCH_CHECK(rc == 0, "Append_kv_cache_prefill failed with error code ", quest_error_string(rc));
 }
 
-// bsk_ops.h:70-82
+// bsk_ops.h:64-76
 void append_kv_cache_decode(torch::Tensor k, torch::Tensor v, torch::Tensor kv_data, torch::Tensor kv_indices,
                             torch::Tensor kv_indptr, unsigned int kv_last_page_len, unsigned int kv_last_page_idx,
                             torch::Tensor metadata_data, torch::Tensor metadata_indices, torch::Tensor metadata_indptr,
@@ -121,7 +121,7 @@ torch::Tensor prefill_with_paged_kv_cache(torch::Tensor q, torch::Tensor kv_data
     return o;
 }
 
-// bsk_ops.h:94-116: the handler class over quest_decode_handler_t
+// bsk_ops.h:88-117: the handler class over quest_decode_handler_t
 class BatchDecodeWithPagedKVCachePyTorchWrapper {
 public:
     static BatchDecodeWithPagedKVCachePyTorchWrapper Create(unsigned int layout) {

@@ -66,7 +66,7 @@ const char* quest_error_string(int code);
 const char* quest_build_info(void);
 
 /*
- * append_kv_cache_decode (bsk_ops.h:70-82, page.cu:6-99 -> AppendPagedKVCacheDecode,
+ * append_kv_cache_decode (bsk_ops.h:64-76, page.cu:6-99 -> AppendPagedKVCacheDecode,
  * decode_page.cuh:577-597, kernel :398-449).
  * k, v: [1][num_heads][head_dim].  Writes the token into the last page and folds k into the
  * page's (max -> K slot, min -> V slot) metadata entry, re-initialising it to -/+65504 when the
@@ -76,7 +76,7 @@ int quest_append_kv_cache_decode(const void* k, const void* v, quest_paged_kv_t 
                                  quest_paged_kv_t metadata, quest_stream_t stream);
 
 /*
- * append_kv_cache_prefill (bsk_ops.h:56-68, page.cu:101-210 -> AppendPagedKVCachePrefill,
+ * append_kv_cache_prefill (bsk_ops.h:50-62, page.cu:101-210 -> AppendPagedKVCachePrefill,
  * decode_page.cuh:613-642, kernel :471-562).  k, v: [append_len][num_heads][head_dim];
  * n_pages_host = number of pages of the sequence (the host knows it: len(kv_indices)).
  */
@@ -85,7 +85,7 @@ int quest_append_kv_cache_prefill(const void* k, const void* v, uint32_t append_
                                   quest_paged_kv_t metadata, quest_stream_t stream);
 
 /*
- * estimate_attn_score (bsk_ops.h:45-52, estimate.cu:6-84 -> MaxPossibleSampleWithPagedKVCache,
+ * estimate_attn_score (bsk_ops.h:41-48, estimate.cu:6-84 -> MaxPossibleSampleWithPagedKVCache,
  * decode_attn.cuh:1092-1149, kernel :245-401).
  * q: [1][num_qo_heads][head_dim]; o: [num_qo_heads][n_out] fp16 with n_out = (number of KV
  * pages) - 1; o[h][p] = fp16( sum_d max(q*Kmax, q*Kmin) ).
@@ -109,7 +109,7 @@ int quest_append_estimate_strided(const void* k, const void* v, quest_paged_kv_t
                                   quest_stream_t stream);
 
 /*
- * topk_filtering (bsk_ops.h:38-43, topk.cu:7-46 -> decode_select_k, decode_select_k.cuh:25-62,
+ * topk_filtering (bsk_ops.h:34-39, topk.cu:7-46 -> decode_select_k, decode_select_k.cuh:25-62,
  * which calls RAFT's radix_topk_one_block_kernel; re-implemented here).
  * estimated_value/indices: [num_heads][num_pages]; d_out/indices_out: [num_heads][page_budget].
  * Deterministic: ties at the k-th value go to the lowest column; output in ascending column order.
@@ -126,7 +126,7 @@ int quest_topk_filtering_strided(const void* estimated_value, uint32_t value_str
                                  uint32_t page_budget, quest_stream_t stream);
 
 /*
- * BatchDecodeWithPagedKVCachePyTorchWrapper (bsk_ops.h:84-116, approx_attn.cu:27-150 ->
+ * BatchDecodeWithPagedKVCachePyTorchWrapper (bsk_ops.h:88-117, approx_attn.cu:27-150 ->
  * BatchDecodeHandler, decode_handler.cuh:39-244).
  */
 typedef struct quest_decode_handler quest_decode_handler_t;
@@ -292,7 +292,7 @@ typedef struct quest_batch {
     uint32_t meta_table_stride; /* ... metadata page tables */
     uint32_t reserved;
     /* Optional per-sequence page budgets, device int32[n_seqs]: pages sequence i attends INCLUDING its current page
-     * (the reference's per-request page budget: InferenceController.set_page_budget, quest/utils/controller.py:39-41,
+     * (the reference's per-request page budget: InferenceController.set_page_budget, quest/utils/controller.py:66-68,
      * one controller per request).  NULL: every sequence takes the budget the handler was planned with.  With
      * budgets, plan the handler (begin_forward) with the LARGEST one; sequence i then selects
      * min(budget[i] - 1, its pages - 1) pages. */
@@ -345,7 +345,7 @@ int quest_decode_layer_fused_batched(quest_decode_handler_t* h, const void* k, c
                                      void* scores_out, uint32_t score_stride, float* lse, quest_stream_t stream);
 /*
  * The four operators of a decode step one by one for a whole batch (the state-driven counterparts of
- * append_kv_cache_decode / estimate_attn_score / topk_filtering / BatchDecodeWithPagedKVCache.forward, bsk_ops.h:38-116,
+ * append_kv_cache_decode / estimate_attn_score / topk_filtering / BatchDecodeWithPagedKVCache.forward, bsk_ops.h:34-117,
  * as quest/utils/__init__.py:141-276 calls them per request): quest_append_kv_cache_decode_batched above, and
  *   estimate : o[n_seqs][num_qo_heads][o_stride], row i scored over state[i].n_pages - 1 pages;
  *   top-k    : per (sequence, head) the k_i = min(budget_i - 1, n_pages_i - 1) largest scores of the row and the
@@ -408,14 +408,14 @@ int quest_decode_set_front_end(quest_decode_handler_t* h, int generation);
 int quest_decode_set_pages_per_chunk(quest_decode_handler_t* h, uint32_t pages_per_chunk);
 
 /*
- * apply_rope_in_place (bsk_ops.h:25-29, page.cu:212-252 -> QKApplyRotaryInPlace,
+ * apply_rope_in_place (bsk_ops.h:23-27, page.cu:212-252 -> QKApplyRotaryInPlace,
  * decode_page.cuh:695-728).  q: [n][num_qo_heads][dim], k: [n][num_kv_heads][dim], in place.
  */
 int quest_apply_rope_in_place(void* q, void* k, uint32_t n, uint32_t past_kv_len,
                               uint32_t num_qo_heads, uint32_t num_kv_heads, uint32_t head_dim,
                               float rope_scale, float rope_theta, quest_stream_t stream);
 
-/* rms_norm_forward (bsk_ops.h:31-34, rms_norm.cu:160-212). input/output: [rows][cols], weight [cols]. */
+/* rms_norm_forward (bsk_ops.h:29-32, rms_norm.cu:160-212). input/output: [rows][cols], weight [cols]. */
 int quest_rms_norm_forward(const void* input, const void* weight, void* output, uint32_t rows,
                            uint32_t cols, float epsilon, quest_stream_t stream);
 
@@ -438,7 +438,7 @@ int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_t n_q, uint
 /*
  * Decode-token projections of a Llama decoder layer around the attention path, fused (EXTENSION; csrc/decode_layer.hip).
  * The reference leaves them to cuBLAS + PyTorch kernels: RMSNorm (quest/ops/csrc/rms_norm.cu:82-213 via
- * quest/models/llama.py:72), q/k/v projections + RoPE (QuestAttention.py:64-70, decode_page.cuh:644-728), o_proj (:118),
+ * quest/models/llama.py:72), q/k/v projections (QuestAttention.py:88-90) + RoPE (:99, decode_page.cuh:644-728), o_proj (QuestAttention.py:175),
  * residual adds and the SwiGLU MLP (llama.py LlamaMLP).  All vectors / matrices fp16, row-major weights [out][in]
  * (torch.nn.Linear.weight), fp32 accumulation, batch 1.
  *   quest_decode_norm_gemv     out[out_dim] = W . rmsnorm(x; gamma, eps)      (gamma NULL: out = W . x)

@@ -5,8 +5,8 @@ validates its tensors the way the reference's CHECK_* macros do (pytorch_extensi
 and then calls the matching C-ABI entry point of libquest_hip.so on torch's current stream.
 PyTorch is only the owner of device memory here; all arithmetic is in the HIP library.
 
-``prefill_with_paged_kv_cache`` is outside the sparse-decode hot path: the
-symbol exists so ``quest.utils`` imports unchanged, and is served by torch SDPA on the gathered pages.
+``prefill_with_paged_kv_cache`` is a hand-written kernel like the others since round 5: the MFMA
+flash kernel of ``csrc/prefill.hip`` over the page table (no gathered K/V copy, no torch attention).
 """
 from __future__ import annotations
 
@@ -634,7 +634,7 @@ def prefill_with_paged_kv_cache(q, kv_data, kv_indices, kv_last_page_len: int, c
 # ---------------------------------------------------------------- handler class
 
 class BatchDecodeWithPagedKVCachePyTorchWrapper:
-    """bsk_ops.h:84-116 / approx_attn.cu:27-150: begin_forward plans, forward launches."""
+    """bsk_ops.h:88-117 / approx_attn.cu:27-150: begin_forward plans, forward launches."""
 
     def __init__(self, layout: int):
         self._layout = int(layout)
