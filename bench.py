@@ -22,7 +22,9 @@ tried and is slower, +16 % -- the RCCL kernel then runs beside the step's kernel
 One JSON line on stdout (rank 0).  Extra objects: "roofline" (the dominant kernel OF THE TIMED STEP:
 sparse_decode_kernel with its top-k front end; algorithmic bytes / HIP-event launch time) and
 "cpu_baseline" (oracle/torch_ref eager port timed on the host cores, bounded sample).  Side objects of the default N = 1 run,
-measured after the headline and outside `value`: "batched_8seq", "cfg5_8seq_gqa" (8 sequences per GPU) and
+measured after the headline and outside `value`: "batched_8seq", "cfg5_8seq_gqa" (8 sequences per GPU), the same and the
+headline on the reference's NHD pool layout ("reference_layout_nhd", "batched_8seq_nhd", "cfg5_8seq_gqa_nhd": the default
+layout is this build's row-rotated NHD since round 6, config.kv_layout) and
 "prefill_attention" (the prefill operator on the headline shapes: the MFMA kernel's TFLOP/s against the dense fp16 peak).
 """
 import argparse
@@ -68,7 +70,12 @@ def parse(argv=None):
     ap.add_argument("--seqlen", type=int)
     ap.add_argument("--token-budget", type=int)
     ap.add_argument("--page-size", type=int, default=16)
-    ap.add_argument("--layout", choices=["NHD", "HND"], default="NHD")
+    ap.add_argument("--layout", choices=["NHD", "HND", "NHD_ROT"], default="NHD_ROT",
+                    help="pool layout: this build's row-rotated NHD (default since round 6: QUEST_LAYOUT_NHD_ROT, "
+                         "include/quest_hip.h -- the NHD shape with the heads of an entry rotated by the entry, so that every "
+                         "head's 256-byte pieces cycle through the address classes MI355X serves unevenly; same bits as NHD), "
+                         "or the reference's NHD / HND.  config.kv_layout names it; the default run reports the NHD figures "
+                         "beside it (side objects `reference_layout_nhd`, `batched_8seq_nhd`, `cfg5_8seq_gqa_nhd`)")
     ap.add_argument("--mode", choices=["graph", "graph-static", "eager"], default="graph",
                     help="graph: ONE hipGraph of the whole step, replayed while the sequence grows by a token per "
                          "step (device-resident step state); graph-static: the same graph without the state "
@@ -958,6 +965,12 @@ def main():
             sides = [("batched_8seq", dict(config=3, seqs_per_gpu=8)), ("cfg5_8seq_gqa", dict(config=5))]
             if dist is not None:
                 sides = sides[1:]
+            elif a.layout != "NHD":
+                # the same three measurements on the REFERENCE's pool layout (a headline on another layout
+                # carries the NHD figure beside it)
+                sides += [("reference_layout_nhd", dict(config=3, layout="NHD")),
+                          ("batched_8seq_nhd", dict(config=3, seqs_per_gpu=8, layout="NHD")),
+                          ("cfg5_8seq_gqa_nhd", dict(config=5, layout="NHD"))]
             for name, overrides in sides:
                 gc.collect()
                 if not stub:
@@ -965,7 +978,7 @@ def main():
                 side_warmup = a.side_warmup if a.side_warmup is not None else max(a.warmup, 20)
                 a2 = parse(["--config", str(overrides["config"]), "--steps", str(a.side_steps), "--warmup", str(side_warmup),
                             "--seed", str(a.seed), "--no-cpu-baseline", "--gpus", str(a.gpus),
-                            "--layer-launches", a.layer_launches]
+                            "--layer-launches", a.layer_launches, "--layout", overrides.get("layout", a.layout)]
                            + (["--seqs-per-gpu", str(overrides["seqs_per_gpu"])] if "seqs_per_gpu" in overrides else []))
                 try:
                     full = measure(a2, dev, dist, world_seen, rank, stub, side=True)
@@ -987,6 +1000,7 @@ def main():
                 roof, ops = full.get("roofline") or {}, full.get("ops_us") or {}
                 out[name] = {
                     "workload": full["config"]["workload"], "sequences_per_gpu": full["config"]["sequences_per_gpu"],
+                    "kv_layout": full["config"]["kv_layout"],
                     "n_gpus": full["n_gpus"], "steps": full["steps"], "tokens_per_s": full["value"],
                     "ms_per_step": full["ms_per_step"],
                     "ms_per_step_without_token_gather": full.get("ms_per_step_without_token_gather"),
@@ -1003,6 +1017,7 @@ def main():
                     "append_estimate_frac_of_hbm_peak": ops.get("append_estimate_frac_of_hbm_peak"),
                     "batched_dense_full_kv_us_per_sequence": ops.get("batched_dense_full_kv_us_per_sequence"),
                     "speedup_vs_batched_dense": full.get("speedup_vs_batched_dense"),
+                    "speedup_vs_dense": full.get("speedup_vs_dense"),
                     "speedup_vs_single_sequence_dense": (out["dense_full_kv_us"] / full["selfattn_us_per_layer"]
                                                          if overrides["config"] == 3 and out.get("dense_full_kv_us") else None),
                     "note": ("measured after the headline timing in the same process(es); not part of `value`"

@@ -33,6 +33,20 @@ typedef void* quest_stream_t; /* hipStream_t */
 
 #define QUEST_LAYOUT_NHD 0u
 #define QUEST_LAYOUT_HND 1u
+/*
+ * EXTENSION (round 6): NHD with the heads of an entry ROTATED by the entry.  A pool layer has the NHD shape
+ * [pages][2][page_size][num_heads][head_dim], but inside entry e's row of heads the K (metadata pool: max) vector of
+ * head h sits in head slot   h ^ (e & rot),   rot   = min(num_heads & -num_heads, 4) - 1        (0, 1 or 3)
+ * and its V (min) vector in   that slot ^ flip,  flip  = (min(num_heads & -num_heads, 32) - 1) & ~3  (0, 4, 12 or 28).
+ * Why: on the plain NHD pool all 256-byte pieces of a head share address bits 8-12, and MI355X serves pieces whose
+ * address bits 8-9 are 01 ~20 % slower than the others under mixed traffic (scripts/probe/addr_class_probe.hip), so a
+ * launch with one workgroup per head ends with its "slow" heads while most CUs idle.  Rotated, every head's pieces
+ * cycle through all values of those bits: every workgroup sees the mix's mean.  Same bytes, same arithmetic, same fold
+ * order as NHD -> the same scores, selections and outputs bit for bit; only WHERE a vector lives differs
+ * (quest_pool_slot below is the whole definition).  Not a layout the reference has (quest/utils/utils.py:1-5 knows NHD and
+ * HND; decode_page.cuh:196-239 are their offsets): a pool in this layout must be written and read through this library.
+ */
+#define QUEST_LAYOUT_NHD_ROT 2u
 
 #define QUEST_EINVAL (-1)      /* malformed argument (null pointer, zero size, bad layout) */
 #define QUEST_EUNSUPPORTED (-2) /* head_dim / page_size / group size outside the built set */
@@ -336,7 +350,7 @@ int quest_decode_append_forward_shared_batched(quest_decode_handler_t* h, const 
  * scores_out: optional inspection copy of the page scores, [n_seqs][num_qo_heads][score_stride] fp16 (NULL: they stay
  * in LDS); the selection can be inspected with quest_decode_set_selection_out.
  * Serves plans with ONE workgroup per head (quest_decode_set_batch + begin_forward on a batch that fills the chip),
- * page_size 16, head_dim 64 / 128, at most 127 selected pages, rows up to 4096 pages; QUEST_EUNSUPPORTED otherwise
+ * page_size 16, head_dim 64 / 128, at most 255 selected pages (token budget 4096), rows up to 4096 pages; QUEST_EUNSUPPORTED otherwise
  * (issue the two launches then).
  */
 int quest_decode_layer_fused_batched(quest_decode_handler_t* h, const void* k, const void* v, quest_paged_kv_t metadata,

@@ -56,7 +56,7 @@ def lib():
     return _lib
 
 
-NHD, HND = 0, 1
+NHD, HND, NHD_ROT = 0, 1, 2  # 2: this build's row-rotated NHD (include/quest_hip.h QUEST_LAYOUT_NHD_ROT), same shape as NHD
 
 
 @dataclass
@@ -78,11 +78,11 @@ class Paged:
 
     @property
     def page_size(self) -> int:
-        return self.data.shape[2] if self.layout == NHD else self.data.shape[3]
+        return self.data.shape[3] if self.layout == HND else self.data.shape[2]
 
     @property
     def num_heads(self) -> int:
-        return self.data.shape[3] if self.layout == NHD else self.data.shape[2]
+        return self.data.shape[2] if self.layout == HND else self.data.shape[3]
 
     @property
     def head_dim(self) -> int:

@@ -121,25 +121,39 @@ typedef struct {
     uint32_t num_heads;     /* heads stored in the pool (kv heads) */
     uint32_t page_size;     /* entries per page */
     uint32_t head_dim;
-    uint32_t layout;        /* 0 = NHD, 1 = HND (quest/utils/utils.py:1-5) */
+    uint32_t layout;        /* 0 = NHD, 1 = HND (quest/utils/utils.py:1-5); 2 = NHD_ROT, this build's extension (below) */
     qo_half* data;          /* [max_pages][2][...] */
     const int32_t* indices; /* [n_pages] page table */
     int32_t n_pages;        /* indptr[1] - indptr[0] */
     uint32_t last_page_len; /* valid entries in the last page, 1..page_size */
 } qo_paged_t;
 
+/* Layout 2 (NHD_ROT, include/quest_hip.h) is NOT a layout of the reference: the NHD shape with the heads of an entry
+ * rotated by the entry -- the K / max vector of head h sits in head slot h ^ (e & rot), its V / min vector in that
+ * slot ^ flip.  The oracle restates only WHERE the vectors live; every algorithm below is the reference's and reads the
+ * pool through these two functions, so the same inputs give the same results in all three layouts. */
+static uint32_t qo_rot(const qo_paged_t* p) {
+    uint32_t low = p->num_heads & (0u - p->num_heads);
+    return p->layout == 2 ? (low < 4u ? low : 4u) - 1u : 0u;
+}
+static uint32_t qo_flip(const qo_paged_t* p) {
+    uint32_t low = p->num_heads & (0u - p->num_heads);
+    return p->layout == 2 ? ((low < 32u ? low : 32u) - 1u) & ~3u : 0u;
+}
 /* decode_page.cuh:196-205 */
 static size_t qo_k_off(const qo_paged_t* p, size_t page, size_t head, size_t entry, size_t feat) {
+    size_t slot = head ^ (entry & qo_rot(p));
     return p->layout == 1
                ? ((page * 2 * p->num_heads + head) * p->page_size + entry) * p->head_dim + feat
-               : ((page * 2 * p->page_size + entry) * p->num_heads + head) * p->head_dim + feat;
+               : ((page * 2 * p->page_size + entry) * p->num_heads + slot) * p->head_dim + feat;
 }
 /* decode_page.cuh:228-239 */
 static size_t qo_v_off(const qo_paged_t* p, size_t page, size_t head, size_t entry, size_t feat) {
+    size_t slot = (head ^ (entry & qo_rot(p))) ^ qo_flip(p);
     return p->layout == 1
                ? (((page * 2 + 1) * p->num_heads + head) * p->page_size + entry) * p->head_dim +
                      feat
-               : (((page * 2 + 1) * p->page_size + entry) * p->num_heads + head) * p->head_dim +
+               : (((page * 2 + 1) * p->page_size + entry) * p->num_heads + slot) * p->head_dim +
                      feat;
 }
 

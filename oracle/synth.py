@@ -56,7 +56,7 @@ def build_sequence(k: np.ndarray, v: np.ndarray, page_size: int = 16, layout: in
     n_pages = (L + page_size - 1) // page_size
     n_meta = (n_pages + page_size - 1) // page_size
     cap, mcap = n_pages + slack_pages, n_meta + slack_pages
-    shape = (lambda c: (c, 2, page_size, H, D)) if layout == NHD else (lambda c: (c, 2, H, page_size, D))
+    shape = (lambda c: (c, 2, H, page_size, D)) if layout == 1 else (lambda c: (c, 2, page_size, H, D))  # 1 = HND
     kv_data = np.zeros(shape(cap), dtype=np.float16)
     meta_data = np.zeros(shape(mcap), dtype=np.float16)
     if perm_seed is None:

@@ -60,9 +60,11 @@ __global__ __launch_bounds__(256) void append_prefill_kernel(quest_paged_kv_t kv
 
     uint16_t* kv_data = reinterpret_cast<uint16_t*>(kv.data);
     uint16_t* m_data = reinterpret_cast<uint16_t*>(meta.data);
-    uint16_t* kdst = kv_data + page * ks.page + (size_t)h * ks.head + f;
-    uint16_t* mmax = m_data + mpage * ms.page + (size_t)h * ms.head + (size_t)mentry * ms.entry + f;
-    uint16_t* mmin = mmax + ms.v_off;
+    uint16_t* kdst = kv_data + page * ks.page + f;  // + entry * ks.entry + (the entry's slot of head h) * ks.head
+    const uint32_t mslot = pool_slot(ms, h, mentry);
+    uint16_t* mmax = m_data + mpage * ms.page + (size_t)mslot * ms.head + (size_t)mentry * ms.entry + f;
+    uint16_t* mmin = mmax + pool_v_off(ms, mslot);
+    const uint32_t kv_v_off = pool_v_off(ks, h);  // (the rotation leaves the flipped slot bits alone: one distance per head)
 
     ushort8 mx, mn;
     if (e0 > 0) {
@@ -80,8 +82,9 @@ __global__ __launch_bounds__(256) void append_prefill_kernel(quest_paged_kv_t kv
         const ushort8 v8 = *reinterpret_cast<const ushort8*>(value + src);
         mx = fold_max(mx, k8);
         mn = fold_min(mn, k8);
-        *reinterpret_cast<ushort8*>(kdst + (size_t)e * ks.entry) = k8;
-        *reinterpret_cast<ushort8*>(kdst + (size_t)e * ks.entry + ks.v_off) = v8;
+        uint16_t* dst = kdst + (size_t)e * ks.entry + (size_t)pool_slot(ks, h, (uint32_t)e) * ks.head;
+        *reinterpret_cast<ushort8*>(dst) = k8;
+        *reinterpret_cast<ushort8*>(dst + kv_v_off) = v8;
     }
     *reinterpret_cast<ushort8*>(mmax) = mx;
     *reinterpret_cast<ushort8*>(mmin) = mn;
@@ -126,7 +129,7 @@ __global__ void step_state_advance_kernel(quest_step_state_t* st, const int32_t*
 
 int check_pool(const quest_paged_kv_t& p) {
     if (!p.data || !p.indices) return QUEST_EINVAL;
-    if (p.layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
+    if (p.layout > QUEST_LAYOUT_NHD_ROT) return QUEST_EINVAL;
     if (p.num_heads == 0 || p.page_size == 0) return QUEST_EINVAL;
     if (p.head_dim != 64 && p.head_dim != 128 && p.head_dim != 256) return QUEST_EUNSUPPORTED;
     if (p.last_page_len == 0 || p.last_page_len > p.page_size) return QUEST_EINVAL;

@@ -59,9 +59,10 @@ __device__ __forceinline__ void append_decode_body(const quest_paged_kv_t& kv, c
 
     uint16_t* kv_data = reinterpret_cast<uint16_t*>(kv.data);
     uint16_t* m_data = reinterpret_cast<uint16_t*>(meta.data);
-    uint16_t* kdst = kv_data + page * ks.page + (size_t)h * ks.head + (size_t)entry * ks.entry + f;
-    uint16_t* mmax = m_data + mpage * ms.page + (size_t)h * ms.head + (size_t)mentry * ms.entry + f;
-    uint16_t* mmin = mmax + ms.v_off;
+    const uint32_t kslot = pool_slot(ks, h, entry), mslot = pool_slot(ms, h, mentry);
+    uint16_t* kdst = kv_data + page * ks.page + (size_t)kslot * ks.head + (size_t)entry * ks.entry + f;
+    uint16_t* mmax = m_data + mpage * ms.page + (size_t)mslot * ms.head + (size_t)mentry * ms.entry + f;
+    uint16_t* mmin = mmax + pool_v_off(ms, mslot);
 
     const ushort8 k8 = *reinterpret_cast<const ushort8*>(key + (size_t)h * D + f);
     const ushort8 v8 = *reinterpret_cast<const ushort8*>(value + (size_t)h * D + f);
@@ -76,7 +77,7 @@ __device__ __forceinline__ void append_decode_body(const quest_paged_kv_t& kv, c
     mx = fold_max(mx, k8);
     mn = fold_min(mn, k8);
     *reinterpret_cast<ushort8*>(kdst) = k8;
-    *reinterpret_cast<ushort8*>(kdst + ks.v_off) = v8;
+    *reinterpret_cast<ushort8*>(kdst + pool_v_off(ks, kslot)) = v8;
     *reinterpret_cast<ushort8*>(mmax) = mx;
     *reinterpret_cast<ushort8*>(mmin) = mn;
 }

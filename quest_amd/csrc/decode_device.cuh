@@ -120,7 +120,8 @@ __device__ __forceinline__ SeqView select_sequence(const DecodeParams& p, uint32
     return v;
 }
 
-constexpr int kFusedMaxPpc = 128;  // pages per workgroup the fused front end can stage in LDS
+constexpr int kFusedMaxPpc = 256;  // pages per workgroup the fused front end can stage in LDS (round 6: 128 -> 256, so that a
+                                    // token budget of 4096 -- the reference's largest, scripts/passkey.sh:11 -- is one workgroup per head)
 
 template <int D>
 struct RowState {
@@ -237,6 +238,7 @@ __device__ __forceinline__ AttendArgs attend_args(const DecodeParams& p) {
     AttendArgs a;
     a.kv = p.kv;
     a.st.page = p.st.page, a.st.v_off = p.st.v_off, a.st.head = p.st.head, a.st.entry = p.st.entry;
+    a.st.rot = p.st.rot, a.st.vflip = p.st.vflip;
     a.group = p.group, a.last_page_len = p.last_page_len, a.last_page_idx = p.last_page_idx;
     a.page_size = p.page_size, a.n_chunks = p.n_chunks, a.ws_stride = p.ws_stride;
     a.scale_log2 = p.scale_log2;
@@ -251,7 +253,8 @@ __device__ __forceinline__ AttendArgs attend_args(const DecodeParams& p) {
 struct AppendRow {
     const half_t* k;   // the kv head's new key / value [D]
     const half_t* v;
-    half_t* meta_entry;  // the current page's metadata entry of this kv head (max; min is st.v_off further)
+    half_t* meta_entry;  // the current page's metadata entry of this kv head (max; min is meta_v_off halves further)
+    uint32_t meta_v_off;
     ushort8 mx, mn;
     bool writer;
 };
@@ -265,8 +268,10 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
     const int row = lane / LPR, col = lane % LPR;
     RowState<D> st;
     const uint32_t hk = hq / p.group;
-    const half_t* head_base = p.kv + (size_t)hk * p.st.head;       // uniform
-    const uint32_t lane_off = row * p.st.entry + col * kVec;        // per lane, loop invariant
+    // address of (page, entry t R + row) of this kv head = pool + page * st.page + uni[t] + lane_off (+ v_off for V): the head
+    // term is split between the two so that the row-rotated pool (st.rot, quest_common.cuh walk_*) walks like the plain ones
+    const uint32_t lane_off = walk_lane_off(p.st, hk, R, row, col * kVec);  // per lane, loop invariant
+    const uint32_t v_off = pool_v_off(p.st, hk);                              // uniform
     float8 qv = to_f32(q_raw);
     qv *= p.scale_log2;
     [[maybe_unused]] half8 app_kn, app_vn;
@@ -284,7 +289,9 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
 
     if constexpr (S_T > 0) {
         constexpr int T = (S_T + R - 1) / R;  // load instructions per page per tensor
-        const uint32_t step = R * p.st.entry;
+        uint32_t uni[T];                        // uniform, loop invariant
+#pragma unroll
+        for (int t = 0; t < T; ++t) uni[t] = walk_uniform(p.st, hk, R, t);
         for (uint32_t s0 = slot_begin + wave; s0 < slot_end; s0 += 2 * NW) {
             const uint32_t s1 = s0 + NW;
             const bool has1 = s1 < slot_end;
@@ -292,8 +299,8 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
             const int32_t pg1 = __builtin_amdgcn_readfirstlane(has1 ? slot_page(s1) : pg0);
             const int len0 = s0 < n_listed ? S_T : (int)p.last_page_len;
             const int len1 = has1 ? (s1 < n_listed ? S_T : (int)p.last_page_len) : 0;
-            const half_t* b0 = head_base + (size_t)pg0 * p.st.page;
-            const half_t* b1 = head_base + (size_t)pg1 * p.st.page;
+            const half_t* b0 = p.kv + (size_t)pg0 * p.st.page;
+            const half_t* b1 = p.kv + (size_t)pg1 * p.st.page;
             half8 k[2 * T], v[2 * T];
             int left[2 * T];
 #pragma unroll
@@ -302,14 +309,14 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
                 left[T + t] = len1 - t * R;
                 // rows past the page's length exist in the pool (the page is allocated) but hold
                 // stale bytes; they are fetched only for the sequence's last page and masked in fold
-                k[t] = ld8_kv(b0 + lane_off + t * step);
-                v[t] = ld8_kv(b0 + lane_off + t * step + p.st.v_off);
+                k[t] = ld8_kv(b0 + uni[t] + lane_off);
+                v[t] = ld8_kv(b0 + uni[t] + lane_off + v_off);
             }
             if (has1) {  // wave-uniform (a likely-taken hint here cost 3.5 us per batched launch: measured, r3j)
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    k[T + t] = ld8_kv(b1 + lane_off + t * step);
-                    v[T + t] = ld8_kv(b1 + lane_off + t * step + p.st.v_off);
+                    k[T + t] = ld8_kv(b1 + uni[t] + lane_off);
+                    v[T + t] = ld8_kv(b1 + uni[t] + lane_off + v_off);
                 }
                 if constexpr (APPEND) {
                     if (s0 >= n_listed || s1 >= n_listed) {  // wave-uniform: one of the two is the current page
@@ -345,16 +352,16 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
             const bool sel = slot < n_listed;
             const int32_t pg = __builtin_amdgcn_readfirstlane(slot_page(slot));
             const int len = sel ? (int)S : (int)p.last_page_len;
-            const half_t* b = head_base + (size_t)pg * p.st.page;
+            const half_t* b = p.kv + (size_t)pg * p.st.page;
             for (int t0 = 0; t0 < len; t0 += R) {
                 half8 k1[1], v1[1];
                 const int left[1] = {len - t0};
                 // rows past `len` stay inside the (allocated) page for page sizes that are a multiple of R;
                 // otherwise clamp to the page's first row -- masked in fold either way
-                const uint32_t r_in = (uint32_t)(t0 + row) < S ? (uint32_t)t0 : 0u;
-                const half_t* ptr = b + lane_off + (size_t)r_in * p.st.entry - (r_in == (uint32_t)t0 ? 0 : (size_t)row * p.st.entry);
+                const uint32_t e = (uint32_t)(t0 + row) < S ? (uint32_t)(t0 + row) : 0u;
+                const half_t* ptr = b + (size_t)e * p.st.entry + (size_t)pool_slot(p.st, hk, e) * p.st.head + col * kVec;
                 k1[0] = ld8(ptr);
-                v1[0] = ld8(ptr + p.st.v_off);
+                v1[0] = ld8(ptr + v_off);
                 fold_groups<D, 1>(st, qv, k1, v1, left, row);
             }
         }
@@ -364,15 +371,15 @@ __device__ __forceinline__ void attend_slots(const AttendArgs p, const SeqView s
         // the wave that folded the current page (slot n_listed), the row of lanes at the new token's position
         if (app.writer && slot_begin <= n_listed && n_listed < slot_end && (uint32_t)wave == (n_listed - slot_begin) % NW &&
             (uint32_t)row == app_e % R) {
-            half_t* dst = const_cast<half_t*>(head_base) + (size_t)p.last_page_idx * p.st.page + lane_off + (app_e / R) * (R * p.st.entry);
+            half_t* dst = const_cast<half_t*>(p.kv) + (size_t)p.last_page_idx * p.st.page + lane_off + walk_uniform(p.st, hk, R, app_e / R);
             st8(dst, app_kn);
-            st8(dst + p.st.v_off, app_vn);
+            st8(dst + v_off, app_vn);
             const ushort8 k8 = __builtin_bit_cast(ushort8, app_kn);
             // a token that opens a page starts from the sentinels, not from stale pool bytes
             const ushort8 mx0 = app_e > 0 ? app.mx : (ushort8)(kHalfNegMax), mn0 = app_e > 0 ? app.mn : (ushort8)(kHalfMax);
             uint16_t* me = reinterpret_cast<uint16_t*>(app.meta_entry) + col * kVec;
             *reinterpret_cast<ushort8*>(me) = fold_max(mx0, k8);
-            *reinterpret_cast<ushort8*>(me + p.st.v_off) = fold_min(mn0, k8);
+            *reinterpret_cast<ushort8*>(me + app.meta_v_off) = fold_min(mn0, k8);
         }
     }
     QUEST_STAMP(6);

@@ -33,7 +33,10 @@ __global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimat
     uint32_t a_meta_table_stride, half_t* __restrict__ o, quest_paged_kv_t meta, AppendTail tail) {
     // a_append_from: first append block (= est_blocks), 0xffffffff when no append rides in this launch
     meta.data = a_meta_data, meta.indices = a_meta_indices, meta.num_heads = a_num_heads, meta.page_size = a_page_size;
-    meta.head_dim = D, meta.layout = HND ? QUEST_LAYOUT_HND : QUEST_LAYOUT_NHD;
+    // a_tile_log2: log2(tile heads) | row-rotated pool << 8 (the layout decides the first loads' addresses, so it travels in
+    // the preloaded block, not in the struct; NHD and NHD_ROT share the HND = false instantiation)
+    meta.head_dim = D, meta.layout = HND ? QUEST_LAYOUT_HND : (a_tile_log2 >> 8) ? QUEST_LAYOUT_NHD_ROT : QUEST_LAYOUT_NHD;
+    a_tile_log2 &= 255u;
     tail.state = a_state, tail.tile_log2 = a_tile_log2, tail.tile_heads = 1u << a_tile_log2, tail.est_blocks = a_append_from, tail.enabled = 1u;
     tail.meta_table_stride = a_meta_table_stride;
     uint32_t seq = 0;
@@ -71,6 +74,7 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     constexpr int R = kWave / (D / kVec);
     constexpr uint32_t ROWS = kEstWaves * est_iter<G>() * R;
     const bool hnd = meta.layout == QUEST_LAYOUT_HND;
+    const PoolStrides strides = pool_strides(meta);
     if (!tail.state && tail.o_stride == 0) tail.o_stride = n_out;  // contiguous rows unless the caller pads them
     uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec);
     // Tile maxima are one key per run of 8 consecutive columns of ONE query head, taken from 8 consecutive lanes of the
@@ -80,6 +84,8 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
     while (tail.tile_off && hw > 1 && (ROWS / hw) % 8u != 0) hw >>= 1;
     const uint32_t ew = ROWS / hw;
     if (tail.tile_off && ew % 8u != 0) return QUEST_EUNSUPPORTED;
+    // row-rotated pool: the heads of a tile's rows (slot ^ (entry & rot)) must be heads of the same tile
+    if (strides.rot >= hw) return QUEST_EUNSUPPORTED;
     tail.tile_heads = hw;
     tail.tile_log2 = (uint32_t)__builtin_ctz(hw);
     tail.est_blocks = ((n_out + ew - 1) / ew) * (meta.num_heads / hw);
@@ -96,7 +102,8 @@ static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_p
                            tail.meta_table_stride, (half_t*)o, meta, tail);
     else
         hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q, meta.data,
-                           meta.indices, tail.state, n_out, meta.num_heads, meta.page_size, tail.tile_log2, append_from,
+                           meta.indices, tail.state, n_out, meta.num_heads, meta.page_size,
+                           tail.tile_log2 | (meta.layout == QUEST_LAYOUT_NHD_ROT ? 1u << 8 : 0u), append_from,
                            tail.meta_table_stride, (half_t*)o, meta, tail);
     QUEST_LAUNCH_CHECK();
     return 0;
@@ -125,7 +132,7 @@ int check_pool(const quest_paged_kv_t& p);  // append.hip
 static int estimate_entry(const void* q, void* o, uint32_t num_qo_heads, uint32_t n_out, const quest_paged_kv_t& metadata,
                           const AppendTail& tail, hipStream_t s, uint32_t n_seqs = 1) {
     if (!q || !metadata.data || !metadata.indices) return QUEST_EINVAL;
-    if (metadata.layout > QUEST_LAYOUT_HND || metadata.num_heads == 0 || metadata.page_size == 0) return QUEST_EINVAL;
+    if (metadata.layout > QUEST_LAYOUT_NHD_ROT || metadata.num_heads == 0 || metadata.page_size == 0) return QUEST_EINVAL;
     if (num_qo_heads == 0 || num_qo_heads % metadata.num_heads != 0) return QUEST_EINVAL;
     if (n_out > 0 && !o) return QUEST_EINVAL;
     if (n_out == 0 && !tail.enabled) return 0;  // nothing to score (single page)

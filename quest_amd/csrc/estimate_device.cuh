@@ -135,10 +135,14 @@ __device__ __forceinline__ void estimate_tile(const half_t* __restrict__ q, half
     half8 mx[kEstIter], mn[kEstIter];
 #pragma unroll
     for (int j = 0; j < kEstIter; ++j) {
-        const half_t* p = data + page[j] * ms.page + (size_t)(h0 + hl[j]) * ms.head + (size_t)(ecl[j] % S) * ms.entry +
-                          col * kVec;
+        // rows follow MEMORY order: row (head slot h0 + hl, entry) holds the max vector of kv head slot ^ (entry & rot) --
+        // a head of the same tile (rot < HW, checked by the host) -- and its min vector sits pool_v_off further (plain
+        // layouts: rot = 0, v_off)
+        const uint32_t e_in = ecl[j] % S, slot = h0 + hl[j];
+        const half_t* p = data + page[j] * ms.page + (size_t)slot * ms.head + (size_t)e_in * ms.entry + col * kVec;
         mx[j] = ld8_stream(p);
-        mn[j] = ld8_stream(p + ms.v_off);
+        mn[j] = ld8_stream(p + pool_v_off(ms, slot));
+        hl[j] ^= e_in & ms.rot;  // from here on: the row's kv HEAD inside the tile
     }
 
     // q -> LDS (these loads are older than the metadata loads, so this does not wait for them)

@@ -145,13 +145,17 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
 
     // the current page's metadata entry of this kv head, as it is before this token (the append's read half): every lane
     // asks for its 16 bytes of the entry (the rows of a wave repeat each other) -- unconditional, held until the stores
-    const half_t* meta_head = a_meta + (size_t)hk * p.st.head;
-    const uint32_t lane_off = row * p.st.entry + col * kVec;
-    half_t* meta_entry = const_cast<half_t*>(meta_head) + (size_t)live_m.z * p.st.page + (size_t)(live_m.y - 1) * p.st.entry;
+    // (metadata and KV pools share their geometry: the same walk -- quest_common.cuh walk_* -- serves both phases)
+    const uint32_t lane_off = walk_lane_off(p.st, hk, R, row, col * kVec);
+    const uint32_t v_off = pool_v_off(p.st, hk);
+    const uint32_t m_entry = (uint32_t)(live_m.y - 1);
+    half_t* meta_entry = const_cast<half_t*>(a_meta) + (size_t)live_m.z * p.st.page + (size_t)m_entry * p.st.entry +
+                         (size_t)pool_slot(p.st, hk, m_entry) * p.st.head;
     AppendRow app;
     app.mx = *reinterpret_cast<const ushort8*>(reinterpret_cast<const uint16_t*>(meta_entry) + col * kVec);
-    app.mn = *reinterpret_cast<const ushort8*>(reinterpret_cast<const uint16_t*>(meta_entry) + p.st.v_off + col * kVec);
+    app.mn = *reinterpret_cast<const ushort8*>(reinterpret_cast<const uint16_t*>(meta_entry) + v_off + col * kVec);
     app.meta_entry = meta_entry;
+    app.meta_v_off = v_off;
     app.k = p.k_new + ((size_t)seq * p.num_kv_heads + hk) * D;
     app.v = p.v_new + ((size_t)seq * p.num_kv_heads + hk) * D;
     app.writer = hq % group == 0;
@@ -175,7 +179,9 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     uint16_t* score_row = p.scores_out ? p.scores_out + ((size_t)seq * a_num_qo_heads + hq) * p.score_stride : nullptr;
     uint32_t mm = kMmNeutral;
     const uint32_t n_mp = (n + S_T - 1) / S_T;  // metadata pages that hold entries to score
-    const uint32_t step = R * p.st.entry;
+    uint32_t uni[T];  // uniform, loop invariant
+#pragma unroll
+    for (int t = 0; t < T; ++t) uni[t] = walk_uniform(p.st, hk, R, t);
     bool ids_parked = false;
     auto park_ids = [&]() {  // page table -> LDS; called after the first round's loads have left
 #pragma unroll
@@ -194,11 +200,11 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     __syncthreads();
     auto issue = [&](uint32_t mp, half8 (&mx)[T], half8 (&mn)[T]) {  // request the 16 entries of metadata page mp
         const int32_t pg = ld_uniform_i32(meta_table + mp);
-        const half_t* b0 = meta_head + (size_t)pg * p.st.page;
+        const half_t* b0 = a_meta + (size_t)pg * p.st.page;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            mx[t] = ld8_stream(b0 + lane_off + t * step);
-            mn[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
+            mx[t] = ld8_stream(b0 + uni[t] + lane_off);
+            mn[t] = ld8_stream(b0 + uni[t] + lane_off + v_off);
         }
     };
     auto fetch = [&]() -> uint32_t {  // a page from the counter (broadcast from lane 0)
@@ -265,6 +271,7 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     AttendArgs aa;
     aa.kv = p.kv;
     aa.st.page = p.st.page, aa.st.v_off = p.st.v_off, aa.st.head = p.st.head, aa.st.entry = p.st.entry;
+    aa.st.rot = p.st.rot, aa.st.vflip = p.st.vflip;
     aa.group = group, aa.last_page_len = (uint32_t)live.z, aa.last_page_idx = live.w;
     aa.page_size = S_T, aa.n_chunks = 1u, aa.ws_stride = p.ws_stride;
     aa.scale_log2 = p.scale_log2;

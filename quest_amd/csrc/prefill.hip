@@ -144,8 +144,10 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_kernel(const Pr
     uint32_t wa[NP];  // (for RP = 16 / 32 the passes differ by a constant)
 #pragma unroll
     for (int i = 0; i < NP; ++i) wa[i] = lds0 + img_off<D>(srow + RP * i, sch);
-    const unsigned char* kv_head_base = reinterpret_cast<const unsigned char*>(p.kv + (size_t)kv_head * p.st.head);
-    const uint32_t v_bytes = p.st.v_off * 2u;
+    // address of (page, entry, kv head) = pool + page * st.page + entry * st.entry + pool_slot(head, entry) * st.head: on the
+    // row-rotated pool (QUEST_LAYOUT_NHD_ROT) the head's slot depends on the entry, so the head term is per lane
+    const unsigned char* kv_base = reinterpret_cast<const unsigned char*>(p.kv);
+    const uint32_t v_bytes = pool_v_off(p.st, kv_head) * 2u;
     auto issue = [&](uint32_t t, half8(&kr)[NP], half8(&vr)[NP]) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -156,15 +158,16 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_kernel(const Pr
                 // V rows zeroed below
                 const uint32_t pi = t * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(row >> 4));
                 const uint32_t pg = (uint32_t)ld_uniform_i32(p.table + min(pi, last_key >> 4));
-                const unsigned char* src = kv_head_base + (size_t)pg * p.st.page * 2u;
-                const uint32_t lane_bytes = ((row & 15u) * p.st.entry + sch * 8u) * 2u;
+                const unsigned char* src = kv_base + (size_t)pg * p.st.page * 2u;
+                const uint32_t lane_bytes = ((row & 15u) * p.st.entry + pool_slot(p.st, kv_head, row & 15u) * p.st.head + sch * 8u) * 2u;
                 kr[i] = *reinterpret_cast<const half8*>(src + lane_bytes);
                 vr[i] = *reinterpret_cast<const half8*>(src + v_bytes + lane_bytes);
             } else {
                 const uint32_t key = min(t * kPfKeys + row, last_key);
                 const uint32_t pi = key / p.page_size;
                 const uint32_t pg = (uint32_t)p.table[pi], slot = key - pi * p.page_size;
-                const unsigned char* src = kv_head_base + ((size_t)pg * p.st.page + (size_t)slot * p.st.entry + sch * 8u) * 2u;
+                const unsigned char* src = kv_base + ((size_t)pg * p.st.page + (size_t)slot * p.st.entry +
+                                                      (size_t)pool_slot(p.st, kv_head, slot) * p.st.head + sch * 8u) * 2u;
                 kr[i] = *reinterpret_cast<const half8*>(src);
                 vr[i] = *reinterpret_cast<const half8*>(src + v_bytes);
             }
@@ -325,7 +328,7 @@ extern "C" int quest_prefill_with_paged_kv_cache(const void* q, void* o, uint32_
                                                  quest_stream_t stream) {
     if (!q || !o || !kv.data || !kv.indices) return QUEST_EINVAL;
     if (n_q == 0 || num_qo_heads == 0 || kv.num_heads == 0 || kv.page_size == 0 || n_pages_host == 0) return QUEST_EINVAL;
-    if (kv.layout != QUEST_LAYOUT_NHD && kv.layout != QUEST_LAYOUT_HND) return QUEST_EINVAL;
+    if (kv.layout > QUEST_LAYOUT_NHD_ROT) return QUEST_EINVAL;
     if (kv.last_page_len == 0 || kv.last_page_len > kv.page_size) return QUEST_EINVAL;
     if (num_qo_heads % kv.num_heads != 0) return QUEST_EINVAL;
     if (kv.head_dim != 64 && kv.head_dim != 128 && kv.head_dim != 256) return QUEST_EUNSUPPORTED;

@@ -18,26 +18,55 @@ typedef float float8 __attribute__((ext_vector_type(8)));
 constexpr int kWave = 64;
 constexpr int kVec = 8;  // halves per lane per 16-byte access
 
-// Strides (in halves) of one pool layer; both layouts of decode_page.cuh:196-239 reduce to these.
+// Strides (in halves) of one pool layer; the layouts of decode_page.cuh:196-239 reduce to these.  `rot` / `vflip` are the
+// row rotation of QUEST_LAYOUT_NHD_ROT (include/quest_hip.h), 0 for the reference's two layouts: the K / max vector of
+// (head h, entry e) lives in head slot  h ^ (e & rot)  of the entry's row of heads, its V / min vector in that slot ^ vflip.
 struct PoolStrides {
     uint32_t page;    // 2 * S * H * D
     uint32_t v_off;   // S * H * D
     uint32_t head;    // NHD: D        HND: S * D
     uint32_t entry;   // NHD: H * D    HND: D
+    uint32_t rot;     // NHD_ROT: min(H & -H, 4) - 1, else 0
+    uint32_t vflip;   // NHD_ROT: (min(H & -H, 32) - 1) & ~3, else 0
 };
 
 __host__ __device__ inline PoolStrides pool_strides(const quest_paged_kv_t& p) {
     PoolStrides s;
     s.v_off = p.page_size * p.num_heads * p.head_dim;
     s.page = 2u * s.v_off;
+    s.rot = s.vflip = 0;
     if (p.layout == QUEST_LAYOUT_HND) {
         s.head = p.page_size * p.head_dim;
         s.entry = p.head_dim;
     } else {
         s.head = p.head_dim;
         s.entry = p.num_heads * p.head_dim;
+        if (p.layout == QUEST_LAYOUT_NHD_ROT) {
+            const uint32_t low = p.num_heads & (0u - p.num_heads);  // largest power of two dividing the head count
+            s.rot = (low < 4u ? low : 4u) - 1u;
+            s.vflip = ((low < 32u ? low : 32u) - 1u) & ~3u;
+        }
     }
     return s;
+}
+// head slot of head h's K / max vector in entry e (e = index INSIDE the page)
+__host__ __device__ inline uint32_t pool_slot(const PoolStrides& s, uint32_t h, uint32_t e) { return h ^ (e & s.rot); }
+// halves from the K / max vector in head slot `slot` to its V / min vector (slot ^ vflip, one tensor further).  The flip
+// only touches slot bits >= 2, which the rotation (bits 0-1) leaves alone: the distance is a per-HEAD constant,
+// pool_v_off(s, h).  (unsigned wrap-around: the true result lies in (0, page))
+__host__ __device__ inline uint32_t pool_v_off(const PoolStrides& s, uint32_t slot) {
+    return s.v_off + (s.vflip - 2u * (slot & s.vflip)) * s.head;
+}
+// The R-row walk of one head's page (attention gather, one-launch layer): entry e = t R + row (R = rows per wave load
+// instruction, a power of two; row < R).  slot(e) = hk ^ (e & rot) splits into a per-LANE part (the bits below R) and a
+// wave-UNIFORM part per round t, so the address stays  page base + uniform[t] + lane offset  whatever the layout:
+//   lane offset  = row * entry + ((hk & (R-1)) ^ (row & rot)) * head + col * 8
+//   uniform[t]   = t R * entry + ((hk ^ (t R & rot)) & ~(R-1)) * head
+__host__ __device__ inline uint32_t walk_lane_off(const PoolStrides& s, uint32_t hk, uint32_t R, uint32_t row, uint32_t col8) {
+    return row * s.entry + (((hk & (R - 1u)) ^ (row & s.rot)) * s.head) + col8;
+}
+__host__ __device__ inline uint32_t walk_uniform(const PoolStrides& s, uint32_t hk, uint32_t R, uint32_t t) {
+    return t * R * s.entry + ((hk ^ (t * R & s.rot)) & ~(R - 1u)) * s.head;
 }
 
 __device__ __forceinline__ half8 ld8(const half_t* p) { return *reinterpret_cast<const half8*>(p); }

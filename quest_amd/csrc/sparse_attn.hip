@@ -119,9 +119,12 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
         qv[g] = to_f32(ld8(sv.q + ((size_t)hk * GS + g) * D + col * kVec));
         qv[g] *= p.scale_log2;
     }
-    const half_t* head_base = p.kv + (size_t)hk * p.st.head;
-    const uint32_t lane_off = row * p.st.entry + col * kVec;
-    const uint32_t step = R * p.st.entry;
+    // page base + uni[t] + lane_off (+ v_off): the walk of quest_common.cuh (walk_*), the same for every pool layout
+    const uint32_t lane_off = walk_lane_off(p.st, hk, R, row, col * kVec);
+    const uint32_t v_off = pool_v_off(p.st, hk);
+    uint32_t uni[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) uni[t] = walk_uniform(p.st, hk, R, t);
     RowState<D> st[GS];
 
     [[maybe_unused]] const size_t app_in_off = ((size_t)blockIdx.z * (a_num_qo_heads / GS) + hk) * D + col * kVec;
@@ -139,11 +142,12 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
         if (app_mine) {
             // metadata entry of the page: entry meta_last_page_len - 1 of the last metadata page (same pool geometry as
             // the KV pool); a token that opens a page starts from the sentinels, not from stale pool bytes
+            const uint32_t me = p.meta_last_page_len - 1u;
             app_mmax = reinterpret_cast<uint16_t*>(p.app_meta) + (size_t)p.meta_last_page_idx * p.st.page +
-                       (size_t)hk * p.st.head + (size_t)(p.meta_last_page_len - 1u) * p.st.entry + col * kVec;
+                       (size_t)pool_slot(p.st, hk, me) * p.st.head + (size_t)me * p.st.entry + col * kVec;
             if (e > 0) {
                 app_mx = *reinterpret_cast<const ushort8*>(app_mmax);
-                app_mn = *reinterpret_cast<const ushort8*>(app_mmax + p.st.v_off);
+                app_mn = *reinterpret_cast<const ushort8*>(app_mmax + v_off);
             }
         }
     }
@@ -151,11 +155,11 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
     // request the K/V rows of slot s0
     auto issue = [&](uint32_t s0, half8 (&k)[T], half8 (&v)[T]) {
         const int32_t pg = __builtin_amdgcn_readfirstlane(s0 < p.n_sel ? sv.indices[s0] : p.last_page_idx);
-        const half_t* b0 = head_base + (size_t)pg * p.st.page;
+        const half_t* b0 = p.kv + (size_t)pg * p.st.page;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            k[t] = ld8_stream(b0 + lane_off + t * step);
-            v[t] = ld8_stream(b0 + lane_off + t * step + p.st.v_off);
+            k[t] = ld8_stream(b0 + uni[t] + lane_off);
+            v[t] = ld8_stream(b0 + uni[t] + lane_off + v_off);
         }
     };
     // fold the rows of slot s0 into the GS states
@@ -245,12 +249,12 @@ __global__ __launch_bounds__(NW* kWave, NW / 2) void shared_decode_kernel(QUEST_
         if (app_mine) {  // write the new token to the pool and fold its key into the page's (max, min) entry
             const uint32_t e = p.last_page_len - 1u;
             const half8 kn = ld8(p.app_k + app_in_off), vn = ld8(p.app_v + app_in_off);
-            half_t* dst = const_cast<half_t*>(head_base) + (size_t)p.last_page_idx * p.st.page + lane_off + (e / R) * step;
+            half_t* dst = const_cast<half_t*>(p.kv) + (size_t)p.last_page_idx * p.st.page + lane_off + walk_uniform(p.st, hk, R, e / R);
             st8(dst, kn);
-            st8(dst + p.st.v_off, vn);
+            st8(dst + v_off, vn);
             const ushort8 k8 = __builtin_bit_cast(ushort8, kn);
             *reinterpret_cast<ushort8*>(app_mmax) = fold_max(app_mx, k8);
-            *reinterpret_cast<ushort8*>(app_mmax + p.st.v_off) = fold_min(app_mn, k8);
+            *reinterpret_cast<ushort8*>(app_mmax + v_off) = fold_min(app_mn, k8);
         }
     }
 
@@ -423,7 +427,7 @@ struct quest_decode_handler {
 static uint32_t target_workgroups(const quest_decode_handler* h) { return h->batch > 1 ? h->num_cus : 2 * h->num_cus; }
 static constexpr uint32_t kMaxChunks = 1024;  // merge kernel's LDS weight table
 extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout) {
-    if (!out || layout > QUEST_LAYOUT_HND) return QUEST_EINVAL;
+    if (!out || layout > QUEST_LAYOUT_NHD_ROT) return QUEST_EINVAL;
     quest_decode_handler* h = new (std::nothrow) quest_decode_handler();
     if (!h) return (int)hipErrorOutOfMemory;
     h->layout = layout;

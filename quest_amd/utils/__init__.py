@@ -305,7 +305,7 @@ def decode_layer_batched(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bCon
             return o
         if one_launch:
             raise RuntimeError("the one-launch layer does not serve this plan / shape (needs one workgroup per head, "
-                               "page_size 16, head_dim 64 / 128, <= 127 selected pages, rows <= 4096 pages)")
+                               "page_size 16, head_dim 64 / 128, <= 255 selected pages, rows <= 4096 pages)")
     _kernels.append_estimate_batched(k, v, b.kv_layer(layer_idx), b.kv_tables, q, scores, b.metadata_layer(layer_idx),
                                      b.meta_tables, b.step_states, max_n, b.layout)
     o = torch.empty_like(q) if out is None else out

@@ -24,7 +24,7 @@ class KvPool:
     def __init__(self, num_layers: int, num_heads: int, head_dim: int, capacity: int, block_len: int,
                  dtype: torch.dtype, device, layout: int = TensorLayout.NHD, shuffle_seed: Optional[int] = None):
         self._layout = TensorLayout.parse(layout)
-        inner = (block_len, num_heads, head_dim) if self._layout == TensorLayout.NHD else (num_heads, block_len, head_dim)
+        inner = (num_heads, block_len, head_dim) if self._layout == TensorLayout.HND else (block_len, num_heads, head_dim)
         self._buf = torch.empty((num_layers, capacity, 2) + inner, dtype=dtype, device=device)
         # LIFO free list; ascending by default (the reference's set.pop() on small ints is too),
         # optionally shuffled so tests exercise arbitrary physical placement.
@@ -57,7 +57,7 @@ class KvPool:
 
     @property
     def block_len(self) -> int:
-        return self._buf.shape[3] if self._layout == TensorLayout.NHD else self._buf.shape[4]
+        return self._buf.shape[4] if self._layout == TensorLayout.HND else self._buf.shape[3]
 
     @property
     def num_free_blocks(self) -> int:

@@ -67,11 +67,16 @@ def used_pages_equal(dev_buf, ora, indices):
 
 def gather_entries(buf: np.ndarray, indices, n_entries: int, layout: int):
     """(K-slot, V-slot) rows ``[n_entries, H, D]`` of a pool layer, in logical order."""
-    S = buf.shape[2] if layout == 0 else buf.shape[3]
+    S = buf.shape[3] if layout == 1 else buf.shape[2]
     idx = np.asarray(indices)
     pages = buf[idx]  # [n, 2, ...]
     if layout == 1:
         pages = pages.transpose(0, 1, 3, 2, 4)  # -> [n, 2, S, H, D]
+    if layout == 2:  # row-rotated NHD: head h's K vector of entry e sits in slot h ^ (e & rot), V in that slot ^ flip
+        import torch
+        from quest_amd.utils.utils import TensorLayout
+
+        pages = TensorLayout.to_logical(torch.from_numpy(np.ascontiguousarray(pages).view(np.int16)), 2).numpy().view(pages.dtype)
     n, _, _, H, D = pages.shape
     k = pages[:, 0].reshape(n * S, H, D)[:n_entries]
     v = pages[:, 1].reshape(n * S, H, D)[:n_entries]

@@ -28,7 +28,7 @@ def _one(meta, fragment):
 @pytest.mark.parametrize("fragment,max_lds", [
     ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi3E", 14 * 1024),   # cfg 3: the timed single-sequence launch
     ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi1E", 14 * 1024),   # batched two-launch form (cfg 5)
-    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi8E", 14 * 1024),   # cfg 4: tiles front end
+    ("sparse_decode_kernelILi128ELi16ELi8ELi8ELi8E", 15 * 1024),   # cfg 4: tiles front end (round 6: the page list holds 256 ids, + 512 B)
     ("sparse_decode_kernelILi128ELi16ELi24ELi8ELi2E", 18 * 1024),  # long rows without tile maxima
     ("sparse_decode_kernelILi128ELi16ELi0ELi4ELin1E", 3 * 1024),   # index-list launches (reference op sequence)
     ("sparse_decode_kernelILi128ELi16ELi0ELi8ELin1E", 5 * 1024),

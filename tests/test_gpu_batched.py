@@ -29,6 +29,10 @@ def _gather(buf_layer, indices, n_entries, layout):
     pages = buf_layer[idx]
     if layout == 1:
         pages = pages.permute(0, 1, 3, 2, 4)
+    if layout == 2:  # the row-rotated pool (QUEST_LAYOUT_NHD_ROT): back to head order
+        from quest_amd.utils.utils import TensorLayout
+
+        pages = TensorLayout.to_logical(pages.view(torch.int16), 2).view(pages.dtype)
     n, _, S, H, D = pages.shape
     return pages[:, 0].reshape(n * S, H, D)[:n_entries], pages[:, 1].reshape(n * S, H, D)[:n_entries]
 
@@ -43,6 +47,10 @@ def _gather(buf_layer, indices, n_entries, layout):
     (8, 8, 0, (16 * 70 + 3, 16 * 24 + 15, 16 * 24 + 16, 16 * 50 + 8, 16 * 9 + 9), False, 128),
     # cfg-5 head shapes, 8 sequences: one workgroup per head -> the XCD-aware grid order (heads of a kv-head group on one XCD)
     (32, 8, 0, (16 * 20 + 5, 16 * 9 + 16, 16 * 31 + 1, 16 * 12 + 7, 16 * 25 + 3, 16 * 8 + 2, 16 * 17 + 9, 16 * 30 + 16), False, 128),
+    # the row-rotated pool (QUEST_LAYOUT_NHD_ROT): GQA 32 / 8 (rot 3, flip 4), MHA with 32 heads (rot 3, flip 28), head_dim 64
+    (32, 8, 2, (16 * 20 + 5, 16 * 9 + 16, 16 * 31 + 1, 16 * 12 + 7, 16 * 25 + 3, 16 * 8 + 2, 16 * 17 + 9, 16 * 30 + 16), False, 128),
+    (32, 32, 2, (16 * 31 + 10, 16 * 20 + 16, 16 * 40 + 1), True, 128),
+    (8, 4, 2, (16 * 12 + 3, 16 * 26 + 16, 7), True, 64),
 ])
 def test_batched_decode_matches_single_sequence(Hq, Hkv, layout, lens, same_split, D):
     import quest_amd.utils as qu
@@ -304,6 +312,8 @@ def test_model_batched_generation_matches_single_sequence(fused, lens):
     (8, 8, 0, 128, (16 * 40 + 3, 16 * 9 + 16, 16 * 25 + 1, 5), (7, 30, 26, 4)),
     (8, 2, 1, 128, (16 * 33 + 9, 16 * 12 + 2, 16 * 20 + 16), (12, 5, 21)),
     (4, 4, 0, 64, (16 * 18 + 7, 16 * 50 + 16), (9, 3)),
+    (32, 8, 2, 128, (16 * 33 + 9, 16 * 12 + 2, 16 * 20 + 16), (12, 5, 21)),
+    (16, 16, 2, 128, (16 * 40 + 3, 16 * 9 + 16, 5), (7, 30, 4)),
 ])
 def test_batched_eager_ops_with_per_sequence_budgets_match_single_sequence_ops(Hq, Hkv, layout, D, lens, budgets):
     """The four operators of a decode step one by one for a whole batch, WITHOUT a captured graph and with a page budget
@@ -410,6 +420,16 @@ def _logical_pages(ctl, phys):
     # GQA: the query heads of a group are separate workgroups that re-read their kv head's metadata; one of them appends
     (8, 2, 0, 128, 7, (16 * 22 + 3, 16 * 30 + 16, 16 * 17 + 1), None, False),
     (32, 8, 0, 128, 6, (16 * 20 + 5, 16 * 9 + 16, 16 * 31 + 1, 16 * 12 + 7, 16 * 25 + 3, 16 * 8 + 2, 16 * 17 + 9, 16 * 30 + 16), None, False),
+    # round 6: up to 255 selected pages in one workgroup (token budget 4096 = 256 pages, the reference's largest:
+    # scripts/passkey.sh:11); one sequence still shorter than the budget
+    (4, 4, 0, 128, 256, (16 * 300 + 10, 16 * 280 + 16, 16 * 100 + 3), None, False),
+    (8, 8, 2, 128, 200, (16 * 260 + 1, 16 * 199 + 16), None, False),
+    (4, 4, 0, 64, 256, (16 * 270 + 7, 16 * 400 + 16), (256, 130), False),
+    # the row-rotated pool: MHA with 32 heads (the shape the layout is for), 4 heads, head_dim 64, GQA, odd q
+    (32, 32, 2, 128, 9, (16 * 31 + 10, 16 * 15 + 16, 16 * 40 + 1, 19), None, False),
+    (4, 4, 2, 128, 7, (16 * 31 + 10, 16 * 15 + 16, 16 * 40 + 1, 19, 7), None, True),
+    (8, 8, 2, 64, 9, (16 * 33 + 9, 16 * 50 + 16), None, False),
+    (32, 8, 2, 128, 6, (16 * 20 + 5, 16 * 9 + 16, 16 * 31 + 1, 16 * 12 + 7), None, False),
 ])
 def test_one_launch_layer_equals_two_launches(Hq, Hkv, layout, D, B, lens, budgets, odd_q):
     """The one-launch layer of a batched step (csrc/layer_device.cuh: a workgroup per (sequence, head) appends, scores its

@@ -41,7 +41,7 @@ def _raw_meta(seed, n_pages, S, H, D, layout, slack=2):
     """A metadata pool whose BOTH slots are N(0,1) (test_max_possible.cu:50-51), shuffled page table."""
     n_meta = (n_pages + S - 1) // S
     cap = n_meta + slack
-    shape = (cap, 2, S, H, D) if layout == oracle.NHD else (cap, 2, H, S, D)
+    shape = (cap, 2, H, S, D) if layout == oracle.HND else (cap, 2, S, H, D)
     # numpy's generator (same image on the GPU box): the libm-free synth generator takes minutes at the sweep's
     # largest pools, and no golden file depends on these bytes
     data = np.random.default_rng(seed).standard_normal(shape, dtype=np.float32).astype(np.float16)
@@ -83,13 +83,18 @@ def _slots(meta: oracle.Paged, n):
     pages = meta.data[meta.indices]
     if meta.layout == oracle.HND:
         pages = pages.transpose(0, 1, 3, 2, 4)
+    if meta.layout == oracle.NHD_ROT:  # the row-rotated pool: back to head order
+        from quest_amd.utils.utils import TensorLayout
+
+        pages = TensorLayout.to_logical(torch.from_numpy(np.ascontiguousarray(pages).view(np.int16)), 2).numpy().view(np.float16)
     m, _, S, H, D = pages.shape
     return (pages[:, 0].reshape(m * S, H, D)[:n].astype(np.float32),
             pages[:, 1].reshape(m * S, H, D)[:n].astype(np.float32))
 
 
 @pytest.mark.parametrize("Hq,Hkv,D,S,layout", [(32, 8, 128, 16, 0), (8, 2, 64, 16, 1), (8, 8, 256, 16, 0), (16, 2, 128, 8, 1),
-                                                (32, 4, 128, 16, 0), (6, 3, 128, 7, 0), (4, 4, 64, 1, 1)])
+                                                (32, 4, 128, 16, 0), (6, 3, 128, 7, 0), (4, 4, 64, 1, 1),
+                                                (32, 8, 128, 16, 2), (32, 32, 128, 16, 2), (8, 4, 64, 16, 2), (6, 6, 128, 7, 2), (16, 8, 256, 16, 2)])
 def test_unordered_slots_gqa_layouts_dims(Hq, Hkv, D, S, layout):
     n_pages = 777
     meta = _raw_meta(11 + Hq + D + S, n_pages, S, Hkv, D, layout)
@@ -98,7 +103,7 @@ def test_unordered_slots_gqa_layouts_dims(Hq, Hkv, D, S, layout):
 
 
 @pytest.mark.parametrize("Hq,Hkv", [(8, 8), (16, 4)])
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_nonfinite_and_sentinel_metadata(Hq, Hkv, layout):
     """+-inf, NaN and the +-65504 open-page sentinels in either slot; the reference's max() keeps the finite
     product where one product is NaN or -inf."""

@@ -177,7 +177,8 @@ def test_cfg4_llama31_gqa_131072_tokens_budget_256_pages():
     torch.testing.assert_close(od[0].float(), od_ref, rtol=5e-3, atol=5e-3)
 
 
-def test_cfg5_eight_batched_32k_gqa_sequences():
+@pytest.mark.parametrize("layout", [0, 2], ids=["NHD", "NHD_ROT"])
+def test_cfg5_eight_batched_32k_gqa_sequences(layout):
     import quest_amd.utils as qu
 
     n, Hq, Hkv, B = 8, 32, 8, 128
@@ -185,7 +186,7 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
     lens = [32768, 32768, 32767, 32755, 32768, 32760, 32752, 32768]
     dev = torch.device(DEV)
     b = qu.BatchedInferenceController(n, 1, Hq, D, PAGE, B, 32768 + 64, torch.float16, dev, num_kv_heads=Hkv,
-                                      shuffle_seed=55)
+                                      shuffle_seed=55, layout=layout)
     g = torch.Generator(device=DEV).manual_seed(5)
     ks, vs = [], []
     for c, L in zip(b.seqs, lens):
@@ -242,7 +243,7 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
         kv_table = list(c.kv_cache.indicies)
         assert states[i][:3] == [L, n_pages, (L - 1) % PAGE + 1] and len(kv_table) == n_pages
         e_est, ev, ei = _expected(q[i:i + 1].cpu().numpy(), meta_np, c.metadata_cache.indicies,
-                                  c.metadata_cache.last_page_len, kv_table, B)
+                                  c.metadata_cache.last_page_len, kv_table, B, layout)
         assert np.array_equal(U16(scores[i, :, : n_pages - 1].cpu().numpy()), U16(e_est)), f"sequence {i}: scores"
         assert np.array_equal(sel_i[i].cpu().numpy(), ei), f"sequence {i}: selected pages"
         assert np.array_equal(U16(sel_v[i].cpu().numpy()), U16(ev))
@@ -251,7 +252,8 @@ def test_cfg5_eight_batched_32k_gqa_sequences():
         # the new token landed in the cache and was folded into its page's metadata
         last = c.kv_cache.indicies[-1]
         slot = (L - 1) % PAGE
-        assert torch.equal(b.kv_layer(0)[last, 0, slot], ks[i][-1]) and torch.equal(b.kv_layer(0)[last, 1, slot], vs[i][-1])
+        page = qu.TensorLayout.to_logical(b.kv_layer(0)[last].view(torch.int16), layout).view(torch.float16)  # [2, S, Hkv, D]
+        assert torch.equal(page[0, slot], ks[i][-1]) and torch.equal(page[1, slot], vs[i][-1])
 
 
 def _prefill(ctl, k, v):
@@ -264,7 +266,7 @@ def _prefill(ctl, k, v):
     ctl.end_forward()
 
 
-@pytest.mark.parametrize("layout", [0, 1], ids=["NHD", "HND"])
+@pytest.mark.parametrize("layout", [0, 1, 2], ids=["NHD", "HND", "NHD_ROT"])
 def test_cfg3_headline_on_the_timed_path(layout):
     """BASELINE configs[2] (the headline: Hq = Hkv = 32, D = 128, L = 32768, budget 2048 tokens = 128 pages) through the
     launches bench.py TIMES -- device-resident step state, `step_advance_dyn` + `decode_layer_dyn`, pool capacity of the
@@ -276,7 +278,7 @@ def test_cfg3_headline_on_the_timed_path(layout):
     import quest_amd.utils as qu
 
     def entries(pool_pages):  # [n, 2, ...] pages of a pool layer -> (K-slot rows, V-slot rows) as [n * S, H, D]
-        x = pool_pages if layout == 0 else pool_pages.permute(0, 1, 3, 2, 4)
+        x = qu.TensorLayout.to_logical(pool_pages.view(torch.int16), layout).view(torch.float16)  # -> [n, 2, S, H, D], head order
         return x[:, 0].reshape(-1, H, D), x[:, 1].reshape(-1, H, D)
 
     L, H, B = 32768, 32, 128
@@ -345,9 +347,11 @@ def test_cfg3_headline_on_the_timed_path(layout):
     assert torch.equal(kk[slot], k[-1]) and torch.equal(vv[slot], v[-1])
 
 
-@pytest.mark.parametrize("extra_tokens,stride,one_launch", [(280, 2068, True), (280, 2068, False), (264, 2068, True),
-                                                            (328, 2072, True), (328, 2072, False)])
-def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride, one_launch):
+@pytest.mark.parametrize("extra_tokens,stride,one_launch,layout", [(280, 2068, True, 0), (280, 2068, False, 0), (264, 2068, True, 0),
+                                                                   (328, 2072, True, 0), (328, 2072, False, 0),
+                                                                   # the row-rotated pool (QUEST_LAYOUT_NHD_ROT), the shape it is for
+                                                                   (280, 2068, True, 2), (328, 2072, False, 2)])
+def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride, one_launch, layout):
     """The `batched_8seq` side measurement of bench.py (8 x cfg-3 MHA sequences) through its timed entry points at the
     bench's own pool capacities -- 2066 / 2065 / 2069 pages per sequence, none a multiple of 4, which used to push every
     batched launch onto the scalar-load front end.  one_launch: the layer as ONE launch (layer_decode_kernel: what the
@@ -358,7 +362,7 @@ def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride
 
     n, H, B, L = 8, 32, 128, 32768
     dev = torch.device(DEV)
-    b = qu.BatchedInferenceController(n, 1, H, D, PAGE, B, L + extra_tokens, torch.float16, dev, shuffle_seed=77)
+    b = qu.BatchedInferenceController(n, 1, H, D, PAGE, B, L + extra_tokens, torch.float16, dev, shuffle_seed=77, layout=layout)
     g = torch.Generator(device=DEV).manual_seed(8)
     lens = [L, L - 1, L, L - 13, L, L, L - 8, L]
     ks, vs = [], []
@@ -400,7 +404,7 @@ def test_cfg3_eight_batched_mha_sequences_on_the_timed_path(extra_tokens, stride
         n_pages = (Li + PAGE - 1) // PAGE
         kv_table = list(c.kv_cache.indicies)
         e_est, ev, ei = _expected(q[i:i + 1].cpu().numpy(), meta_np, c.metadata_cache.indicies,
-                                  c.metadata_cache.last_page_len, kv_table, B)
+                                  c.metadata_cache.last_page_len, kv_table, B, layout)
         assert np.array_equal(U16(scores[i, :, : n_pages - 1].cpu().numpy()), U16(e_est)), f"sequence {i}: scores"
         assert np.array_equal(sel_i[i].cpu().numpy(), ei), f"sequence {i}: selected pages"
         assert np.array_equal(U16(sel_v[i].cpu().numpy()), U16(ev))

@@ -27,7 +27,10 @@ def _cases(n, seed):
         n_pages = int(rng.integers(2, 60))
         L = (n_pages - 1) * page + int(rng.integers(1, page + 1))
         B = int(rng.integers(2, n_pages + 3))  # sometimes >= pages: the full-attention branch
-        out.append((Hkv * G, Hkv, D, page, L, B, int(rng.integers(0, 2)), int(rng.integers(0, 1 << 20))))
+        layout = int(rng.integers(0, 2))  # (the draw of earlier rounds: the other parameters keep their sequence)
+        if len(out) % 3 == 2:
+            layout = 2  # every third case on the row-rotated pool (QUEST_LAYOUT_NHD_ROT)
+        out.append((Hkv * G, Hkv, D, page, L, B, layout, int(rng.integers(0, 1 << 20))))
     return out
 
 

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 PAGE = 16
 
 
-@pytest.mark.parametrize("Hq,Hkv,layout,L0,steps", [(4, 4, 0, 16 * 31 + 10, 45), (8, 2, 1, 16 * 15 + 16, 40)])
+@pytest.mark.parametrize("Hq,Hkv,layout,L0,steps", [(4, 4, 0, 16 * 31 + 10, 45), (8, 2, 1, 16 * 15 + 16, 40),
+                                                  (32, 8, 2, 16 * 15 + 16, 40), (32, 32, 2, 16 * 31 + 10, 40)])
 def test_graph_replay_matches_eager_over_growing_sequence(Hq, Hkv, layout, L0, steps):
     import quest_amd.utils as qu
     from quest_amd import _kernels
@@ -57,8 +58,8 @@ def test_graph_replay_matches_eager_over_growing_sequence(Hq, Hkv, layout, L0, s
     kbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     vbuf = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
     # first case: 16-byte aligned score rows (second-generation front end), second: odd stride (first generation)
-    scores = qu.score_scratch(gr) if layout == 0 else torch.empty(Hq, gr.max_pages | 1, device=dev, dtype=torch.float16)
-    gr._decode_handler.set_front_end(2 if layout == 0 else 1)
+    scores = qu.score_scratch(gr) if layout != 1 else torch.empty(Hq, gr.max_pages | 1, device=dev, dtype=torch.float16)
+    gr._decode_handler.set_front_end(2 if layout == 0 else 1 if layout == 1 else 0)
     obuf = [None] * layers
 
     def step():
@@ -408,7 +409,7 @@ def test_stale_decode_graph_is_refused_after_quest_clear():
 
 
 @pytest.mark.parametrize("Hq,Hkv,D,layout,L0", [(8, 8, 128, 0, 70), (8, 2, 128, 1, 33), (4, 1, 64, 0, 16 * 17), (16, 2, 128, 0, 300),
-                                                 (32, 32, 128, 0, 4096 - 5)])
+                                                 (32, 32, 128, 0, 4096 - 5), (32, 32, 128, 2, 16 * 40 - 5), (32, 8, 128, 2, 300), (8, 4, 64, 2, 100)])
 def test_dense_layer_with_the_append_folded_into_the_attention_launch(Hq, Hkv, D, layout, L0):
     """A full-KV layer of a captured step is TWO launches (attention with the decode append folded in + merge) instead of
     three: same KV pool bytes, same metadata bytes and the same output bits as the separate append launch followed by the

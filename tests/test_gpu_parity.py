@@ -33,7 +33,7 @@ def _close(a, b, tol=5e-3):
 
 # ---------------------------------------------------------------------------- append / metadata
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("L,split", [(27, None), (61, 17), (113, 100), (482, None), (1011, 1000), (33, 32), (17, 16)])
 def test_append_bit_exact(layout, L, split):
     Hq = Hkv = 8
@@ -63,7 +63,7 @@ def test_append_chunked_prefill_bit_exact():
 
 # ---------------------------------------------------------------------------- estimate
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_estimate_bit_exact_and_golden(golden, layout):
     qu = _qu()
     for seed, L, H in golden["est_cases"]:
@@ -86,7 +86,7 @@ def test_estimate_gqa_dims_pages(Hq, Hkv, D, page):
     qu = _qu()
     L = 777
     q, k, v = inputs(50 + Hq + D, L, Hq, Hkv, D)
-    for layout in (0, 1):
+    for layout in (0, 1, 2):
         ctl = make_controller(L, Hq, Hkv, D, page, 1024, layout=layout, shuffle_seed=1)
         fill(ctl, k, v)
         got = qu.decode_estimate(cuda(q), ctl, 0).cpu().numpy()
@@ -175,7 +175,7 @@ def test_sparse_attention_golden_indices(golden):
     for seed, L, H, B, has_idx in golden["approx_cases"]:
         seed, L, H, B = int(seed), int(L), int(H), int(B)
         q, k, v = inputs(seed, L, H)
-        for layout in (0, 1):
+        for layout in (0, 1, 2):
             ctl = make_controller(L, H, H, 128, PAGE, B, layout=layout, shuffle_seed=seed)
             fill(ctl, k, v)
             table = np.array(ctl.kv_cache.indicies, np.int32)
@@ -216,7 +216,7 @@ def test_chain_gqa_dims_pages(Hq, Hkv, D, page, B):
     qu = _qu()
     L = 613
     q, k, v = inputs(70 + Hq + D + page, L, Hq, Hkv, D)
-    for layout in (0, 1):
+    for layout in (0, 1, 2):
         ctl = make_controller(L, Hq, Hkv, D, page, B, layout=layout, shuffle_seed=2)
         fill(ctl, k, v)
         assert ctl.need_estimate()

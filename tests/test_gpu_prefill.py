@@ -72,6 +72,10 @@ def test_prefill_vs_reference_fixtures():
     (90, 200, 2, 2, 1, 1, True),
     (257, 640, 4, 1, 31, 0, True),
     (100, 260, 2, 2, 3, 0, False),
+    (200, 1000, 8, 2, 16, 2, True),     # the row-rotated pool (QUEST_LAYOUT_NHD_ROT): GQA, MHA with 32 heads, generic page walk
+    (300, 515, 32, 32, 16, 2, False),
+    (150, 411, 4, 4, 7, 2, True),
+    (129, 300, 16, 8, 16, 2, True),
 ])
 def test_prefill_vs_oracle(qo, kv, Hq, Hkv, page, layout, causal):
     q, k, v = _randn(qo * 7 + kv, qo, Hq, 128), _randn(kv + 1, kv, Hkv, 128), _randn(kv + 2, kv, Hkv, 128)
@@ -91,6 +95,8 @@ def test_prefill_vs_oracle(qo, kv, Hq, Hkv, page, layout, causal):
     (300, 515, 4, 4, 16, 1, False),
     (150, 411, 4, 2, 7, 0, True),
     (257, 640, 4, 1, 31, 1, True),
+    (200, 700, 8, 4, 16, 2, True),
+    (120, 333, 8, 8, 5, 2, True),
 ])
 def test_prefill_other_head_dims_vs_oracle(D, qo, kv, Hq, Hkv, page, layout, causal):
     """head_dim 64 (two LDS buffers of 32 KiB, 32-row staging passes) and 256 (one wave per SIMD, ONE buffer and a second
@@ -113,6 +119,8 @@ def test_prefill_fuzz_vs_oracle():
         Hkv, group = int(rng.integers(1, 10)), int(rng.choice([1, 1, 2, 4]))
         page = int(rng.choice([16, 16, 16, 1, 2, 5, 8, 24, 33]))
         layout, causal = int(rng.integers(0, 2)), bool(rng.integers(0, 4))
+        if case % 3 == 2:
+            layout = 2  # the row-rotated pool
         D = int(rng.choice([128, 128, 64, 256]))
         q = _randn(3 * case, qo, Hkv * group, D)
         k, v = _randn(3 * case + 1, kv, Hkv, D), _randn(3 * case + 2, kv, Hkv, D)

@@ -49,7 +49,7 @@ def _host_pool(cache, layout):
 
 
 @pytest.mark.parametrize("page_size", [1, 3, 7, 16, 31])
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_append_reference_sweep_pools_bit_exact(page_size, layout):
     for seq_len in (17, 31, 71, 111, 330, 512, 1110, 4100):
         for D in (64, 128, 256):

@@ -50,7 +50,7 @@ def test_estimate_matches_reference_oracle(golden):
     worst = 0.0
     for seed, L, H in golden["est_cases"]:
         q, k, v = _inputs(int(seed), int(L), int(H))
-        for layout in (oracle.NHD, oracle.HND):
+        for layout in (oracle.NHD, oracle.HND, oracle.NHD_ROT):
             kv, meta = synth.build_sequence(k, v, PAGE, layout=layout, perm_seed=int(seed))
             got = oracle.estimate(q, meta)
             ref = golden[f"est_{L}"]
@@ -240,3 +240,55 @@ def test_prefill_oracle_matches_reference_oracle():
     full = torch_ref.prefill_attention(q, k, v, causal=False)
     last = torch_ref.prefill_attention(q[-1:], k, v, causal=True)
     torch.testing.assert_close(full[-1:], last, rtol=1e-6, atol=1e-6)
+
+
+def test_row_rotated_layout_is_a_permutation_of_nhd_and_gives_the_same_results():
+    """Layout 2 (NHD_ROT, include/quest_hip.h: head h's K / max vector of entry e in head slot h ^ (e & rot), its V / min
+    vector in that slot ^ flip) is this build's extension, not the reference's: it may only change WHERE a vector lives.
+    For head counts with every (rot, flip) combination, page sizes 16 / 7 / 1, prefill + decode appends: the pools are the
+    NHD pools permuted by the definition (quest_amd.utils.TensorLayout.to_logical restates it in torch), and estimate,
+    top-k and attention give the NHD results bit for bit."""
+    from quest_amd.utils.utils import TensorLayout
+
+    for H, S, L in ((32, 16, 16 * 19 + 5), (8, 16, 16 * 20), (4, 16, 300), (6, 7, 200), (12, 16, 257), (16, 16, 16 * 17 + 1),
+                    (2, 1, 40), (3, 16, 100), (64, 16, 16 * 16 + 3)):
+        D = 64
+        rot, flip = TensorLayout.rotation(H)
+        low = H & -H
+        assert rot == min(low, 4) - 1 and flip == ((min(low, 32) - 1) & ~3) and (rot | flip) < max(low, 1)
+        q = synth.normal_f16(H * 7 + 1, (1, 2 * H, D))  # GQA 2: per-query-head scores against the kv head's metadata
+        k, v = synth.normal_f16(H * 7 + 2, (L, H, D)), synth.normal_f16(H * 7 + 3, (L, H, D))
+        res = {}
+        for layout in (oracle.NHD, oracle.NHD_ROT):
+            n0 = L - 9
+            kv, meta = synth.build_sequence(k[:n0], v[:n0], S, layout=layout, perm_seed=5, slack_pages=4)
+            # build_sequence sized the pools for n0 tokens + slack: grow token by token through the decode append
+            full_kv, full_meta = synth.build_sequence(k, v, S, layout=layout, perm_seed=5, slack_pages=4)
+            kv = oracle.Paged(np.zeros_like(full_kv.data), full_kv.indices, 1, layout)
+            meta = oracle.Paged(np.zeros_like(full_meta.data), full_meta.indices, 1, layout)
+            n_pages0, n_meta0 = (n0 + S - 1) // S, ((n0 + S - 1) // S + S - 1) // S
+            kv = oracle.Paged(kv.data, full_kv.indices[:n_pages0], (n0 - 1) % S + 1, layout)
+            meta = oracle.Paged(meta.data, full_meta.indices[:n_meta0], (n_pages0 - 1) % S + 1, layout)
+            oracle.append_prefill(kv, meta, k[:n0], v[:n0])
+            for t in range(n0, L):
+                n_pages, n_meta = t // S + 1, (t // S) // S + 1
+                kv = oracle.Paged(kv.data, full_kv.indices[:n_pages], t % S + 1, layout)
+                meta = oracle.Paged(meta.data, full_meta.indices[:n_meta], (n_pages - 1) % S + 1, layout)
+                oracle.append_decode(kv, meta, k[t:t + 1], v[t:t + 1])
+            assert np.array_equal(kv.data.view(np.uint16), full_kv.data.view(np.uint16)), (H, S, "append paths disagree")
+            assert np.array_equal(meta.data.view(np.uint16), full_meta.data.view(np.uint16))
+            est = oracle.estimate(q, meta)
+            n_sel = min(5, est.shape[1])
+            vals, idx = oracle.topk(est, np.tile(kv.indices[:-1], (2 * H, 1)), n_sel)
+            o, _ = oracle.sparse_attn(q, kv, idx, n_sel, int(kv.indices[-1]), kv.last_page_len)
+            res[layout] = (kv, meta, est, vals, idx, o)
+        a, b = res[oracle.NHD], res[oracle.NHD_ROT]
+        for i in (2, 3, 4, 5):
+            assert np.array_equal(np.asarray(a[i]).view(np.uint16 if a[i].dtype == np.float16 else a[i].dtype),
+                                  np.asarray(b[i]).view(np.uint16 if b[i].dtype == np.float16 else b[i].dtype)), (H, S, i)
+        for pa, pb in ((a[0], b[0]), (a[1], b[1])):  # pools: rotated == NHD permuted by the definition
+            used = pa.indices
+            back = TensorLayout.to_logical(torch.from_numpy(pb.data[used].view(np.int16)), 2).numpy()
+            assert np.array_equal(back, pa.data[used].view(np.int16)), (H, S)
+            if (rot and S > 1) or flip:  # (a one-entry page has nothing to rotate by)
+                assert not np.array_equal(pb.data[used].view(np.int16), pa.data[used].view(np.int16))
