@@ -104,6 +104,9 @@ def parse(argv=None):
     ap.add_argument("--separate-dense-append", action="store_true",
                     help="full-KV layers: issue the decode append as its own launch (three launches per layer, as before "
                          "round 4) instead of folded into the attention launch (A/B)")
+    ap.add_argument("--separate-advance", action="store_true",
+                    help="single-sequence graph steps: head every step with the step_state_advance launch (as before round 6) "
+                         "instead of letting the next token's reservation ride in the last layer's merge launch (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--kernel-sweep", action="store_true",
@@ -236,6 +239,7 @@ class Workload:
         n_pages_end = (cap_tokens + a.page_size - 1) // a.page_size
         self.dense = self.page_budget >= n_pages_end  # budget covers the cache for the whole run: full-KV decode
         self.dyn = a.mode == "graph" and a.skip_layers == 0 and not a.unfused
+        self.fold = self.dyn and not a.separate_advance  # see prime()
         if self.dyn:
             # state-driven stepping: the graph's first node reserves the token on the device
             ctl.enable_device_state()
@@ -249,17 +253,27 @@ class Workload:
         else:
             ctl.prepare_metadata(1)
 
+    def prime(self):
+        """Folded stepping (round 6): the NEXT token's reservation rides in the last layer's merge launch instead of heading
+        every step as a 1-thread launch of its own (4.7 us of dependent latency per token) -- so the first token is reserved
+        here, once, before the first step; device state and host mirror then run one reserved token ahead."""
+        if self.dyn and self.fold:
+            self.qu.step_advance_dyn(self.ctl)
+            self.ctl.prepare_metadata(1)
+
     def step_dyn(self):
         """One decode token, every length read from device memory (replayable as the sequence grows)."""
         qu, ctl, a = self.qu, self.ctl, self.a
-        qu.step_advance_dyn(ctl)
+        if not self.fold:
+            qu.step_advance_dyn(ctl)
         for layer in range(a.layers):
+            last = self.fold and layer == a.layers - 1
             if self.dense:
                 self.outs[layer] = qu.decode_layer_dense_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer,
-                                                             fuse_append=not a.separate_dense_append)
+                                                             fuse_append=not a.separate_dense_append, advance_after=last)
             else:
                 self.outs[layer] = qu.decode_layer_dyn(self.q[layer], self.k1[layer], self.v1[layer], ctl, layer,
-                                                       self.scores)
+                                                       self.scores, advance_after=last)
 
     def after_replay(self):
         if self.dyn:
@@ -699,6 +713,9 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
 
     # ---- the step, eager or captured
     if a.mode in ("graph", "graph-static") and not stub:
+        for wl in ws:
+            if hasattr(wl, "prime"):
+                wl.prime()  # folded stepping: reserve the first token once (the host mirror follows)
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(warm):
@@ -706,7 +723,7 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         for wl in ws:
-            wl.sync()  # the warm-up advanced the device state; start from the prefilled cache
+            wl.sync()  # the warm-up advanced the device state; start from the host mirror's (prefilled [+ primed]) cache
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step_all()
@@ -779,7 +796,9 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
                        "head_dim": a.head_dim, "seqlen": a.seqlen, "page_size": a.page_size,
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
                        "kv_layout": a.layout, "mode": a.mode, "seed": a.seed, "skip_layers": a.skip_layers,
-                       "launches_per_layer": "5 (reference op sequence)" if a.unfused else
+                       "launches_per_layer": ("3 (append | full-KV attention | merge)" if a.separate_dense_append else
+                                              "2 (full-KV attention with the decode append folded in | merge)")
+                       if not bpl["sparse"] else "5 (reference op sequence)" if a.unfused else
                        "1 (a workgroup per (sequence, head): append + estimate into LDS + top-k from LDS + sparse attn)"
                        if getattr(w, "one_launch", False) else "3 (append+estimate | top-k+sparse attn | merge)",
                        "sequences_per_gpu": n_local,

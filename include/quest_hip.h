@@ -318,6 +318,18 @@ typedef struct quest_batch {
 int quest_step_state_advance_batched(quest_step_state_t* state, const int32_t* kv_tables, const int32_t* meta_tables,
                                      uint32_t page_size, uint32_t max_kv_pages, uint32_t max_meta_pages,
                                      quest_batch_t batch, quest_stream_t stream);
+
+/* The same reservation RIDING IN A STEP'S LAST LAUNCH (round 6): quest_step_state_advance at the head of a captured step is a
+ * 1-thread launch of dependent loads -- 4.7 us per token.  Nothing after a layer's merge launch reads the step state, so the
+ * reservation for the NEXT token can be made there: arm it on the handler right before the last layer's forward call of a
+ * step; the merge launch of that call carries it (one thread per sequence of its first workgroup) and the handler disarms.
+ * A forward whose plan has no merge launch issues it as its own launch behind the attention kernel (correct, nothing saved).
+ * The caller reserves the FIRST token with quest_step_state_advance before the first step; from then on the device state
+ * (and its host mirror, InferenceController.prepare_metadata(1) after every step) runs one reserved token ahead of the
+ * tokens appended.  state == NULL disarms.  At most 64 sequences. */
+int quest_decode_arm_step_advance(quest_decode_handler_t* h, quest_step_state_t* state, const int32_t* kv_tables,
+                                  const int32_t* meta_tables, uint32_t page_size, uint32_t max_kv_pages,
+                                  uint32_t max_meta_pages, quest_batch_t batch);
 int quest_append_estimate_batched(const void* k, const void* v, quest_paged_kv_t kv, const void* q, void* o,
                                   uint32_t num_qo_heads, uint32_t o_stride, uint32_t max_n_out,
                                   quest_paged_kv_t metadata, const quest_step_state_t* state, quest_batch_t batch,

@@ -942,6 +942,23 @@ class BatchDecodeWithPagedKVCachePyTorchWrapper:
                                                  idx_out.data_ptr() if idx_out is not None else None),
               "set_selection_out")
 
+    def arm_step_advance(self, state, kv_tables, meta_tables, page_size: int) -> None:
+        """The NEXT token's reservation (``step_state_advance``) rides in this handler's next forward call: in its merge
+        launch where the plan has one, as its own launch behind the attention kernel otherwise.  ``state`` is the step state
+        ``[8]`` (one sequence, tables ``[capacity]``) or ``[n, 8]`` (tables ``[n, capacity]``).  Call right before the LAST
+        layer's forward of a step whose first token was reserved by ``step_state_advance`` (quest_hip.h)."""
+        for t, n in ((state, "state"), (kv_tables, "kv_tables"), (meta_tables, "meta_tables")):
+            _check_input(t, n)
+            _check_eq(t.dtype, torch.int32, f"{n}.scalar_type(), torch::kInt32")
+        if state.dim() == 1:
+            b = Batch(1, 0, 0, 0, None)
+            max_kv, max_meta = kv_tables.numel(), meta_tables.numel()
+        else:
+            b = _batch(state, kv_tables, meta_tables)
+            max_kv, max_meta = kv_tables.size(1), meta_tables.size(1)
+        check(lib.quest_decode_arm_step_advance(self._h, state.data_ptr(), kv_tables.data_ptr(), meta_tables.data_ptr(),
+                                                int(page_size), max_kv, max_meta, b), "arm_step_advance")
+
     def set_skip_merge(self, skip: bool) -> None:
         """Measurement aid: launch only the attention kernel (partial states stay unmerged, ``o`` unwritten)."""
         check(lib.quest_decode_set_skip_merge(self._h, int(bool(skip))), "set_skip_merge")

@@ -77,6 +77,7 @@ SIGNATURES = {
     "quest_decode_forward_shared_dyn": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_vp, c_vp]),
     "quest_apply_rope_in_place_dyn": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_vp, c_vp]),
     "quest_step_state_advance_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, Batch, c_vp]),
+    "quest_decode_arm_step_advance": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, Batch]),
     "quest_append_estimate_batched": (ctypes.c_int, [c_vp, c_vp, PagedKV, c_vp, c_vp, c_u32, c_u32, c_u32, PagedKV,
                                                       c_vp, Batch, c_vp]),
     "quest_decode_forward_fused_topk_batched": (ctypes.c_int, [c_vp, c_vp, c_vp, PagedKV, c_u32, c_vp, c_u32, c_u32,

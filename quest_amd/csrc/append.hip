@@ -94,37 +94,11 @@ __global__ void step_state_advance_kernel(quest_step_state_t* st, const int32_t*
                                           const int32_t* __restrict__ meta_table, uint32_t S, uint32_t max_kv_pages,
                                           uint32_t max_meta_pages, quest_batch_t batch) {
     // prepare_metadata(1) of quest/utils/controller.py:72-76 + kv_cache.py:115-126, on the device;
-    // one thread per sequence
+    // one thread per sequence (body: append_device.cuh step_state_advance_one)
     const uint32_t seq = blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= batch.n_seqs) return;
-    st += seq;
-    kv_table += (size_t)seq * batch.kv_table_stride;
-    meta_table += (size_t)seq * batch.meta_table_stride;
-    quest_step_state_t s = *st;
-    if (s.kv_last_page_len == (int32_t)S &&
-        ((uint32_t)s.n_pages >= max_kv_pages ||
-         (s.meta_last_page_len == (int32_t)S && (uint32_t)s.n_meta_pages >= max_meta_pages))) {
-        // pool exhausted: stay on the last token (memory-safe; the host mirror raises "KvPool exhausted"
-        // right after the replay) and flag it
-        st->reserved = 1;
-        return;
-    }
-    s.seq_len += 1;
-    if (s.kv_last_page_len == (int32_t)S) {  // the token opens a new KV page ...
-        s.n_pages += 1;
-        s.kv_last_page_len = 1;
-        s.kv_last_page_idx = kv_table[s.n_pages - 1];
-        if (s.meta_last_page_len == (int32_t)S) {  // ... whose metadata entry may open a new metadata page
-            s.n_meta_pages += 1;
-            s.meta_last_page_len = 1;
-            s.meta_last_page_idx = meta_table[s.n_meta_pages - 1];
-        } else {
-            s.meta_last_page_len += 1;
-        }
-    } else {
-        s.kv_last_page_len += 1;
-    }
-    *st = s;
+    step_state_advance_one(st + seq, kv_table + (size_t)seq * batch.kv_table_stride,
+                           meta_table + (size_t)seq * batch.meta_table_stride, S, max_kv_pages, max_meta_pages);
 }
 
 int check_pool(const quest_paged_kv_t& p) {

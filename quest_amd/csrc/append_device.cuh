@@ -82,4 +82,49 @@ __device__ __forceinline__ void append_decode_body(const quest_paged_kv_t& kv, c
     *reinterpret_cast<ushort8*>(mmin) = mn;
 }
 
+// prepare_metadata(1) of quest/utils/controller.py:72-76 + kv_cache.py:115-126 for ONE sequence, on the device: reserve room
+// for one more token (a new KV page, and a new metadata page for its entry, where the last ones are full).  Run by the
+// step_state_advance launch (append.hip) or by one thread of a step's LAST launch (StepAdvance below).
+__device__ __forceinline__ void step_state_advance_one(quest_step_state_t* st, const int32_t* __restrict__ kv_table,
+                                                       const int32_t* __restrict__ meta_table, uint32_t S,
+                                                       uint32_t max_kv_pages, uint32_t max_meta_pages) {
+    quest_step_state_t s = *st;
+    if (s.kv_last_page_len == (int32_t)S &&
+        ((uint32_t)s.n_pages >= max_kv_pages ||
+         (s.meta_last_page_len == (int32_t)S && (uint32_t)s.n_meta_pages >= max_meta_pages))) {
+        // pool exhausted: stay on the last token (memory-safe; the host mirror raises "KvPool exhausted"
+        // right after the replay) and flag it
+        st->reserved = 1;
+        return;
+    }
+    s.seq_len += 1;
+    if (s.kv_last_page_len == (int32_t)S) {  // the token opens a new KV page ...
+        s.n_pages += 1;
+        s.kv_last_page_len = 1;
+        s.kv_last_page_idx = kv_table[s.n_pages - 1];
+        if (s.meta_last_page_len == (int32_t)S) {  // ... whose metadata entry may open a new metadata page
+            s.n_meta_pages += 1;
+            s.meta_last_page_len = 1;
+            s.meta_last_page_idx = meta_table[s.n_meta_pages - 1];
+        } else {
+            s.meta_last_page_len += 1;
+        }
+    } else {
+        s.kv_last_page_len += 1;
+    }
+    *st = s;
+}
+
+// The NEXT step's reservation riding in the last launch of this step (round 6): the 1-thread
+// step_state_advance launch at the head of a captured step costs 4.7 us of dependent latency per token.  No launch after a
+// layer's merge reads the step state, so thread `seq` of the merge launch's workgroup 0 runs it after its own work; the device
+// state (and its host mirror) then describe the cache one reserved token ahead between steps.
+struct StepAdvance {
+    quest_step_state_t* st;  // nullptr: nothing rides
+    const int32_t* kv_table;
+    const int32_t* meta_table;
+    uint32_t page_size, max_kv_pages, max_meta_pages;
+    quest_batch_t batch;
+};
+
 }  // namespace quest

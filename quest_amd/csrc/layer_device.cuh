@@ -198,13 +198,28 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     __shared__ uint32_t s_next;
     if (tid == 0) s_next = NW;
     __syncthreads();
+    // Tuning builds (GQA batches in one launch): -DQUEST_LAYER_GQA_STAGGER=<pages> starts the metadata
+    // walk of the j-th query head of a kv-head group j * <pages> metadata pages further (0: a j-th of the row further), so
+    // that the heads of a group -- co-located on one XCD by the grid order -- find each other's metadata in its L2 instead of
+    // streaming it four times; -DQUEST_LAYER_META_CACHED keeps those loads in the L2's normal replacement order.  Measured at
+    // cfg 5: profiles/r06_ab_gqa_one_launch_staggered_walk.txt.  (A page's scores do not depend on when they are computed.)
+#ifdef QUEST_LAYER_GQA_STAGGER
+    const uint32_t walk0 = n_mp == 0 ? 0u : ((hq % group) * (QUEST_LAYER_GQA_STAGGER > 0 ? (uint32_t)QUEST_LAYER_GQA_STAGGER : n_mp / group)) % n_mp;
+#else
+    constexpr uint32_t walk0 = 0;
+#endif
     auto issue = [&](uint32_t mp, half8 (&mx)[T], half8 (&mn)[T]) {  // request the 16 entries of metadata page mp
         const int32_t pg = ld_uniform_i32(meta_table + mp);
         const half_t* b0 = a_meta + (size_t)pg * p.st.page;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
+#ifdef QUEST_LAYER_META_CACHED
+            mx[t] = ld8(b0 + uni[t] + lane_off);
+            mn[t] = ld8(b0 + uni[t] + lane_off + v_off);
+#else
             mx[t] = ld8_stream(b0 + uni[t] + lane_off);
             mn[t] = ld8_stream(b0 + uni[t] + lane_off + v_off);
+#endif
         }
     };
     auto fetch = [&]() -> uint32_t {  // a page from the counter (broadcast from lane 0)
@@ -229,13 +244,14 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     // SLOWER: 89.9-92.3 vs 86.4 us per launch.  This access shape wants shallow queues: scripts/probe/addr_class_probe.hip.)
     for (uint32_t mp = wave; mp < n_mp;) {
         half8 mx[T], mn[T];
-        issue(mp, mx, mn);
+        const uint32_t mpw = mp + walk0 < n_mp ? mp + walk0 : mp + walk0 - n_mp;  // (walk0 = 0 outside the tuning builds)
+        issue(mpw, mx, mn);
         const uint32_t nx = fetch();  // the next round's page, asked for while this round's loads fly
         if (!ids_parked) {
             park_ids();
             ids_parked = true;
         }
-        score(mp, mx, mn);
+        score(mpw, mx, mn);
         mp = nx;
     }
     if (!ids_parked) park_ids();  // waves without a round (short sequences)

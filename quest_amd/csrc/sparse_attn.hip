@@ -320,13 +320,18 @@ template <int D>
 __global__ __launch_bounds__(D* kMergeGroups) void merge_states_kernel(const float* __restrict__ ws,
                                                                         half_t* __restrict__ o,
                                                                         float* __restrict__ lse, uint32_t n_chunks,
-                                                                        uint32_t ws_stride) {
+                                                                        uint32_t ws_stride, StepAdvance adv) {
     __shared__ float s_w[1024];  // per-chunk weight exp2(m_c - M); planner keeps n_chunks <= 1024
     __shared__ float s_red[kMergeGroups][D + 1];
     __shared__ float s_M;
     const uint32_t hq = blockIdx.x, tid = threadIdx.x;
     const uint32_t f = tid % D, g = tid / D;
     const float* w = ws + (size_t)hq * n_chunks * ws_stride;
+    // the next step's reservation (StepAdvance, append_device.cuh): nothing in or after this launch reads the state
+    if (adv.st && hq == 0 && tid < adv.batch.n_seqs)
+        step_state_advance_one(adv.st + tid, adv.kv_table + (size_t)tid * adv.batch.kv_table_stride,
+                               adv.meta_table + (size_t)tid * adv.batch.meta_table_stride, adv.page_size, adv.max_kv_pages,
+                               adv.max_meta_pages);
     if (n_chunks <= kMergeFastChunks) {  // launch-uniform
         merge_head_fast<D, D * kMergeGroups>(w, o + (size_t)hq * D, lse ? lse + hq : nullptr, n_chunks, ws_stride, tid,
                                                     &s_red[0][0]);
@@ -416,7 +421,26 @@ struct quest_decode_handler {
     uint32_t last_launch[6] = {0, 0, 0, 0, 0, 0};  // quest_decode_last_launch_info
     void* sel_val_out = nullptr;                 // inspection aid (quest_decode_set_selection_out)
     int32_t* sel_idx_out = nullptr;
+    StepAdvance armed_advance = {};              // quest_decode_arm_step_advance: rides in the next merge launch, once
 };
+
+// the armed reservation, handed to the merge launch that is about to be issued (and disarmed)
+static StepAdvance take_armed_advance(quest_decode_handler* h) {
+    const StepAdvance adv = h->armed_advance;
+    h->armed_advance = StepAdvance{};
+    return adv;
+}
+// a launch that turned out to have no merge launch (one workgroup per head, merge skipped): the reservation still happens
+// behind this layer's kernels, as its own launch
+static int flush_armed_advance(quest_decode_handler* h, hipStream_t s) {
+    if (!h->armed_advance.st) return 0;
+    const StepAdvance a = take_armed_advance(h);
+    if (a.batch.n_seqs == 1)  // (one sequence: its tables are plain arrays, no strides to check)
+        return quest_step_state_advance(a.st, a.kv_table, a.meta_table, a.page_size, a.max_kv_pages, a.max_meta_pages,
+                                        (quest_stream_t)s);
+    return quest_step_state_advance_batched(a.st, a.kv_table, a.meta_table, a.page_size, a.max_kv_pages, a.max_meta_pages,
+                                            a.batch, (quest_stream_t)s);
+}
 
 // Workgroups the planner aims for.  One sequence: the kernel is built for 2 workgroups (8 waves) per CU,
 // so 2 x CUs workgroups (512) are one fully resident round, each wave with 16 x 1 KiB loads in flight.
@@ -426,6 +450,25 @@ struct quest_decode_handler {
 // launch).
 static uint32_t target_workgroups(const quest_decode_handler* h) { return h->batch > 1 ? h->num_cus : 2 * h->num_cus; }
 static constexpr uint32_t kMaxChunks = 1024;  // merge kernel's LDS weight table
+extern "C" int quest_decode_arm_step_advance(quest_decode_handler_t* h, quest_step_state_t* state, const int32_t* kv_tables,
+                                             const int32_t* meta_tables, uint32_t page_size, uint32_t max_kv_pages,
+                                             uint32_t max_meta_pages, quest_batch_t batch) {
+    if (!h) return QUEST_EINVAL;
+    if (!state) {  // disarm
+        h->armed_advance = StepAdvance{};
+        return 0;
+    }
+    if (!kv_tables || !meta_tables || page_size == 0 || max_kv_pages == 0 || max_meta_pages == 0 || batch.n_seqs == 0)
+        return QUEST_EINVAL;
+    if (batch.n_seqs > 1 && (batch.kv_table_stride < max_kv_pages || batch.meta_table_stride < max_meta_pages)) return QUEST_EINVAL;
+    if (!h->started) return QUEST_ESTATE;
+    // the reservation rides in the next MERGE launch (one thread per sequence of its first workgroup); a forward whose plan
+    // has no merge launch issues it as its own launch behind the attention kernel instead (correct, nothing saved)
+    if (batch.n_seqs > 64) return QUEST_EUNSUPPORTED;
+    h->armed_advance = StepAdvance{state, kv_tables, meta_tables, page_size, max_kv_pages, max_meta_pages, batch};
+    return 0;
+}
+
 extern "C" int quest_decode_handler_create(quest_decode_handler_t** out, uint32_t layout) {
     if (!out || layout > QUEST_LAYOUT_NHD_ROT) return QUEST_EINVAL;
     quest_decode_handler* h = new (std::nothrow) quest_decode_handler();
@@ -630,10 +673,11 @@ static int launch_decode_fc(quest_decode_handler* h, const DecodeParams& p, uint
 merge:
     if (h->n_chunks > 1 && !h->skip_merge) {  // o / lse / partials of a batch are contiguous over (sequence, head): one grid
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
-                           (const float*)p.ws, p.o, QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride);
+                           (const float*)p.ws, p.o, QUEST_LSE_ENABLED ? p.lse : nullptr, h->n_chunks, p.ws_stride,
+                           take_armed_advance(h));
         QUEST_LAUNCH_CHECK();
     }
-    return 0;
+    return flush_armed_advance(h, s);
 }
 
 // fc: fused top-k front end variant (0 = page ids come from an index tensor)
@@ -885,10 +929,11 @@ static int launch_shared(const quest_decode_handler* h, const DecodeParams& p_in
     QUEST_LAUNCH_CHECK();
     if (p.n_chunks > 1 && !h->skip_merge) {
         hipLaunchKernelGGL((merge_states_kernel<D>), dim3(num_qo_heads * n_seqs), dim3(D * kMergeGroups), 0, s,
-                           (const float*)p.ws, p.o, p.lse, p.n_chunks, p.ws_stride);
+                           (const float*)p.ws, p.o, p.lse, p.n_chunks, p.ws_stride,
+                           take_armed_advance(const_cast<quest_decode_handler*>(h)));
         QUEST_LAUNCH_CHECK();
     }
-    return 0;
+    return flush_armed_advance(const_cast<quest_decode_handler*>(h), s);
 }
 
 struct SharedAppend {  // optional decode append riding in the group-shared launch
@@ -1115,7 +1160,7 @@ extern "C" int quest_decode_layer_fused_batched(quest_decode_handler_t* h, const
     QUEST_LAUNCH_CHECK();
     uint32_t* info = h->last_launch;  // front-end variant 7 = the one-launch layer (keys from LDS)
     info[0] = FC, info[1] = NW, info[2] = 7u, info[3] = 1u, info[4] = 1u, info[5] = batch.n_seqs;
-    return 0;
+    return flush_armed_advance(h, s);  // (no merge launch to ride in: the armed reservation follows as its own launch)
 }
 
 extern "C" int quest_decode_forward_batched(quest_decode_handler_t* h, const void* q, void* o, quest_paged_kv_t kv,

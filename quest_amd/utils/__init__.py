@@ -210,13 +210,18 @@ def step_advance_dyn(iController: InferenceController) -> None:
 def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
                      layer_idx: int, scores: torch.Tensor, rope_scale: Optional[float] = None,
                      rope_theta: Optional[float] = None, apply_rope: bool = False,
-                     tiles: Optional[bool] = None) -> torch.Tensor:
+                     tiles: Optional[bool] = None, advance_after: bool = False) -> torch.Tensor:
     """One layer of a decode token in the sparse regime (pages > budget), every length read from the
     device-resident state: [RoPE] -> append+estimate -> top-k+attention (+merge).  ``scores`` is a
     caller-owned ``[Hq, >= max_pages]`` fp16 scratch (``score_scratch``).  ``tiles``: None = the tiles launches for pools
-    of at least ``iController.tiles_min_pages`` pages (where the scratch has room and the plan allows), True / False force."""
+    of at least ``iController.tiles_min_pages`` pages (where the scratch has room and the plan allows), True / False force.
+    ``advance_after``: the LAST layer of a step -- the next token's reservation (``step_advance_dyn``) rides in this layer's
+    merge launch instead of heading the next step as a launch of its own (the first token is reserved by one
+    ``step_advance_dyn`` before the first step; the host mirror ``prepare_metadata(1)`` follows every step as before)."""
     ctl = iController
     _need_state(ctl)
+    if advance_after:
+        ctl._decode_handler.arm_step_advance(ctl.step_state, ctl.kv_table_full, ctl.meta_table_full, ctl.page_size)
     if apply_rope:
         scale, theta = _rope_defaults(rope_scale, rope_theta)
         _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
@@ -242,8 +247,8 @@ def decode_layer_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iControl
 
 def decode_layer_dense_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iController: InferenceController,
                            layer_idx: int, rope_scale: Optional[float] = None, rope_theta: Optional[float] = None,
-                           apply_rope: bool = False, fuse_append: bool = True) -> torch.Tensor:
-    """One FULL-KV layer of a decode token, every length read from the device-resident state:
+                           apply_rope: bool = False, fuse_append: bool = True, advance_after: bool = False) -> torch.Tensor:
+    """One FULL-KV layer of a decode token (``advance_after``: see ``decode_layer_dyn``), every length read from the device-resident state:
     [RoPE] -> append + attention over all pages in ONE launch (group-shared kernel; the workgroup that attends the
     current page takes the new token from k / v, writes it to the pool and folds it into the metadata) (+merge).  Shapes
     outside the group-shared kernel take the separate append launch.  Needs ``begin_graph_decode(dense_layers=True)``."""
@@ -254,6 +259,8 @@ def decode_layer_dense_dyn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, iC
         _kernels.apply_rope_in_place_dyn(q, k, scale, theta, ctl.step_state)
     o = torch.empty_like(q)
     kvb, mb = ctl.kv_cache.buf_layer(layer_idx), ctl.metadata_cache.buf_layer(layer_idx)
+    if advance_after:
+        ctl._dense_handler.arm_step_advance(ctl.step_state, ctl.kv_table_full, ctl.meta_table_full, ctl.page_size)
     if not (fuse_append and ctl._dense_handler.append_forward_shared_dyn(k, v, mb, ctl.meta_table_full, q, o, kvb,
                                                                          ctl.kv_table_full, ctl.step_state)):
         _kernels.append_kv_cache_decode_dyn(k, v, kvb, ctl.kv_table_full, mb, ctl.meta_table_full, ctl.step_state, ctl.layout)

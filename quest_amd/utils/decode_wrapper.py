@@ -87,6 +87,9 @@ class BatchDecodeWithPagedKVCacheWrapper:
     def set_skip_merge(self, skip: bool) -> None:
         self._wrapper.set_skip_merge(skip)
 
+    def arm_step_advance(self, state, kv_tables, meta_tables, page_size: int) -> None:
+        self._wrapper.arm_step_advance(state, kv_tables, meta_tables, page_size)
+
     def set_front_end(self, generation: int) -> None:
         self._wrapper.set_front_end(generation)
 

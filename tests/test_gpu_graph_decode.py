@@ -455,3 +455,108 @@ def test_dense_layer_with_the_append_folded_into_the_attention_launch(Hq, Hkv, D
     kvq = three.kv_cache.buf_layer(0)[torch.as_tensor(three.kv_cache.indicies, device=dev).long()]
     n_full = (L // page) if L % page == 0 else (L // page)
     assert torch.equal(kvp[:n_full], kvq[:n_full])
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,layout,L0,B,dense,ppc", [
+    (8, 8, 128, 0, 16 * 31 + 10, 7, False, 0),      # sparse chain, several workgroups per head: rides in the merge launch
+    (32, 8, 128, 2, 16 * 15 + 16, 6, False, 0),     # GQA, row-rotated pool
+    (4, 4, 64, 0, 16 * 40 + 3, 9, False, 9),        # one workgroup per head (no merge launch): issued as its own launch
+    (8, 2, 128, 0, 16 * 20 + 5, 1 << 20, True, 0),  # full-KV layers: rides in the dense handler's merge launch
+    (8, 8, 128, 1, 16 * 18 + 16, 5, False, 0),      # HND
+])
+def test_next_tokens_reservation_riding_in_the_last_launch_equals_the_advance_launch(Hq, Hkv, D, layout, L0, B, dense, ppc):
+    """Folded stepping (round 6, quest_decode_arm_step_advance): the step_state_advance launch at the head of every captured
+    step against the same reservation riding in the LAST layer's merge launch (first token reserved once, up front).  Same
+    outputs token after token across KV-page and metadata-page boundaries, same pools; between steps the folded run's device
+    state == its host mirror == the other run's state one reservation ahead."""
+    import quest_amd.utils as qu
+
+    dev = torch.device("cuda:0")
+    layers, steps = 3, 45
+    q0, k0, v0 = inputs(91, L0, Hq, Hkv, D)
+    g = torch.Generator(device=dev).manual_seed(7)
+    new_q = torch.randn(steps, layers, 1, Hq, D, generator=g, device=dev, dtype=torch.float16)
+    new_k = torch.randn(steps, layers, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+    new_v = torch.randn(steps, layers, 1, Hkv, D, generator=g, device=dev, dtype=torch.float16)
+
+    class Run:
+        def __init__(self, fold):
+            self.fold = fold
+            ctl = self.ctl = make_controller(L0 + steps + 40, Hq, Hkv, D, PAGE, B, layout=layout, shuffle_seed=21,
+                                             num_layers=layers, max_seq_len=L0 + steps + 40)
+            ctl.prepare_metadata(L0)
+            ctl.begin_forward(L0)
+            for l in range(layers):
+                qu.append_kv(cuda(k0), cuda(v0), ctl, l)
+            ctl.end_forward()
+            ctl.enable_device_state()
+            if ppc:
+                ctl._decode_handler.set_pages_per_chunk(ppc)
+            ctl.begin_graph_decode(dense_layers=dense)
+            self.scores = qu.score_scratch(ctl)
+            self.q = torch.empty(layers, 1, Hq, D, device=dev, dtype=torch.float16)
+            self.k = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
+            self.v = torch.empty(layers, 1, Hkv, D, device=dev, dtype=torch.float16)
+            self.o = [None] * layers
+            if fold:  # the first token's reservation, once
+                qu.step_advance_dyn(ctl)
+                ctl.prepare_metadata(1)
+            self.set_inputs(0)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.step()  # warm-up (re-decoded by the first replay: the append is idempotent)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ctl.sync_device_state()  # device <- host mirror (prefilled, + the first reservation when folded)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.step()
+            ctl.sync_device_state()
+
+        def set_inputs(self, t):
+            self.q.copy_(new_q[t]); self.k.copy_(new_k[t]); self.v.copy_(new_v[t])
+
+        def step(self):
+            ctl = self.ctl
+            if not self.fold:
+                qu.step_advance_dyn(ctl)
+            for l in range(layers):
+                last = self.fold and l == layers - 1
+                if dense:
+                    self.o[l] = qu.decode_layer_dense_dyn(self.q[l], self.k[l], self.v[l], ctl, l, apply_rope=True, advance_after=last)
+                else:
+                    self.o[l] = qu.decode_layer_dyn(self.q[l], self.k[l], self.v[l], ctl, l, self.scores, apply_rope=True,
+                                                    advance_after=last)
+
+    sep, fold = Run(False), Run(True)
+    if ppc:
+        assert fold.ctl._decode_handler.plan_info()[1] == 1  # no merge launch in this plan
+    for t in range(steps):
+        for r in (sep, fold):
+            r.set_inputs(t)
+            r.graph.replay()
+            r.ctl.prepare_metadata(1)
+        for l in range(layers):
+            assert torch.equal(sep.o[l], fold.o[l]), f"token {t} layer {l}"
+        # device state == host mirror in both runs; the folded one is one reservation ahead
+        for r in (sep, fold):
+            st = r.ctl.step_state.cpu().tolist()
+            kv, meta = r.ctl.kv_cache, r.ctl.metadata_cache
+            assert st[:8] == [kv.seqlen, len(kv.indicies), kv.last_page_len, kv.indicies[-1], len(meta.indicies),
+                              meta.last_page_len, meta.indicies[-1], 0], (t, r.fold, st)
+        assert fold.ctl.kv_cache.seqlen == sep.ctl.kv_cache.seqlen + 1
+    L = sep.ctl.kv_cache.seqlen
+    assert L == L0 + steps and len(sep.ctl.kv_cache.indicies) > (L0 + PAGE - 1) // PAGE + 1, "the run must cross page boundaries"
+    # every appended token and every page's metadata identical (the folded run's extra reserved token holds nothing yet)
+    from quest_amd.utils import TensorLayout
+
+    def valid(ctl, cache, n, l):
+        pages = cache.buf_layer(l)[torch.tensor(list(cache.indicies), device=dev)]
+        x = TensorLayout.to_logical(pages.view(torch.int16), ctl.layout)
+        return x.transpose(0, 1).reshape(2, -1, x.shape[-2], x.shape[-1])[:, :n]
+
+    n_pages = (L + PAGE - 1) // PAGE
+    for l in range(layers):
+        assert torch.equal(valid(sep.ctl, sep.ctl.kv_cache, L, l), valid(fold.ctl, fold.ctl.kv_cache, L, l))
+        assert torch.equal(valid(sep.ctl, sep.ctl.metadata_cache, n_pages, l), valid(fold.ctl, fold.ctl.metadata_cache, n_pages, l))
