@@ -26,8 +26,8 @@ namespace quest {
 // The leading scalar arguments are the fields the first loads of a workgroup need (role, page-table entry, metadata
 // rows, live length): scalar kernel arguments are preloaded into SGPRs at wave launch (14 dwords beside the kernarg
 // pointer, build.py), a struct passed by value is not -- its remaining fields arrive by s_load while those loads fly.
-template <int D, int G, bool HND>
-__global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimate_kernel(
+template <int D, int G, bool HND, int EWV>
+__global__ __launch_bounds__(EWV* kWave, QUEST_EST_MIN_WAVES) void estimate_kernel(
     const half_t* __restrict__ q, void* a_meta_data, const int32_t* a_meta_indices, const quest_step_state_t* a_state,
     uint32_t n_out, uint32_t a_num_heads, uint32_t a_page_size, uint32_t a_tile_log2, uint32_t a_append_from,
     uint32_t a_meta_table_stride, half_t* __restrict__ o, quest_paged_kv_t meta, AppendTail tail) {
@@ -58,55 +58,77 @@ __global__ __launch_bounds__(kEstWaves* kWave, QUEST_EST_MIN_WAVES) void estimat
         }
         // The appended token only touches the CURRENT page's KV entry and metadata entry (index n_out),
         // which the estimate excludes (e < n_out), so the two halves of the launch share no byte.
-        append_decode_body(tail.kv, meta, tail.key, tail.value, (blockIdx.x - tail.est_blocks) * (kEstWaves * kWave) + threadIdx.x);
+        append_decode_body(tail.kv, meta, tail.key, tail.value, (blockIdx.x - tail.est_blocks) * (EWV * kWave) + threadIdx.x);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char est_smem[];
-    __shared__ uint32_t s_literal[kEstWaves];
+    __shared__ uint32_t s_literal[EWV];
     const uint32_t head_tiles = meta.num_heads >> tail.tile_log2;
-    estimate_tile<D, G, HND, kEstWaves, 1>(q, o, meta, n_out, tail, blockIdx.x / head_tiles, blockIdx.x % head_tiles,
-                                           threadIdx.x, est_smem, s_literal, seq * meta.num_heads * G);
+    estimate_tile<D, G, HND, EWV, 1>(q, o, meta, n_out, tail, blockIdx.x / head_tiles, blockIdx.x % head_tiles,
+                                     threadIdx.x, est_smem, s_literal, seq * meta.num_heads * G);
 }
 
-template <int D, int G>
-static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, AppendTail tail,
-                           hipStream_t s, uint32_t n_seqs) {
+// Tile shape of a launch with EWV-wave workgroups: kv heads per tile (`hw`) and whether the shape can be served.
+template <int D, int G, int EWV>
+static bool estimate_tile_shape(const quest_paged_kv_t& meta, const AppendTail& tail, const PoolStrides& strides, uint32_t& hw) {
     constexpr int R = kWave / (D / kVec);
-    constexpr uint32_t ROWS = kEstWaves * est_iter<G>() * R;
-    const bool hnd = meta.layout == QUEST_LAYOUT_HND;
-    const PoolStrides strides = pool_strides(meta);
-    if (!tail.state && tail.o_stride == 0) tail.o_stride = n_out;  // contiguous rows unless the caller pads them
-    uint32_t hw = pick_tile_heads(meta.num_heads, G, D / kVec);
+    constexpr uint32_t ROWS = EWV * est_iter<G>() * R;
+    hw = pick_tile_heads(meta.num_heads, G, D / kVec, EWV);
     // Tile maxima are one key per run of 8 consecutive columns of ONE query head, taken from 8 consecutive lanes of the
-    // score store loop: a tile must be a multiple of 8 entries wide.  head_dim 256 has 32-row tiles, so 8 heads per tile
-    // would leave 4 entries (two heads' scores in one 8-lane run): narrow the tile's head range instead, and refuse
-    // what still does not fit -- before anything is launched (the callers then take the whole-row launches).
+    // score store loop: a tile must be a multiple of 8 entries wide.  Narrow the tile's head range where it is not (head_dim
+    // 256, two-wave workgroups), and refuse what still does not fit -- before anything is launched.
     while (tail.tile_off && hw > 1 && (ROWS / hw) % 8u != 0) hw >>= 1;
-    const uint32_t ew = ROWS / hw;
-    if (tail.tile_off && ew % 8u != 0) return QUEST_EUNSUPPORTED;
+    if (tail.tile_off && (ROWS / hw) % 8u != 0) return false;
     // row-rotated pool: the heads of a tile's rows (slot ^ (entry & rot)) must be heads of the same tile
-    if (strides.rot >= hw) return QUEST_EUNSUPPORTED;
+    if (strides.rot >= hw) return false;
+    return hw * G * (D / kVec) <= 2u * EWV * kWave;  // q staging capacity
+}
+
+template <int D, int G, int EWV>
+static int launch_estimate_w(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, AppendTail tail,
+                             hipStream_t s, uint32_t n_seqs, uint32_t hw) {
+    constexpr int R = kWave / (D / kVec);
+    constexpr uint32_t ROWS = EWV * est_iter<G>() * R;
+    const bool hnd = meta.layout == QUEST_LAYOUT_HND;
+    if (!tail.state && tail.o_stride == 0) tail.o_stride = n_out;  // contiguous rows unless the caller pads them
+    const uint32_t ew = ROWS / hw;
     tail.tile_heads = hw;
     tail.tile_log2 = (uint32_t)__builtin_ctz(hw);
     tail.est_blocks = ((n_out + ew - 1) / ew) * (meta.num_heads / hw);
     uint32_t blocks = tail.est_blocks;
-    if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + kEstWaves * kWave - 1) / (kEstWaves * kWave);
+    if (tail.enabled) blocks += (meta.num_heads * (D / kVec) + EWV * kWave - 1) / (EWV * kWave);
     if (blocks == 0) return 0;
     dim3 grid(blocks, n_seqs);
     const size_t lds = est_tile_lds_bytes(hw, G, D, ew);
     const uint32_t append_from = tail.enabled ? tail.est_blocks : 0xffffffffu;
-    if (hw * G * (D / kVec) > 2 * kEstWaves * kWave) return QUEST_EUNSUPPORTED;  // q staging capacity
     if (hnd)
-        hipLaunchKernelGGL((estimate_kernel<D, G, true>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q, meta.data,
+        hipLaunchKernelGGL((estimate_kernel<D, G, true, EWV>), grid, dim3(EWV * kWave), lds, s, (const half_t*)q, meta.data,
                            meta.indices, tail.state, n_out, meta.num_heads, meta.page_size, tail.tile_log2, append_from,
                            tail.meta_table_stride, (half_t*)o, meta, tail);
     else
-        hipLaunchKernelGGL((estimate_kernel<D, G, false>), grid, dim3(kEstWaves * kWave), lds, s, (const half_t*)q, meta.data,
+        hipLaunchKernelGGL((estimate_kernel<D, G, false, EWV>), grid, dim3(EWV * kWave), lds, s, (const half_t*)q, meta.data,
                            meta.indices, tail.state, n_out, meta.num_heads, meta.page_size,
                            tail.tile_log2 | (meta.layout == QUEST_LAYOUT_NHD_ROT ? 1u << 8 : 0u), append_from,
                            tail.meta_table_stride, (half_t*)o, meta, tail);
     QUEST_LAUNCH_CHECK();
     return 0;
+}
+
+// Workgroup width: TWO waves (32-row tiles) where the tile shape allows -- smaller workgroups start and retire in finer
+// steps, measured A B A B on one box (profiles/r06_ab_estimate_tile_shapes.txt, r06_ab_estimate_waves.txt): cfg 4 A+E 9.16 ->
+// 8.73 us (layer 28.9 -> 28.4), cfg 3 7.97 -> 7.83 (21.82 -> 21.72), 8 x cfg 3 two-launch form 11.20 -> 11.11, cfg 5 no
+// change; 8 waves and 8 load rounds per wave are slower -- else the four-wave tile of rounds 1-5 (it stages twice the query
+// vectors: GQA shapes whose group does not fit two waves' staging, row-rotated pools whose rotation needs >= 4 heads).
+// -DQUEST_EST_WAVES=4 forces the four-wave form (A/B).
+template <int D, int G>
+static int launch_estimate(const void* q, void* o, uint32_t n_out, const quest_paged_kv_t& meta, const AppendTail& tail,
+                           hipStream_t s, uint32_t n_seqs) {
+    const PoolStrides strides = pool_strides(meta);
+    uint32_t hw = 0;
+    if (kEstWaves == 2 && estimate_tile_shape<D, G, 2>(meta, tail, strides, hw))
+        return launch_estimate_w<D, G, 2>(q, o, n_out, meta, tail, s, n_seqs, hw);
+    if (estimate_tile_shape<D, G, 4>(meta, tail, strides, hw)) return launch_estimate_w<D, G, 4>(q, o, n_out, meta, tail, s, n_seqs, hw);
+    return QUEST_EUNSUPPORTED;
 }
 
 template <int D>

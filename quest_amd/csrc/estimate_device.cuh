@@ -9,10 +9,10 @@ namespace quest {
 #define QUEST_EST_ITER 4
 #endif
 #ifndef QUEST_EST_WAVES
-#define QUEST_EST_WAVES 4
+#define QUEST_EST_WAVES 2  // preferred workgroup width of the estimate launch (estimate.hip launch_estimate: 2, else 4)
 #endif
 constexpr int kEstIter = QUEST_EST_ITER;    // load instructions per tensor per wave, all in flight together
-constexpr int kEstWaves = QUEST_EST_WAVES;  // waves per workgroup
+constexpr int kEstWaves = QUEST_EST_WAVES;  // preferred waves per workgroup (a template parameter of the kernel: 2 or 4)
 #ifndef QUEST_EST_ITER_GQA
 #define QUEST_EST_ITER_GQA 4
 #endif
