@@ -366,15 +366,17 @@ class LlamaForCausalLM(nn.Module):
             json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
 
     def quest_init(self, page_size: int, max_seq_len: int, token_budget: int = 512, dtype=torch.float16,
-                   device=torch.device("cuda:0")) -> None:
+                   device=torch.device("cuda:0"), kv_layout="NHD") -> None:
         """llama.py:520-552: build the controller; ``token_budget`` is in TOKENS, the controller's page
-        budget is ``token_budget // page_size`` pages (llama.py:536)."""
+        budget is ``token_budget // page_size`` pages (llama.py:536).  ``kv_layout`` (EXTENSION; the reference hard-wires
+        NHD, controller.py:38): "NHD", "HND" or this build's row-rotated "NHD_ROT" (same results, faster batched launches)."""
         assert self.model.iController is None, "Can't init Quest Controller twice."
         cfg = self.config
         self.model._quest_page_budget = token_budget // page_size
         self.model.iController = qutils.InferenceController(
             cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads, page_size,
-            self.model._quest_page_budget, max_seq_len, dtype, device, num_kv_heads=cfg.num_key_value_heads)
+            self.model._quest_page_budget, max_seq_len, dtype, device, num_kv_heads=cfg.num_key_value_heads,
+            layout=qutils.TensorLayout.parse(kv_layout))
         print(f"Quest allocates KV-Cache of {max_seq_len} tokens; token_budget {token_budget} = "
               f"{self.model._quest_page_budget} pages of {page_size}")
 
@@ -462,7 +464,7 @@ class LlamaForCausalLM(nn.Module):
 
     # ------------------------------------------------------------------ batched serving (EXTENSION)
     def quest_init_batched(self, n_seqs: int, page_size: int, max_seq_len: int, token_budget: int = 512,
-                           dtype=torch.float16, device=torch.device("cuda:0")) -> None:
+                           dtype=torch.float16, device=torch.device("cuda:0"), kv_layout="NHD") -> None:
         """``quest_init`` for ``n_seqs`` sequences decoded together: one shared KV pool and metadata pool
         (``BatchedInferenceController``).  Prompts are processed one sequence at a time with
         ``prefill_sequence``; decode steps then run all sequences in one hipGraph replay."""
@@ -472,7 +474,7 @@ class LlamaForCausalLM(nn.Module):
         self.model.bController = qutils.BatchedInferenceController(
             n_seqs, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads,
             page_size, self.model._quest_page_budget, max_seq_len, dtype, device,
-            num_kv_heads=cfg.num_key_value_heads)
+            num_kv_heads=cfg.num_key_value_heads, layout=qutils.TensorLayout.parse(kv_layout))
 
     def prefill_sequence(self, seq: int, input_ids: torch.Tensor) -> torch.Tensor:
         """Run the prompt of sequence ``seq`` (``[1, L]``) through the ordinary single-sequence path over the

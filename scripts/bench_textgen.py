@@ -56,7 +56,7 @@ def time_batched(cfg, a, dense, dev):
     for m in model.modules():
         if hasattr(m, "variance_epsilon"):
             m.weight.data.fill_(1.0)
-    model.quest_init_batched(a.seqs, 16, a.ctx + 256, a.token_budget)
+    model.quest_init_batched(a.seqs, 16, a.ctx + 256, a.token_budget, kv_layout=a.layout)
     if dense:
         model.model._quest_skip_layer = a.layers
     b = model.model.bController
@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--inter", type=int, default=11008)
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--layout", choices=["NHD", "HND", "NHD_ROT"], default="NHD_ROT",
+                    help="pool layout (quest_init's kv_layout): the row-rotated NHD of round 6 by default, NHD = the reference's")
     ap.add_argument("--seqs", type=int, default=1, help="sequences decoded together (batched launches)")
     ap.add_argument("--checkpoint", default=None,
                     help="Hugging Face Llama checkpoint directory (config.json + safetensors) to load instead of "
@@ -154,7 +156,7 @@ def main():
     if a.seqs > 1:
         q_ms = time_batched(cfg, a, False, dev)
         d_ms = time_batched(cfg, a, True, dev)
-        print(json.dumps({"bench": "e2e batched decode, random-weight Llama", "sequences": a.seqs, "ctx": a.ctx,
+        print(json.dumps({"bench": "e2e batched decode, random-weight Llama", "sequences": a.seqs, "ctx": a.ctx, "kv_layout": a.layout,
                           "token_budget": a.token_budget, "layers": a.layers, "hidden": a.hidden, "heads": a.heads,
                           "kv_heads": a.kv_heads, "intermediate": a.inter, "vocab": a.vocab, "dense_first_layers": 2,
                           "fused_decoder_layer_launches": getattr(time_batched, "fused_layers", None), "ms_per_step_quest": q_ms,
@@ -178,7 +180,7 @@ def main():
             for m in model.modules():
                 if hasattr(m, "variance_epsilon"):
                     m.weight.data.fill_(1.0)
-        model.quest_init(16, a.ctx + 256 + a.generate, budget)
+        model.quest_init(16, a.ctx + 256 + a.generate, budget, kv_layout=a.layout)
         ctl = model.model.iController
         g = torch.Generator(device=dev).manual_seed(1)
         D = a.hidden // a.heads
@@ -226,7 +228,7 @@ def main():
         torch.cuda.empty_cache()
     out = {"bench": "e2e decode latency, random-weight Llama", "ctx": a.ctx, "token_budget": a.token_budget,
            "page_budget_pages": a.token_budget // 16, "layers": a.layers, "hidden": a.hidden, "heads": a.heads,
-           "kv_heads": a.kv_heads, "dense_first_layers": 2,
+           "kv_heads": a.kv_heads, "dense_first_layers": 2, "kv_layout": a.layout,
            "ms_per_token_quest": results["quest"], "ms_per_token_full_kv": results["dense"],
            "speedup": results["dense"] / results["quest"],
            "reference_published": "RTX 6000 Ada, ctx 32768 FP16: 36.8 ms -> 21.2 ms @ budget 2048 (1.74x)"}
