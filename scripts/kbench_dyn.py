@@ -45,6 +45,7 @@ print(f"layer dyn: {bench.time_kernel_loop(both, a.layers, 10):.2f} us")
 
 # the bench's whole step (advance + 32 layers) as one graph, timed by HIP events over back-to-back replays
 ctl.sync_device_state()
+w.prime()  # folded stepping (round 6): the first token's reservation, once; every step then ends with the next one's
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
