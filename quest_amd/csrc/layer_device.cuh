@@ -242,6 +242,26 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
     };
     // (Requesting the next page before the current one is scored -- two register sets, 16 loads in flight per lane -- is
     // SLOWER: 89.9-92.3 vs 86.4 us per launch.  This access shape wants shallow queues: scripts/probe/addr_class_probe.hip.)
+#ifdef QUEST_LAYER_TWO_PAGES
+    // tuning build: TWO metadata pages per round from the counter (16 loads in flight per lane).  Round 5 measured 86.8 vs 86.2 us
+    // on the NHD pool ("this access shape wants shallow queues"); re-measured on the row-rotated pool in round 6:
+    // profiles/r06_ab_layer_kernel_two_pages_per_round.txt
+    for (uint32_t mp = wave; mp < n_mp;) {
+        half8 mx[T], mn[T], mx2[T], mn2[T];
+        issue(mp, mx, mn);
+        const uint32_t mp2 = fetch();
+        const bool has2 = mp2 < n_mp;
+        if (has2) issue(mp2, mx2, mn2);
+        const uint32_t nx = has2 ? fetch() : mp2;
+        if (!ids_parked) {
+            park_ids();
+            ids_parked = true;
+        }
+        score(mp, mx, mn);
+        if (has2) score(mp2, mx2, mn2);
+        mp = nx;
+    }
+#else
     for (uint32_t mp = wave; mp < n_mp;) {
         half8 mx[T], mn[T];
         const uint32_t mpw = mp + walk0 < n_mp ? mp + walk0 : mp + walk0 - n_mp;  // (walk0 = 0 outside the tuning builds)
@@ -254,6 +274,7 @@ __device__ __forceinline__ void layer_decode_body(QUEST_LAYER_HEAD_PARAMS, const
         score(mpw, mx, mn);
         mp = nx;
     }
+#endif
     if (!ids_parked) park_ids();  // waves without a round (short sequences)
     QUEST_STAMP(1);
     QUEST_WS_NOW(ws_est)  // this wave's share of the head's pages is scored
