@@ -212,6 +212,42 @@ def test_bench_launcher_reports_a_failing_rank0():
     assert len(lines) == 1 and json.loads(lines[0])["failed_rank"] == 0
 
 
+def test_bench_default_single_gpu_line_names_its_pool_layout_and_carries_the_nhd_figures_beside_it():
+    """Round 6: the default pool layout of bench.py is this build's row-rotated NHD.  The line says so (config.kv_layout) and
+    the default N = 1 run measures the headline and both 8-sequence side configurations on the REFERENCE's NHD pool as
+    well (a headline on another layout carries the NHD figure beside it); `--layout NHD` runs the reference's
+    layout and needs no such objects.  CPU stub: the control flow and the JSON contract, not the numbers."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["QUEST_BENCH_STUB"] = "1"
+
+    def run(*extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--side-steps", "3",
+                            "--no-cpu-baseline", *extra], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and r.stdout.strip() == lines[0], r.stdout
+        return json.loads(lines[0])
+
+    out = run()
+    assert out["n_gpus"] == 1 and out["config"]["kv_layout"] == "NHD_ROT" and "side_error" not in out
+    for key, layout, seqs in (("batched_8seq", "NHD_ROT", 8), ("cfg5_8seq_gqa", "NHD_ROT", 8), ("reference_layout_nhd", "NHD", 1),
+                              ("batched_8seq_nhd", "NHD", 8), ("cfg5_8seq_gqa_nhd", "NHD", 8)):
+        side = out[key]
+        assert "error" not in side, (key, side)
+        assert side["kv_layout"] == layout and side["sequences_per_gpu"] == seqs and side["steps"] == 3, (key, side)
+    assert "configs[4]" in out["cfg5_8seq_gqa_nhd"]["workload"] and "configs[2]" in out["reference_layout_nhd"]["workload"]
+    out = run("--layout", "NHD")
+    assert out["config"]["kv_layout"] == "NHD" and "batched_8seq" in out and "cfg5_8seq_gqa" in out
+    assert not any(k.endswith("_nhd") for k in out)
+    out = run("--no-side")
+    assert not any(k in out for k in ("batched_8seq", "cfg5_8seq_gqa", "reference_layout_nhd"))
+
+
 def test_bench_config_labels_follow_the_arguments():
     import importlib.util
 
