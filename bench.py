@@ -796,6 +796,8 @@ def measure(a, dev, dist, world_seen, rank, stub, side=False):
                        "head_dim": a.head_dim, "seqlen": a.seqlen, "page_size": a.page_size,
                        "token_budget": a.token_budget, "page_budget_pages": a.token_budget // a.page_size,
                        "kv_layout": a.layout, "mode": a.mode, "seed": a.seed, "skip_layers": a.skip_layers,
+                       "step_state_advance": ("rides in the last layer's merge launch (quest_decode_arm_step_advance)"
+                                              if getattr(w, "fold", False) else "its own launch at the head of the step"),
                        "launches_per_layer": ("3 (append | full-KV attention | merge)" if a.separate_dense_append else
                                               "2 (full-KV attention with the decode append folded in | merge)")
                        if not bpl["sparse"] else "5 (reference op sequence)" if a.unfused else
