@@ -72,9 +72,9 @@ def test_hf_checkpoint_logits_match_transformers(tmp_path, kv_heads, rope):
     # module-by-module step (bit for bit), finite.  (The fused decoder layers of the default graph differ from the
     # module path by fp16 rounding: tests/test_gpu_decode_layer.py.)
     outs = []
-    for graph in (False, True):
+    for graph, kv_layout in ((False, "NHD"), (True, "NHD"), (True, "NHD_ROT")):
         q = LlamaForCausalLM.from_pretrained(d, device=dev)
-        q.quest_init(16, 512, token_budget=64)
+        q.quest_init(16, 512, token_budget=64, kv_layout=kv_layout)
         with torch.inference_mode():
             lg = q(input_ids=prompt.to(dev))
             if graph:
@@ -88,3 +88,5 @@ def test_hf_checkpoint_logits_match_transformers(tmp_path, kv_heads, rope):
         outs.append(torch.stack(seq))
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+    # ... and on the row-rotated pool (quest_init(kv_layout="NHD_ROT"), round 6): where a vector lives does not change a logit
+    assert torch.equal(outs[0], outs[2])
