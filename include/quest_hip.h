@@ -43,7 +43,7 @@ typedef void* quest_stream_t; /* hipStream_t */
  * launch with one workgroup per head ends with its "slow" heads while most CUs idle.  Rotated, every head's pieces
  * cycle through all values of those bits: every workgroup sees the mix's mean.  Same bytes, same arithmetic, same fold
  * order as NHD -> the same scores, selections and outputs bit for bit; only WHERE a vector lives differs
- * (quest_pool_slot below is the whole definition).  Not a layout the reference has (quest/utils/utils.py:1-5 knows NHD and
+ * (quest_pool_slot, declared with the pool view below, is the whole definition).  Not a layout the reference has (quest/utils/utils.py:1-5 knows NHD and
  * HND; decode_page.cuh:196-239 are their offsets): a pool in this layout must be written and read through this library.
  */
 #define QUEST_LAYOUT_NHD_ROT 2u
@@ -73,6 +73,13 @@ typedef struct quest_paged_kv {
     uint32_t layout;
     uint32_t reserved;
 } quest_paged_kv_t;
+
+/* Where a vector lives inside an entry's row of heads (host function, no GPU): the head SLOT of head `head`'s K / max vector
+ * (v_slot == 0) or V / min vector (v_slot != 0) of entry `entry` (its index inside the page) in a pool of `num_heads` heads.
+ * NHD and HND: the head itself; NHD_ROT: head ^ (entry & rot) [^ flip for V], the definition in the comment of
+ * QUEST_LAYOUT_NHD_ROT above.  The address of the vector is then, in halves from the layer's base,
+ * page * 2*S*H*D + v * S*H*D + entry * H*D + slot * D (NHD family).  0xffffffff for a malformed layout / head. */
+uint32_t quest_pool_slot(uint32_t layout, uint32_t num_heads, uint32_t head, uint32_t entry, int v_slot);
 
 const char* quest_error_string(int code);
 

@@ -43,6 +43,7 @@ class Batch(ctypes.Structure):
 SIGNATURES = {
     "quest_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "quest_build_info": (ctypes.c_char_p, []),
+    "quest_pool_slot": (c_u32, [c_u32, c_u32, c_u32, c_u32, ctypes.c_int]),
     "quest_append_kv_cache_decode": (ctypes.c_int, [c_vp, c_vp, PagedKV, PagedKV, c_vp]),
     "quest_append_kv_cache_prefill": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, PagedKV, c_vp]),
     "quest_estimate_attn_score": (ctypes.c_int, [c_vp, c_vp, c_u32, c_u32, PagedKV, c_vp]),

@@ -101,6 +101,15 @@ __global__ void step_state_advance_kernel(quest_step_state_t* st, const int32_t*
                            meta_table + (size_t)seq * batch.meta_table_stride, S, max_kv_pages, max_meta_pages);
 }
 
+extern "C" uint32_t quest_pool_slot(uint32_t layout, uint32_t num_heads, uint32_t head, uint32_t entry, int v_slot) {
+    if (layout > QUEST_LAYOUT_NHD_ROT || num_heads == 0 || head >= num_heads) return 0xffffffffu;
+    quest_paged_kv_t p{};
+    p.layout = layout, p.num_heads = num_heads, p.page_size = 1, p.head_dim = 8;  // (only the layout and the head count matter)
+    const PoolStrides st = pool_strides(p);
+    const uint32_t slot = pool_slot(st, head, entry);
+    return v_slot ? slot ^ st.vflip : slot;
+}
+
 int check_pool(const quest_paged_kv_t& p) {
     if (!p.data || !p.indices) return QUEST_EINVAL;
     if (p.layout > QUEST_LAYOUT_NHD_ROT) return QUEST_EINVAL;

@@ -24,6 +24,40 @@ def test_library_exports_every_declared_symbol():
     assert b"begin_forward" in _lib.lib.quest_error_string(-3)
 
 
+def test_pool_slot_of_the_library_is_the_layout_definition_python_restates():
+    """QUEST_LAYOUT_NHD_ROT is defined in ONE place per language: csrc/quest_common.cuh (exported as the host function
+    quest_pool_slot), `TensorLayout.rotation` / `to_logical` in Python and qo_k_off / qo_v_off in the C oracle.  The
+    library's function against the Python restatement for every head count up to 72 and every entry of a 16-entry page, and the
+    properties the kernels rely on: a slot stays inside the row, K and V slots are permutations of the heads, the rotation
+    touches slot bits 0-1 only and the V flip bits 2-4 only (so the K -> V distance is a per-head constant)."""
+    import torch
+
+    from quest_amd._lib import lib
+    from quest_amd.utils.utils import TensorLayout
+
+    for H in range(1, 73):
+        rot, flip = TensorLayout.rotation(H)
+        assert rot in (0, 1, 3) and flip in (0, 4, 12, 28) and (rot & flip) == 0
+        for e in range(16):
+            k_slots = [lib.quest_pool_slot(2, H, h, e, 0) for h in range(H)]
+            v_slots = [lib.quest_pool_slot(2, H, h, e, 1) for h in range(H)]
+            assert k_slots == [h ^ (e & rot) for h in range(H)] and v_slots == [s ^ flip for s in k_slots]
+            assert sorted(k_slots) == list(range(H)) and sorted(v_slots) == list(range(H))
+            assert all(((h ^ k) & ~3) == 0 and ((k ^ v) & ~28) == 0 for h, (k, v) in enumerate(zip(k_slots, v_slots)))
+            for layout in (0, 1):
+                assert [lib.quest_pool_slot(layout, H, h, e, 1) for h in range(H)] == list(range(H))
+        # to_logical on a tagged pool page: element [kv, e, h] of the NHD view is what slot (kv, e, h) of the rotated page holds
+        S = 16
+        page = torch.zeros(1, 2, S, H, 1, dtype=torch.int32)
+        for kv in range(2):
+            for e in range(S):
+                for h in range(H):
+                    page[0, kv, e, lib.quest_pool_slot(2, H, h, e, kv), 0] = 10000 * kv + 100 * e + h
+        want = torch.tensor([[[10000 * kv + 100 * e + h for h in range(H)] for e in range(S)] for kv in range(2)], dtype=torch.int32)
+        assert torch.equal(TensorLayout.to_logical(page, 2)[0, ..., 0], want), H
+    assert lib.quest_pool_slot(3, 8, 0, 0, 0) == 0xffffffff and lib.quest_pool_slot(2, 8, 8, 0, 0) == 0xffffffff
+
+
 def test_c_abi_argument_errors_without_gpu():
     """Argument validation returns error codes before any launch (no GPU needed)."""
     import ctypes
