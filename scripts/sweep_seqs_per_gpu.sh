@@ -4,7 +4,7 @@
 #   scripts/sweep_seqs_per_gpu.sh r05
 R=${1:-r05}
 O=gpurun_out/${R}_seqs_per_gpu_sweep.jsonl; mkdir -p gpurun_out; : > $O
-for n in 1 2 3 4 6 8 12 16; do
+for n in 1 2 3 4 5 6 8 12 16; do
   timeout -k 10 300 python bench.py --seqs-per-gpu $n --steps 100 --warmup 10 --no-side --no-cpu-baseline 2> gpurun_out/${R}_sweep_$n.err | grep '^{' >> $O || { tail -3 gpurun_out/${R}_sweep_$n.err; exit 1; }
 done
 python3 - "$O" <<'PY'
