@@ -256,6 +256,7 @@ class BatchedInferenceController:
         # 11.16 (profiles/r05_sweep_sequences_per_gpu_one_vs_two_launches.txt).  With GQA the query heads of a group would
         # each stream their kv head's metadata (cfg 5: 68.9 vs 58.8 us per layer): two launches.
         self.one_launch_layers = self.num_heads == self.num_kv_heads and self._fills_the_chip(n_seqs * num_heads, device)
+        self.last_layer_launches = None  # 1 / 2: which form utils.decode_layer_batched ran last (its docstring)
 
     @staticmethod
     def _fills_the_chip(workgroups: int, device) -> bool:
