@@ -26,7 +26,9 @@ def ext():
     return mod
 
 
-def test_every_op_of_the_binding_matches_the_python_shim(ext):
+@pytest.mark.parametrize("layout", [0, 2], ids=["NHD", "NHD_ROT"])
+def test_every_op_of_the_binding_matches_the_python_shim(ext, layout):
+    """(layout 2: the row-rotated pool of round 6 -- the binding only passes the layout id through to the C ABI)"""
     from quest_amd import _kernels
     import quest_amd.utils as qu
 
@@ -35,7 +37,7 @@ def test_every_op_of_the_binding_matches_the_python_shim(ext):
     q, k, v = inputs(5, L, Hq, Hkv, D)
     results = []
     for mod in (_kernels, ext):
-        ctl = make_controller(L, Hq, Hkv, D, 16, B, shuffle_seed=3)
+        ctl = make_controller(L, Hq, Hkv, D, 16, B, shuffle_seed=3, layout=layout)
         kc, vc = cuda(k), cuda(v)
         qd = cuda(q)
         qr, kr = qd.clone(), kc[-1:].clone()
@@ -49,7 +51,7 @@ def test_every_op_of_the_binding_matches_the_python_shim(ext):
         ctl.prepare_metadata(L - 1)
         ctl.begin_forward(L - 1)
         mod.append_kv_cache_prefill(kc[:-1], vc[:-1], *args())
-        # prefill attention over the pages just written (bsk_ops.h:84-92): the whole prompt (causal), a 37-row chunk at the
+        # prefill attention over the pages just written (bsk_ops.h:78-86): the whole prompt (causal), a 37-row chunk at the
         # end of the cache (causal, masked) and one row (full attention) -- GQA, K/V not repeated
         qp = cuda(inputs(21, L - 1, Hq, Hkv, D)[1][:, :1].repeat(Hq, axis=1))  # [L-1, Hq, D]
         pre = [mod.prefill_with_paged_kv_cache(x, ctl.kv_cache.buf_layer(0), ctl.kv_indices_with_last, ctl.kv_cache.last_page_len,
